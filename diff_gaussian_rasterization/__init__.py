@@ -1,0 +1,11 @@
+"""Drop-in module name the reference imports (`from diff_gaussian_rasterization import
+GaussianRasterizationSettings, GaussianRasterizer`, /root/reference/src/model/decoder/
+cuda_splatting.py:5-8).  Putting this repository on PYTHONPATH ahead of (or instead of) the CUDA
+pip package routes the reference's decoder to the MI355X-native HIP rasteriser unchanged."""
+from splatter360_amd.rasterizer import (  # noqa: F401
+    GaussianRasterizationSettings,
+    GaussianRasterizer,
+    _RasterizeViews as _RasterizeGaussians,
+)
+
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer"]

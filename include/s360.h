@@ -1,0 +1,153 @@
+/*
+ * s360.h — C ABI of the MI355X-native panoramic Gaussian-splat rasteriser (libs360.so).
+ *
+ * Drop-in boundary for the one native dependency of thucz/splatter360's render path: the
+ * `diff_gaussian_rasterization` extension imported at
+ *     /root/reference/src/model/decoder/cuda_splatting.py:5-8
+ * and called at cuda_splatting.py:99-124 (forward) / by autograd (backward).  The reference
+ * defines no C ABI itself (its extension is a pybind11 module that is not vendored); each entry
+ * point below names the upstream pybind function / reference call site it replaces.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every data pointer is DEVICE memory (HIP, gfx950) unless
+ *     the name ends in _host;  all tensors are contiguous float32 / int32 / uint32;
+ *   - the caller owns every buffer (outputs and workspaces); sizes come from s360_layout();
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), performs NO host
+ *     synchronisation and allocates nothing; kernels are re-entrant across streams/devices;
+ *   - return value: 0 on success, negative S360_E_* otherwise; nothing throws across the ABI;
+ *   - a call renders V views of ONE Gaussian cloud (V = 1 reproduces one reference rasteriser
+ *     call; V = 6 renders the six cube faces of an equirectangular view in one fused pass,
+ *     replacing the per-face Python loop at src/model/decoder/decoder_splatting_cuda.py:47-59).
+ */
+#ifndef S360_H
+#define S360_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define S360_ABI_VERSION 1
+#define S360_MAX_VIEWS 8
+#define S360_TILE 16
+
+enum {
+    S360_OK = 0,
+    S360_E_BADARG = -1,    /* null pointer / non-positive size / V > S360_MAX_VIEWS */
+    S360_E_WORKSPACE = -2, /* workspace smaller than s360_layout() reports */
+    S360_E_LAUNCH = -3,    /* hipGetLastError() != hipSuccess after a launch */
+    S360_E_UNSUPPORTED = -4
+};
+
+/* flags */
+#define S360_FLAG_SHARED_CAMPOS 1u /* all V views share campos: SH->RGB evaluated once per Gaussian */
+
+/*
+ * One camera, exactly the per-call fields of GaussianRasterizationSettings
+ * (cuda_splatting.py:99-112).  42 floats, lives in DEVICE memory (array of V).
+ * viewmatrix / projmatrix are the flat [4,4] tensors handed over at cuda_splatting.py:86-87
+ * (row-vector convention: element [r][c] of the transposed matrix at index 4*r+c).
+ */
+typedef struct S360View {
+    float viewmatrix[16];
+    float projmatrix[16];
+    float campos[3];
+    float tanfovx, tanfovy;
+    float bg[3];
+} S360View;
+
+typedef struct S360Params {
+    int32_t P;              /* Gaussians */
+    int32_t V;              /* views rendered by this call (1..S360_MAX_VIEWS) */
+    int32_t H, W;           /* image size of every view */
+    int32_t sh_degree;      /* active SH degree 0..4 (settings.sh_degree) */
+    int32_t M;              /* SH coefficients stored per Gaussian per channel (shs.shape[1]); 0 = colors_precomp */
+    uint32_t flags;         /* S360_FLAG_* */
+    uint32_t max_instances; /* capacity of the binning buffers ((Gaussian,tile) pairs, "num_rendered") */
+} S360Params;
+
+/* Byte offsets of every array inside the forward workspace (state kept for backward and exposed
+ * for parity tests: upstream's geomBuffer / binningBuffer / imgBuffer). */
+typedef struct S360Layout {
+    size_t total_bytes;         /* forward workspace size */
+    size_t header;              /* uint32[64]: [0]=num_instances [1]=overflow flag [2]=max tile list length */
+    size_t tiles_touched;       /* uint32[V*P] */
+    size_t offsets;             /* uint32[V*P]  inclusive scan of tiles_touched (upstream point_offsets) */
+    size_t scan_scratch;        /* uint32[...] */
+    size_t rec_a;               /* float4[V*P]  x, y, conic.a, conic.b */
+    size_t rec_b;               /* float4[V*P]  conic.c, opacity, r, g */
+    size_t rec_c;               /* float4[V*P]  b, depth, rect_min (x | y<<16), rect_max (x | y<<16) */
+    size_t clamped;             /* uint8[V*P]   bit c set: colour channel c was clamped at 0 */
+    size_t tile_count;          /* uint32[V*T] */
+    size_t tile_start;          /* uint32[V*T+1] exclusive scan (upstream ranges: [start[t], start[t+1])) */
+    size_t tile_cursor;         /* uint32[V*T] */
+    size_t keys;                /* uint64[max_instances]  (depth bits << 32 | pair index), sorted per tile */
+    size_t list;                /* uint32[max_instances]  sorted pair indices p = v*P + g (upstream point_list) */
+    size_t final_T;             /* float[V*H*W] */
+    size_t n_contrib;           /* uint32[V*H*W] */
+    size_t tile_max_contrib;    /* uint32[V*T] */
+    size_t backward_bytes;      /* size of the separate backward scratch workspace */
+} S360Layout;
+
+/* ABI version of the loaded library (== S360_ABI_VERSION). */
+int s360_abi_version(void);
+const char* s360_error_string(int code);
+
+/* Workspace layout / sizes for the given problem (pure host arithmetic). */
+int s360_layout(const S360Params* prm, S360Layout* out);
+
+/*
+ * Forward: replaces upstream `rasterize_gaussians(...)` as reached from
+ * GaussianRasterizer.forward (call site cuda_splatting.py:117-124).
+ *   views[V] (device)  means3D[P,3]  cov6[P,6] (cov3D_precomp, order 00,01,02,11,12,22)
+ *   opacities[P]  shs[P,M,3] or NULL  colors_precomp[P,3] or NULL (exactly one non-NULL)
+ * Outputs: images[V,3,H,W], radii[V,P] (int32), plus state in `workspace`.
+ */
+int s360_forward(const S360Params* prm, const S360View* views, const float* means3D,
+                 const float* cov6, const float* opacities, const float* shs,
+                 const float* colors_precomp, float* images, int32_t* radii, void* workspace,
+                 size_t workspace_bytes, void* stream);
+
+/*
+ * Backward: replaces upstream `rasterize_gaussians_backward(...)` (autograd backward of the
+ * call above).  `workspace` is the forward workspace, unmodified since s360_forward.
+ *   dL_dimages[V,3,H,W]
+ * Outputs (all written, no accumulation into caller data):
+ *   d_means3D[P,3]  d_means2D[V,P,3] (NDC-scaled screen-space gradient, z = 0)
+ *   d_cov6[P,6]  d_opacities[P]  d_shs[P,M,3] or NULL  d_colors[P,3] or NULL
+ * Gradients are summed over the V views with a fixed (deterministic) order.
+ */
+int s360_backward(const S360Params* prm, const S360View* views, const float* means3D,
+                  const float* cov6, const float* opacities, const float* shs,
+                  const float* colors_precomp, const void* workspace, size_t workspace_bytes,
+                  const float* dL_dimages, float* d_means3D, float* d_means2D, float* d_cov6,
+                  float* d_opacities, float* d_shs, float* d_colors, void* bwd_workspace,
+                  size_t bwd_workspace_bytes, void* stream);
+
+/*
+ * Cube -> equirectangular stitch: replaces Cube2Equirec.forward
+ * (/root/reference/src/geometry/layers.py:108-116, F.grid_sample trilinear / border /
+ * align_corners=True over the [C,6,fw,fw] face stack).
+ *   faces[6,C,fw,fw] in Cube2Equirec's slot order (F R B L U D) when face_map == NULL, else
+ *   slot s reads faces[face_map[s] & 7] and, when bit 3 of face_map[s] is set, flipped on both
+ *   image axes — face_map = {3, 4, 1, 2, 0|8, 5|8} applies the reference's change_order()
+ *   (src/model/model_wrapper_erp.py:135-145) to faces given in rendered order (U B L F R D)
+ *   without materialising the permuted copy.  face_map_host is read on the HOST.
+ *   grid[eh,ew,3] = Cube2Equirec.sample_grid (u, v, face-z);  erp[C,eh,ew].
+ */
+int s360_cube2erp_forward(const float* faces, const float* grid, float* erp, int32_t channels,
+                          int32_t face_w, int32_t equ_h, int32_t equ_w,
+                          const int32_t* face_map_host, void* stream);
+
+/* Adjoint of the stitch: d_faces[6,C,fw,fw] (same face order / face_map as forward) is
+ * ZEROED then accumulated with float atomics (non-deterministic summation order). */
+int s360_cube2erp_backward(const float* d_erp, const float* grid, float* d_faces,
+                           int32_t channels, int32_t face_w, int32_t equ_h, int32_t equ_w,
+                           const int32_t* face_map_host, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* S360_H */

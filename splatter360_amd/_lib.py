@@ -1,0 +1,112 @@
+"""Loader / builder of the C-ABI shared library libs360.so (include/s360.h).
+
+The product path has NO fallback: if the HIP library is missing or cannot be loaded, every
+operator raises.  `build()` cross-compiles for gfx950 with hipcc (works without a GPU).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+_PKG = Path(__file__).resolve().parent
+_CSRC = _PKG / "csrc"
+LIB_PATH = _PKG / "libs360.so"
+SOURCES = ("s360_forward.hip", "s360_backward.hip", "s360_stitch.hip")
+HIPCC_FLAGS = ("--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+               "-Wno-unused-result")
+
+S360_MAX_VIEWS = 8
+FLAG_SHARED_CAMPOS = 1
+
+
+class S360Params(C.Structure):
+    _fields_ = [("P", C.c_int32), ("V", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("sh_degree", C.c_int32), ("M", C.c_int32), ("flags", C.c_uint32),
+                ("max_instances", C.c_uint32)]
+
+
+class S360Layout(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in (
+        "total_bytes", "header", "tiles_touched", "offsets", "scan_scratch", "rec_a", "rec_b", "rec_c",
+        "clamped", "tile_count", "tile_start", "tile_cursor", "keys", "list", "final_T", "n_contrib",
+        "tile_max_contrib", "backward_bytes")]
+
+
+EXPORTS = ("s360_abi_version", "s360_error_string", "s360_layout", "s360_forward", "s360_backward",
+           "s360_cube2erp_forward", "s360_cube2erp_backward")
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found; cannot build libs360.so")
+
+
+def needs_build() -> bool:
+    if not LIB_PATH.exists():
+        return True
+    t = LIB_PATH.stat().st_mtime
+    deps = [_CSRC / s for s in SOURCES] + [_CSRC / "s360_device.h", _PKG.parent / "include" / "s360.h"]
+    return any(d.stat().st_mtime > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    """hipcc --offload-arch=gfx950 ... -> splatter360_amd/libs360.so (in-tree)."""
+    if not force and not needs_build():
+        return LIB_PATH
+    cmd = [_hipcc(), *HIPCC_FLAGS, *[str(_CSRC / s) for s in SOURCES], "-o", str(LIB_PATH)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or r.returncode:
+        print(" ".join(cmd))
+        print(r.stdout, r.stderr)
+    if r.returncode:
+        raise RuntimeError("hipcc failed building libs360.so:\n" + r.stderr[-4000:])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """The loaded library.  Raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP rasteriser was not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). There is no CPU fallback.")
+    l = C.CDLL(str(LIB_PATH))
+    vp, i32, sz = C.c_void_p, C.c_int32, C.c_size_t
+    l.s360_abi_version.restype = C.c_int
+    l.s360_error_string.restype = C.c_char_p
+    l.s360_error_string.argtypes = [C.c_int]
+    l.s360_layout.restype = C.c_int
+    l.s360_layout.argtypes = [C.POINTER(S360Params), C.POINTER(S360Layout)]
+    l.s360_forward.restype = C.c_int
+    l.s360_forward.argtypes = [C.POINTER(S360Params)] + [vp] * 9 + [sz, vp]
+    l.s360_backward.restype = C.c_int
+    l.s360_backward.argtypes = [C.POINTER(S360Params)] + [vp] * 7 + [sz] + [vp] * 8 + [sz, vp]
+    l.s360_cube2erp_forward.restype = C.c_int
+    l.s360_cube2erp_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, C.POINTER(i32), vp]
+    l.s360_cube2erp_backward.restype = C.c_int
+    l.s360_cube2erp_backward.argtypes = [vp, vp, vp, i32, i32, i32, i32, C.POINTER(i32), vp]
+    if l.s360_abi_version() != 1:
+        raise RuntimeError("libs360.so ABI version mismatch")
+    _lib = l
+    return l
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        raise RuntimeError(f"{what} failed: {lib().s360_error_string(code).decode()} ({code})")
+
+
+def layout(prm: S360Params) -> S360Layout:
+    out = S360Layout()
+    check(lib().s360_layout(C.byref(prm), C.byref(out)), "s360_layout")
+    return out

@@ -1,0 +1,464 @@
+// s360_backward.hip — backward kernels.  gfx950 / wave64 only.
+//
+//   k_zero_inst        zero the per-instance raster-gradient slots [0, num_instances)
+//   k_render_bwd       1 workgroup per tile, back-to-front replay from final_T / n_contrib.
+//                      Per splat the 9 raster gradients are reduced over the 64 pixels of a wave
+//                      with DPP adds (no LDS, no atomics), the 4 waves meet in LDS, and ONE
+//                      record per (tile, splat) instance is written — the slot index is the
+//                      instance's position in emission order (grouped by (view, Gaussian) pair).
+//   k_preprocess_bwd   1 thread per Gaussian: gathers its instances (contiguous, deterministic
+//                      order), chains conic -> cov2D -> cov3D / mean, projection -> mean,
+//                      SH -> dL/dSH + view-direction term, sums the V views in registers and
+//                      writes each 340-byte gradient exactly once (SH slab staged through LDS).
+// No float atomics anywhere: gradients are bit-reproducible run to run.
+#include "s360_device.h"
+
+namespace s360 {
+
+constexpr int BWD_BATCH = 128;
+constexpr int GREC = 12;  // floats per instance record: gx gy gA gB | gC gop gr gg | gb - - -
+
+__global__ __launch_bounds__(S360_BLOCK) void k_zero_inst(float4* __restrict__ inst_grad, const uint32_t* __restrict__ header,
+                                                         uint32_t cap) {
+    const size_t n4 = (size_t)min(header[0], cap) * (GREC / 4);
+    for (size_t i = (size_t)blockIdx.x * S360_BLOCK + threadIdx.x; i < n4; i += (size_t)gridDim.x * S360_BLOCK)
+        inst_grad[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+__global__ __launch_bounds__(S360_BLOCK) void k_render_bwd(
+    KParams kp, const S360View* __restrict__ views, const uint32_t* __restrict__ tile_start,
+    const uint32_t* __restrict__ list, const uint32_t* __restrict__ offsets, const float4* __restrict__ recA,
+    const float4* __restrict__ recB, const float4* __restrict__ recC, const float* __restrict__ final_T,
+    const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ tile_max_contrib,
+    const float* __restrict__ dL_dimages, float4* __restrict__ inst_grad) {
+    __shared__ float4 sA[BWD_BATCH];
+    __shared__ float4 sB[BWD_BATCH];
+    __shared__ float sC[BWD_BATCH];
+    __shared__ uint32_t sInst[BWD_BATCH];
+    __shared__ float4 sAcc[4][BWD_BATCH][GREC / 4];
+
+    const int t = blockIdx.x;
+    const int v = t / kp.T, rem = t - v * kp.T;
+    const int ty = rem / kp.gx, tx = rem - ty * kp.gx;
+    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int px = tx * 16 + lx, py = ty * 16 + ly;
+    const bool inside = px < kp.W && py < kp.H;
+    const float pxf = (float)px, pyf = (float)py;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+
+    const uint32_t start = min(tile_start[t], kp.cap);
+    const uint32_t maxc = tile_max_contrib[t];  // entries [0, maxc) of this tile's list can contribute
+    if (maxc == 0) return;
+
+    const size_t hw = (size_t)kp.H * kp.W;
+    const size_t pix = (size_t)py * kp.W + px;
+    const S360View& vw = views[v];
+    float T_final = 0.f, dp0 = 0.f, dp1 = 0.f, dp2 = 0.f;
+    uint32_t last = 0;
+    if (inside) {
+        T_final = final_T[(size_t)v * hw + pix];
+        last = n_contrib[(size_t)v * hw + pix];
+        const float* dimg = dL_dimages + (size_t)v * 3 * hw;
+        dp0 = dimg[pix];
+        dp1 = dimg[hw + pix];
+        dp2 = dimg[2 * hw + pix];
+    }
+    const float bg_dot = vw.bg[0] * dp0 + vw.bg[1] * dp1 + vw.bg[2] * dp2;
+    float T = T_final;
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_alpha = 0.f;
+
+    // batches walk the list back to front; batch element j is list entry (hi - j)
+    for (int64_t hi = (int64_t)maxc - 1; hi >= 0; hi -= BWD_BATCH) {
+        const int cnt = (int)min((int64_t)BWD_BATCH, hi + 1);
+        __syncthreads();
+        if ((int)threadIdx.x < cnt) {
+            const uint32_t idx = (uint32_t)(hi - threadIdx.x);
+            const uint32_t p = list[start + idx];
+            const float4 c = recC[p];
+            sA[threadIdx.x] = recA[p];
+            sB[threadIdx.x] = recB[p];
+            sC[threadIdx.x] = c.x;
+            const uint32_t rmin = __float_as_uint(c.z), rmax = __float_as_uint(c.w);
+            const int minx = rmin & 0xFFFF, miny = rmin >> 16, maxx = rmax & 0xFFFF;
+            const uint32_t base = p == 0 ? 0u : offsets[p - 1];
+            sInst[threadIdx.x] = base + (uint32_t)((ty - miny) * (maxx - minx) + (tx - minx));
+        }
+        {
+            float4* z = &sAcc[0][0][0];
+            for (int i = threadIdx.x; i < 4 * BWD_BATCH * (GREC / 4); i += S360_BLOCK) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+        for (int j = 0; j < cnt; ++j) {
+            const uint32_t contributor = (uint32_t)(hi - j);  // 0-based position in the list
+            float g_x = 0.f, g_y = 0.f, g_A = 0.f, g_B = 0.f, g_C = 0.f, g_op = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f;
+            bool active = false;
+            if (contributor < last) {
+                const float4 a = sA[j];
+                const float4 bb = sB[j];
+                const float dx = a.x - pxf, dy = a.y - pyf;
+                const float power = -0.5f * (a.z * dx * dx + bb.x * dy * dy) - a.w * dx * dy;
+                if (power <= 0.0f) {
+                    const float G = __expf(power);
+                    const float alpha = fminf(0.99f, bb.y * G);
+                    if (alpha >= 1.0f / 255.0f) {
+                        active = true;
+                        T = T / (1.0f - alpha);
+                        const float dchannel_dcolor = alpha * T;
+                        const float c0 = bb.z, c1 = bb.w, c2 = sC[j];
+                        acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
+                        acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
+                        acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2;
+                        lc0 = c0; lc1 = c1; lc2 = c2;
+                        float dL_dalpha = (c0 - acc0) * dp0 + (c1 - acc1) * dp1 + (c2 - acc2) * dp2;
+                        g_r = dchannel_dcolor * dp0;
+                        g_g = dchannel_dcolor * dp1;
+                        g_b = dchannel_dcolor * dp2;
+                        dL_dalpha *= T;
+                        last_alpha = alpha;
+                        dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+                        const float dL_dG = bb.y * dL_dalpha;
+                        const float gdx = G * dx, gdy = G * dy;
+                        const float dG_ddelx = -gdx * a.z - gdy * a.w;
+                        const float dG_ddely = -gdy * bb.x - gdx * a.w;
+                        g_x = dL_dG * dG_ddelx;
+                        g_y = dL_dG * dG_ddely;
+                        g_A = -0.5f * gdx * dx * dL_dG;
+                        g_B = -gdx * dy * dL_dG;
+                        g_C = -0.5f * gdy * dy * dL_dG;
+                        g_op = G * dL_dalpha;
+                    }
+                }
+            }
+            if (__ballot(active) == 0ull) continue;  // wave-uniform skip: nothing to reduce
+            g_x = wave_sum_lane63(g_x);
+            g_y = wave_sum_lane63(g_y);
+            g_A = wave_sum_lane63(g_A);
+            g_B = wave_sum_lane63(g_B);
+            g_C = wave_sum_lane63(g_C);
+            g_op = wave_sum_lane63(g_op);
+            g_r = wave_sum_lane63(g_r);
+            g_g = wave_sum_lane63(g_g);
+            g_b = wave_sum_lane63(g_b);
+            if (lane == 63) {
+                sAcc[wave][j][0] = make_float4(g_x, g_y, g_A, g_B);
+                sAcc[wave][j][1] = make_float4(g_C, g_op, g_r, g_g);
+                sAcc[wave][j][2] = make_float4(g_b, 0.f, 0.f, 0.f);
+            }
+        }
+        __syncthreads();
+        // 4 waves -> one record per instance; thread (j, q) handles quarter-record q of entry j
+        for (int w = threadIdx.x; w < cnt * (GREC / 4); w += S360_BLOCK) {
+            const int j = w / (GREC / 4), q = w - j * (GREC / 4);
+            const float4 s0 = sAcc[0][j][q], s1 = sAcc[1][j][q], s2 = sAcc[2][j][q], s3 = sAcc[3][j][q];
+            float4 r;
+            r.x = ((s0.x + s1.x) + s2.x) + s3.x;
+            r.y = ((s0.y + s1.y) + s2.y) + s3.y;
+            r.z = ((s0.z + s1.z) + s2.z) + s3.z;
+            r.w = ((s0.w + s1.w) + s2.w) + s3.w;
+            const uint32_t inst = sInst[j];
+            if (inst < kp.cap) inst_grad[(size_t)inst * (GREC / 4) + q] = r;
+        }
+    }
+}
+
+template <bool USE_SH>
+__global__ __launch_bounds__(S360_BLOCK) void k_preprocess_bwd(
+    KParams kp, const S360View* __restrict__ views, const float* __restrict__ means, const float* __restrict__ cov6,
+    const float* __restrict__ shs, const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ offsets,
+    const uint8_t* __restrict__ clamped, const float4* __restrict__ inst_grad, float* __restrict__ d_means3D,
+    float* __restrict__ d_means2D, float* __restrict__ d_cov6, float* __restrict__ d_opac, float* __restrict__ d_shs,
+    float* __restrict__ d_colors) {
+    extern __shared__ __attribute__((aligned(16))) float lds_sh[];  // [256*M*3] SH slab, then [256*V*3] dRGB
+    const int tid = threadIdx.x;
+    const int g0 = blockIdx.x * S360_BLOCK;
+    const int g = g0 + tid;
+    const int P = kp.P;
+    const int nb = min(S360_BLOCK, P - g0);
+    const int nfl = nb * kp.M * 3;
+    float* lds_drgb = lds_sh + S360_BLOCK * kp.M * 3;  // per-thread, per-view dRGB (non-shared campos)
+    const bool want_sh = USE_SH && d_shs != nullptr;
+
+    if (want_sh) {
+        const float* src = shs + (size_t)g0 * kp.M * 3;
+        if ((((uintptr_t)src) & 15) == 0) {
+            const int n4 = nfl >> 2;
+            const float4* s4 = reinterpret_cast<const float4*>(src);
+            float4* d4 = reinterpret_cast<float4*>(lds_sh);
+            for (int i = tid; i < n4; i += S360_BLOCK) d4[i] = s4[i];
+            for (int i = (n4 << 2) + tid; i < nfl; i += S360_BLOCK) lds_sh[i] = src[i];
+        } else {
+            for (int i = tid; i < nfl; i += S360_BLOCK) lds_sh[i] = src[i];
+        }
+        __syncthreads();
+    }
+
+    const bool shared_cam = (kp.flags & S360_FLAG_SHARED_CAMPOS) != 0;
+    const int n_sh = (kp.deg + 1) * (kp.deg + 1);
+    if (g < P) {
+        const float mx = means[3 * g], my = means[3 * g + 1], mz = means[3 * g + 2];
+        float c6[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) c6[k] = cov6[6 * (size_t)g + k];
+        float dm0 = 0.f, dm1 = 0.f, dm2 = 0.f, dop = 0.f;
+        float dc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float drgb_sum[3] = {0.f, 0.f, 0.f};  // clamp-masked, summed over views
+        float dcol_sum[3] = {0.f, 0.f, 0.f};  // colors_precomp gradient
+        bool any_visible = false;
+        int first_visible = -1;
+
+        for (int v = 0; v < kp.V; ++v) {
+            const size_t p = (size_t)v * P + g;
+            float gx_ = 0.f, gy_ = 0.f;
+            float drgb_v[3] = {0.f, 0.f, 0.f};
+            if (tiles_touched[p] != 0) {
+                any_visible = true;
+                if (first_visible < 0) first_visible = v;
+                const uint32_t i0 = p == 0 ? 0u : offsets[p - 1];
+                const uint32_t i1 = min(offsets[p], kp.cap);
+                float gA = 0.f, gB = 0.f, gC = 0.f, gop = 0.f, gr = 0.f, gg = 0.f, gb = 0.f;
+                for (uint32_t i = i0; i < i1; ++i) {
+                    const float4 r0 = inst_grad[(size_t)i * 3], r1 = inst_grad[(size_t)i * 3 + 1], r2 = inst_grad[(size_t)i * 3 + 2];
+                    gx_ += r0.x; gy_ += r0.y; gA += r0.z; gB += r0.w;
+                    gC += r1.x; gop += r1.y; gr += r1.z; gg += r1.w;
+                    gb += r2.x;
+                }
+                dop += gop;
+                const S360View& vw = views[v];
+                const float* V = vw.viewmatrix;
+                Geo ge;
+                geo_compute(V, vw.tanfovx, vw.tanfovy, kp.W, kp.H, mx, my, mz, c6, ge);
+                const float a = ge.a, b = ge.b, c = ge.c;
+                const float det = a * c - b * b;
+                const float d2inv = 1.0f / (det * det + 0.0000001f);
+                float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
+                if (d2inv != 0.f) {
+                    dL_da = d2inv * (-c * c * gA + b * c * gB + (det - a * c) * gC);
+                    dL_dc = d2inv * (-a * a * gC + a * b * gB + (det - a * c) * gA);
+                    dL_db = d2inv * (2.f * b * c * gA - (det + 2.f * b * b) * gB + 2.f * a * b * gC);
+                    const float *M0 = ge.M0, *M1 = ge.M1;
+                    dc[0] += M0[0] * M0[0] * dL_da + M0[0] * M1[0] * dL_db + M1[0] * M1[0] * dL_dc;
+                    dc[3] += M0[1] * M0[1] * dL_da + M0[1] * M1[1] * dL_db + M1[1] * M1[1] * dL_dc;
+                    dc[5] += M0[2] * M0[2] * dL_da + M0[2] * M1[2] * dL_db + M1[2] * M1[2] * dL_dc;
+                    dc[1] += 2.f * M0[0] * M0[1] * dL_da + (M0[0] * M1[1] + M0[1] * M1[0]) * dL_db + 2.f * M1[0] * M1[1] * dL_dc;
+                    dc[2] += 2.f * M0[0] * M0[2] * dL_da + (M0[0] * M1[2] + M0[2] * M1[0]) * dL_db + 2.f * M1[0] * M1[2] * dL_dc;
+                    dc[4] += 2.f * M0[1] * M0[2] * dL_da + (M0[1] * M1[2] + M0[2] * M1[1]) * dL_db + 2.f * M1[1] * M1[2] * dL_dc;
+                }
+                float dM0[3], dM1[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    dM0[j] = 2.f * dL_da * ge.v0[j] + dL_db * ge.v1[j];
+                    dM1[j] = 2.f * dL_dc * ge.v1[j] + dL_db * ge.v0[j];
+                }
+                float dJ00 = 0.f, dJ02 = 0.f, dJ11 = 0.f, dJ12 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    dJ00 += dM0[j] * V[j * 4 + 0];
+                    dJ02 += dM0[j] * V[j * 4 + 2];
+                    dJ11 += dM1[j] * V[j * 4 + 1];
+                    dJ12 += dM1[j] * V[j * 4 + 2];
+                }
+                const float tz = 1.f / ge.tz, tz2 = tz * tz, tz3 = tz2 * tz;
+                const float dt0 = (ge.xin ? 1.f : 0.f) * (-ge.fx * tz2 * dJ02);
+                const float dt1 = (ge.yin ? 1.f : 0.f) * (-ge.fy * tz2 * dJ12);
+                const float dt2 = -ge.fx * tz2 * dJ00 - ge.fy * tz2 * dJ11 + (2.f * ge.fx * ge.txc) * tz3 * dJ02 +
+                                  (2.f * ge.fy * ge.tyc) * tz3 * dJ12;
+                dm0 += V[0] * dt0 + V[1] * dt1 + V[2] * dt2;
+                dm1 += V[4] * dt0 + V[5] * dt1 + V[6] * dt2;
+                dm2 += V[8] * dt0 + V[9] * dt1 + V[10] * dt2;
+                // projection chain (NDC-scaled screen-space gradient)
+                const float m2x = gx_ * (0.5f * (float)kp.W), m2y = gy_ * (0.5f * (float)kp.H);
+                gx_ = m2x;
+                gy_ = m2y;
+                const float* Pm = vw.projmatrix;
+                const float mhx = Pm[0] * mx + Pm[4] * my + Pm[8] * mz + Pm[12];
+                const float mhy = Pm[1] * mx + Pm[5] * my + Pm[9] * mz + Pm[13];
+                const float mhw = Pm[3] * mx + Pm[7] * my + Pm[11] * mz + Pm[15];
+                const float mw = 1.f / (mhw + 0.0000001f);
+                const float mul1 = mhx * mw * mw, mul2 = mhy * mw * mw;
+                dm0 += (Pm[0] * mw - Pm[3] * mul1) * m2x + (Pm[1] * mw - Pm[3] * mul2) * m2y;
+                dm1 += (Pm[4] * mw - Pm[7] * mul1) * m2x + (Pm[5] * mw - Pm[7] * mul2) * m2y;
+                dm2 += (Pm[8] * mw - Pm[11] * mul1) * m2x + (Pm[9] * mw - Pm[11] * mul2) * m2y;
+                if (USE_SH) {
+                    const uint32_t cb = clamped[p];
+                    drgb_v[0] = (cb & 1u) ? 0.f : gr;
+                    drgb_v[1] = (cb & 2u) ? 0.f : gg;
+                    drgb_v[2] = (cb & 4u) ? 0.f : gb;
+                    drgb_sum[0] += drgb_v[0];
+                    drgb_sum[1] += drgb_v[1];
+                    drgb_sum[2] += drgb_v[2];
+                } else {
+                    dcol_sum[0] += gr;
+                    dcol_sum[1] += gg;
+                    dcol_sum[2] += gb;
+                }
+            }
+            if (d_means2D) {
+                d_means2D[3 * p] = gx_;
+                d_means2D[3 * p + 1] = gy_;
+                d_means2D[3 * p + 2] = 0.f;
+            }
+            if (want_sh && !shared_cam) {
+                // view-direction term per view (campos differs); dRGB kept for the dSH pass
+                float* dr = lds_drgb + (tid * kp.V + v) * 3;
+                dr[0] = drgb_v[0]; dr[1] = drgb_v[1]; dr[2] = drgb_v[2];
+                if (tiles_touched[p] != 0) {
+                    const S360View& vw = views[v];
+                    const float ddx = mx - vw.campos[0], ddy = my - vw.campos[1], ddz = mz - vw.campos[2];
+                    const float inv = 1.f / sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
+                    const float x = ddx * inv, y = ddy * inv, z = ddz * inv;
+                    float bx[25], by[25], bz[25];
+                    sh_basis_grad(kp.deg, x, y, z, bx, by, bz);
+                    const float* sh = lds_sh + tid * kp.M * 3;
+                    float q0 = 0.f, q1 = 0.f, q2 = 0.f;
+                    for (int k = 0; k < n_sh; ++k) {
+                        const float s = sh[k * 3] * drgb_v[0] + sh[k * 3 + 1] * drgb_v[1] + sh[k * 3 + 2] * drgb_v[2];
+                        q0 += bx[k] * s; q1 += by[k] * s; q2 += bz[k] * s;
+                    }
+                    const float dot = x * q0 + y * q1 + z * q2;
+                    dm0 += (q0 - x * dot) * inv;
+                    dm1 += (q1 - y * dot) * inv;
+                    dm2 += (q2 - z * dot) * inv;
+                }
+            }
+        }
+
+        if (want_sh) {
+            float* sh = lds_sh + tid * kp.M * 3;
+            if (shared_cam) {
+                if (any_visible) {
+                    const S360View& vw = views[first_visible];
+                    const float ddx = mx - vw.campos[0], ddy = my - vw.campos[1], ddz = mz - vw.campos[2];
+                    const float inv = 1.f / sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
+                    const float x = ddx * inv, y = ddy * inv, z = ddz * inv;
+                    float Y[25], bx[25], by[25], bz[25];
+                    sh_basis(kp.deg, x, y, z, Y);
+                    sh_basis_grad(kp.deg, x, y, z, bx, by, bz);
+                    float q0 = 0.f, q1 = 0.f, q2 = 0.f;
+                    for (int k = 0; k < n_sh; ++k) {
+                        const float s = sh[k * 3] * drgb_sum[0] + sh[k * 3 + 1] * drgb_sum[1] + sh[k * 3 + 2] * drgb_sum[2];
+                        q0 += bx[k] * s; q1 += by[k] * s; q2 += bz[k] * s;
+                        sh[k * 3] = Y[k] * drgb_sum[0];
+                        sh[k * 3 + 1] = Y[k] * drgb_sum[1];
+                        sh[k * 3 + 2] = Y[k] * drgb_sum[2];
+                    }
+                    for (int k = n_sh * 3; k < kp.M * 3; ++k) sh[k] = 0.f;
+                    const float dot = x * q0 + y * q1 + z * q2;
+                    dm0 += (q0 - x * dot) * inv;
+                    dm1 += (q1 - y * dot) * inv;
+                    dm2 += (q2 - z * dot) * inv;
+                } else {
+                    for (int k = 0; k < kp.M * 3; ++k) sh[k] = 0.f;
+                }
+            } else {
+                for (int k = 0; k < kp.M * 3; ++k) sh[k] = 0.f;
+                for (int v = 0; v < kp.V; ++v) {
+                    const size_t p = (size_t)v * P + g;
+                    if (tiles_touched[p] == 0) continue;
+                    const S360View& vw = views[v];
+                    const float ddx = mx - vw.campos[0], ddy = my - vw.campos[1], ddz = mz - vw.campos[2];
+                    const float inv = 1.f / sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
+                    float Y[25];
+                    sh_basis(kp.deg, ddx * inv, ddy * inv, ddz * inv, Y);
+                    const float* dr = lds_drgb + (tid * kp.V + v) * 3;
+                    for (int k = 0; k < n_sh; ++k) {
+                        sh[k * 3] += Y[k] * dr[0];
+                        sh[k * 3 + 1] += Y[k] * dr[1];
+                        sh[k * 3 + 2] += Y[k] * dr[2];
+                    }
+                }
+            }
+        }
+        d_means3D[3 * g] = dm0;
+        d_means3D[3 * g + 1] = dm1;
+        d_means3D[3 * g + 2] = dm2;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) d_cov6[6 * (size_t)g + k] = dc[k];
+        d_opac[g] = dop;
+        if (!USE_SH && d_colors) {
+            d_colors[3 * g] = dcol_sum[0];
+            d_colors[3 * g + 1] = dcol_sum[1];
+            d_colors[3 * g + 2] = dcol_sum[2];
+        }
+    }
+    if (want_sh) {
+        __syncthreads();
+        float* dst = d_shs + (size_t)g0 * kp.M * 3;
+        if ((((uintptr_t)dst) & 15) == 0) {
+            const int n4 = nfl >> 2;
+            float4* o4 = reinterpret_cast<float4*>(dst);
+            const float4* l4 = reinterpret_cast<const float4*>(lds_sh);
+            for (int i = tid; i < n4; i += S360_BLOCK) o4[i] = l4[i];
+            for (int i = (n4 << 2) + tid; i < nfl; i += S360_BLOCK) dst[i] = lds_sh[i];
+        } else {
+            for (int i = tid; i < nfl; i += S360_BLOCK) dst[i] = lds_sh[i];
+        }
+    }
+}
+
+}  // namespace s360
+
+using namespace s360;
+
+#define S360_CHECK_LAUNCH()                                        \
+    do {                                                           \
+        if (hipGetLastError() != hipSuccess) return S360_E_LAUNCH; \
+    } while (0)
+
+extern "C" int s360_backward(const S360Params* prm, const S360View* views, const float* means3D, const float* cov6,
+                             const float* opacities, const float* shs, const float* colors_precomp,
+                             const void* workspace, size_t workspace_bytes, const float* dL_dimages, float* d_means3D,
+                             float* d_means2D, float* d_cov6, float* d_opacities, float* d_shs, float* d_colors,
+                             void* bwd_workspace, size_t bwd_workspace_bytes, void* stream_) {
+    (void)opacities;
+    if (!prm || !views || !workspace || !dL_dimages || !bwd_workspace) return S360_E_BADARG;
+    if ((shs == nullptr) == (colors_precomp == nullptr)) return S360_E_BADARG;
+    if (prm->P > 0 && (!means3D || !cov6 || !d_means3D || !d_cov6 || !d_opacities)) return S360_E_BADARG;
+    S360Layout L;
+    int rc = s360_layout(prm, &L);
+    if (rc) return rc;
+    if (workspace_bytes < L.total_bytes || bwd_workspace_bytes < L.backward_bytes) return S360_E_WORKSPACE;
+    if (prm->P == 0) return S360_OK;
+    hipStream_t st = (hipStream_t)stream_;
+    const char* ws = (const char*)workspace;
+
+    KParams kp;
+    kp.P = prm->P; kp.V = prm->V; kp.H = prm->H; kp.W = prm->W; kp.deg = prm->sh_degree; kp.M = prm->M;
+    kp.gx = (prm->W + 15) / 16; kp.gy = (prm->H + 15) / 16; kp.T = kp.gx * kp.gy;
+    kp.flags = prm->flags; kp.cap = prm->max_instances;
+    const int nt = kp.V * kp.T;
+
+    const uint32_t* header = (const uint32_t*)(ws + L.header);
+    const uint32_t* tiles_touched = (const uint32_t*)(ws + L.tiles_touched);
+    const uint32_t* offsets = (const uint32_t*)(ws + L.offsets);
+    const float4* recA = (const float4*)(ws + L.rec_a);
+    const float4* recB = (const float4*)(ws + L.rec_b);
+    const float4* recC = (const float4*)(ws + L.rec_c);
+    const uint8_t* clamped = (const uint8_t*)(ws + L.clamped);
+    const uint32_t* tile_start = (const uint32_t*)(ws + L.tile_start);
+    const uint32_t* list = (const uint32_t*)(ws + L.list);
+    const float* final_T = (const float*)(ws + L.final_T);
+    const uint32_t* n_contrib = (const uint32_t*)(ws + L.n_contrib);
+    const uint32_t* tile_max_contrib = (const uint32_t*)(ws + L.tile_max_contrib);
+    float4* inst_grad = (float4*)bwd_workspace;
+
+    hipLaunchKernelGGL(k_zero_inst, dim3(2048), dim3(S360_BLOCK), 0, st, inst_grad, header, kp.cap);
+    hipLaunchKernelGGL(k_render_bwd, dim3(nt), dim3(S360_BLOCK), 0, st, kp, views, tile_start, list, offsets, recA, recB,
+                       recC, final_T, n_contrib, tile_max_contrib, dL_dimages, inst_grad);
+    S360_CHECK_LAUNCH();
+    const int nblk = (kp.P + S360_BLOCK - 1) / S360_BLOCK;
+    if (shs) {
+        size_t lds = d_shs ? (size_t)S360_BLOCK * kp.M * 3 * 4 : 0;
+        if (d_shs && !(kp.flags & S360_FLAG_SHARED_CAMPOS)) lds += (size_t)S360_BLOCK * kp.V * 3 * 4;
+        if (lds > 160 * 1024) return S360_E_UNSUPPORTED;
+        (void)hipFuncSetAttribute((const void*)k_preprocess_bwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(k_preprocess_bwd<true>, dim3(nblk), dim3(S360_BLOCK), lds, st, kp, views, means3D, cov6, shs,
+                           tiles_touched, offsets, clamped, inst_grad, d_means3D, d_means2D, d_cov6, d_opacities, d_shs,
+                           d_colors);
+    } else {
+        hipLaunchKernelGGL(k_preprocess_bwd<false>, dim3(nblk), dim3(S360_BLOCK), 0, st, kp, views, means3D, cov6, shs,
+                           tiles_touched, offsets, clamped, inst_grad, d_means3D, d_means2D, d_cov6, d_opacities, d_shs,
+                           d_colors);
+    }
+    S360_CHECK_LAUNCH();
+    return S360_OK;
+}

@@ -1,0 +1,196 @@
+// s360_device.h — device-side helpers shared by the gfx950 kernels (wave64, CDNA4).
+//
+// The whole library is compiled with -ffp-contract=off: the per-Gaussian geometry below keeps
+// the exact expression order of the CPU oracle so that every integer intermediate (radius, tile
+// rect, tiles_touched, sort order) is bit-identical; hot loops that want FMAs say so explicitly
+// with __builtin_fmaf.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/s360.h"
+
+#define S360_WAVE 64
+#define S360_BLOCK 256
+
+namespace s360 {
+
+// Problem description passed by value to every kernel (lands in SGPRs).
+struct KParams {
+    int P, V, H, W, deg, M;
+    int gx, gy, T;  // tiles per row / column / view
+    uint32_t flags, cap;
+};
+
+// Real-SH constants (degree <= 3: public 3DGS table; degree 4: standard real-SH table).
+__device__ constexpr float kC0 = 0.28209479177387814f;
+__device__ constexpr float kC1 = 0.4886025119029199f;
+__device__ constexpr float kC2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                     -1.0925484305920792f, 0.5462742152960396f};
+__device__ constexpr float kC3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                     0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                     -0.5900435899266435f};
+__device__ constexpr float kC4[9] = {2.5033429417967046f, -1.7701307697799304f, 0.9461746957575601f,
+                                     -0.6690465435572892f, 0.10578554691520431f, -0.6690465435572892f,
+                                     0.47308734787878004f, -1.7701307697799304f, 0.6258357354491761f};
+
+// Y[0..(deg+1)^2) at unit direction (x,y,z).  DEG is a compile-time bound, deg the runtime degree.
+__device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, float* Y) {
+    Y[0] = kC0;
+    if (deg > 0) {
+        Y[1] = -kC1 * y;
+        Y[2] = kC1 * z;
+        Y[3] = -kC1 * x;
+        if (deg > 1) {
+            float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            Y[4] = kC2[0] * xy;
+            Y[5] = kC2[1] * yz;
+            Y[6] = kC2[2] * (2.0f * zz - xx - yy);
+            Y[7] = kC2[3] * xz;
+            Y[8] = kC2[4] * (xx - yy);
+            if (deg > 2) {
+                Y[9] = kC3[0] * y * (3.0f * xx - yy);
+                Y[10] = kC3[1] * xy * z;
+                Y[11] = kC3[2] * y * (4.0f * zz - xx - yy);
+                Y[12] = kC3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+                Y[13] = kC3[4] * x * (4.0f * zz - xx - yy);
+                Y[14] = kC3[5] * z * (xx - yy);
+                Y[15] = kC3[6] * x * (xx - 3.0f * yy);
+                if (deg > 3) {
+                    Y[16] = kC4[0] * xy * (xx - yy);
+                    Y[17] = kC4[1] * yz * (3.0f * xx - yy);
+                    Y[18] = kC4[2] * xy * (7.0f * zz - 1.0f);
+                    Y[19] = kC4[3] * yz * (7.0f * zz - 3.0f);
+                    Y[20] = kC4[4] * (zz * (35.0f * zz - 30.0f) + 3.0f);
+                    Y[21] = kC4[5] * xz * (7.0f * zz - 3.0f);
+                    Y[22] = kC4[6] * (xx - yy) * (7.0f * zz - 1.0f);
+                    Y[23] = kC4[7] * xz * (xx - 3.0f * yy);
+                    Y[24] = kC4[8] * (xx * (xx - 3.0f * yy) - yy * (3.0f * xx - yy));
+                }
+            }
+        }
+    }
+}
+
+// dY_k/d(x,y,z) of the polynomial forms above.
+__device__ __forceinline__ void sh_basis_grad(int deg, float x, float y, float z, float* dx, float* dy,
+                                              float* dz) {
+#pragma unroll
+    for (int k = 0; k < 25; ++k) dx[k] = dy[k] = dz[k] = 0.0f;
+    if (deg > 0) {
+        dy[1] = -kC1;
+        dz[2] = kC1;
+        dx[3] = -kC1;
+        if (deg > 1) {
+            float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            dx[4] = kC2[0] * y;  dy[4] = kC2[0] * x;
+            dy[5] = kC2[1] * z;  dz[5] = kC2[1] * y;
+            dx[6] = kC2[2] * (-2.0f * x); dy[6] = kC2[2] * (-2.0f * y); dz[6] = kC2[2] * (4.0f * z);
+            dx[7] = kC2[3] * z;  dz[7] = kC2[3] * x;
+            dx[8] = kC2[4] * (2.0f * x); dy[8] = kC2[4] * (-2.0f * y);
+            if (deg > 2) {
+                dx[9] = kC3[0] * (6.0f * xy); dy[9] = kC3[0] * (3.0f * xx - 3.0f * yy);
+                dx[10] = kC3[1] * yz; dy[10] = kC3[1] * xz; dz[10] = kC3[1] * xy;
+                dx[11] = kC3[2] * (-2.0f * xy); dy[11] = kC3[2] * (4.0f * zz - xx - 3.0f * yy); dz[11] = kC3[2] * (8.0f * yz);
+                dx[12] = kC3[3] * (-6.0f * xz); dy[12] = kC3[3] * (-6.0f * yz); dz[12] = kC3[3] * (6.0f * zz - 3.0f * xx - 3.0f * yy);
+                dx[13] = kC3[4] * (4.0f * zz - 3.0f * xx - yy); dy[13] = kC3[4] * (-2.0f * xy); dz[13] = kC3[4] * (8.0f * xz);
+                dx[14] = kC3[5] * (2.0f * xz); dy[14] = kC3[5] * (-2.0f * yz); dz[14] = kC3[5] * (xx - yy);
+                dx[15] = kC3[6] * (3.0f * xx - 3.0f * yy); dy[15] = kC3[6] * (-6.0f * xy);
+                if (deg > 3) {
+                    float xyz = xy * z;
+                    dx[16] = kC4[0] * y * (3.0f * xx - yy); dy[16] = kC4[0] * x * (xx - 3.0f * yy);
+                    dx[17] = kC4[1] * (6.0f * xyz); dy[17] = kC4[1] * z * (3.0f * xx - 3.0f * yy); dz[17] = kC4[1] * y * (3.0f * xx - yy);
+                    dx[18] = kC4[2] * y * (7.0f * zz - 1.0f); dy[18] = kC4[2] * x * (7.0f * zz - 1.0f); dz[18] = kC4[2] * (14.0f * xyz);
+                    dy[19] = kC4[3] * z * (7.0f * zz - 3.0f); dz[19] = kC4[3] * y * (21.0f * zz - 3.0f);
+                    dz[20] = kC4[4] * (140.0f * zz * z - 60.0f * z);
+                    dx[21] = kC4[5] * z * (7.0f * zz - 3.0f); dz[21] = kC4[5] * x * (21.0f * zz - 3.0f);
+                    dx[22] = kC4[6] * (2.0f * x) * (7.0f * zz - 1.0f); dy[22] = -kC4[6] * (2.0f * y) * (7.0f * zz - 1.0f); dz[22] = kC4[6] * (14.0f * z) * (xx - yy);
+                    dx[23] = kC4[7] * z * (3.0f * xx - 3.0f * yy); dy[23] = -kC4[7] * (6.0f * xyz); dz[23] = kC4[7] * x * (xx - 3.0f * yy);
+                    dx[24] = kC4[8] * (4.0f * xx * x - 12.0f * x * yy); dy[24] = kC4[8] * (4.0f * yy * y - 12.0f * xx * y);
+                }
+            }
+        }
+    }
+}
+
+// p' = V p with V(i,j) = m[4j+i]: the [4,4] tensors arrive transposed (cuda_splatting.py:85-87).
+__device__ __forceinline__ void xform43(const float* m, float px, float py, float pz, float& ox, float& oy,
+                                        float& oz) {
+    ox = m[0] * px + m[4] * py + m[8] * pz + m[12];
+    oy = m[1] * px + m[5] * py + m[9] * pz + m[13];
+    oz = m[2] * px + m[6] * py + m[10] * pz + m[14];
+}
+
+// Per-(Gaussian, view) geometry shared by preprocess forward and backward.
+struct Geo {
+    float tx, ty, tz, txc, tyc, fx, fy;
+    bool xin, yin;
+    float J00, J02, J11, J12;
+    float M0[3], M1[3], v0[3], v1[3];
+    float a, b, c;  // cov2D incl. the +0.3 low-pass dilation
+};
+
+__device__ __forceinline__ void geo_compute(const float* V, float tanfovx, float tanfovy, int W, int H,
+                                            float mx, float my, float mz, const float* c6, Geo& g) {
+    xform43(V, mx, my, mz, g.tx, g.ty, g.tz);
+    const float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
+    const float txtz = g.tx / g.tz, tytz = g.ty / g.tz;
+    g.xin = !(txtz < -limx || txtz > limx);
+    g.yin = !(tytz < -limy || tytz > limy);
+    g.txc = fminf(limx, fmaxf(-limx, txtz)) * g.tz;
+    g.tyc = fminf(limy, fmaxf(-limy, tytz)) * g.tz;
+    g.fx = (float)W / (2.0f * tanfovx);
+    g.fy = (float)H / (2.0f * tanfovy);
+    const float tz = g.tz;
+    g.J00 = g.fx / tz;
+    g.J02 = -(g.fx * g.txc) / (tz * tz);
+    g.J11 = g.fy / tz;
+    g.J12 = -(g.fy * g.tyc) / (tz * tz);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        g.M0[j] = g.J00 * V[j * 4 + 0] + g.J02 * V[j * 4 + 2];
+        g.M1[j] = g.J11 * V[j * 4 + 1] + g.J12 * V[j * 4 + 2];
+    }
+    const float S[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        g.v0[k] = S[k][0] * g.M0[0] + S[k][1] * g.M0[1] + S[k][2] * g.M0[2];
+        g.v1[k] = S[k][0] * g.M1[0] + S[k][1] * g.M1[1] + S[k][2] * g.M1[2];
+    }
+    g.a = g.M0[0] * g.v0[0] + g.M0[1] * g.v0[1] + g.M0[2] * g.v0[2];
+    g.b = g.M1[0] * g.v0[0] + g.M1[1] * g.v0[1] + g.M1[2] * g.v0[2];
+    g.c = g.M1[0] * g.v1[0] + g.M1[1] * g.v1[1] + g.M1[2] * g.v1[2];
+    g.a += 0.3f;
+    g.c += 0.3f;
+}
+
+// ---- wave64 primitives -------------------------------------------------------------------
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF, bool BOUND = true>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, BOUND));
+}
+
+// Sum over the 64 lanes of a wave with DPP only (no LDS traffic); result valid in lane 63.
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+    v += dpp_f<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_f<0x141>(v);  // row_half_mirror
+    v += dpp_f<0x140>(v);  // row_mirror  -> every lane of a 16-lane row holds the row sum
+    v += dpp_f<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+    v += dpp_f<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+__device__ __forceinline__ float readlane63(float v) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o));
+    return v;
+}
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+}  // namespace s360

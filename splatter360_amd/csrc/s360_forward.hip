@@ -1,0 +1,541 @@
+// s360_forward.hip — forward kernels: fused multi-view preprocess, scans, tile binning,
+// per-tile depth sort in LDS, front-to-back composite.  gfx950 / wave64 only.
+//
+// Pipeline (all asynchronous on one stream, no host sync):
+//   k_preprocess    1 thread / Gaussian, loops the V views in registers: cull, EWA cov2D, conic,
+//                   radius, tile rect; SH->RGB once per Gaussian when the views share campos;
+//                   SH coefficients staged through LDS with coalesced 16-byte loads.
+//   k_scan_*        inclusive scan of tiles_touched over the V*P (view, Gaussian) pairs
+//   k_tile_scan     exclusive scan of the per-tile instance counts  -> tile ranges
+//   k_emit          scatter (depth bits << 32 | pair) keys into their tile's bucket
+//   k_sort_tiles    bitonic sort of each tile's bucket inside LDS (unique 64-bit keys: the order
+//                   equals a stable radix sort by (tile, depth) with ascending-index emission)
+//   k_render        1 workgroup (4 waves) per 16x16 tile, LDS-staged batches of 256 splats
+#include "s360_device.h"
+
+namespace s360 {
+
+// ------------------------------------------------------------------------------ preprocess
+template <bool USE_SH>
+__global__ __launch_bounds__(S360_BLOCK) void k_preprocess(
+    KParams kp, const S360View* __restrict__ views, const float* __restrict__ means,
+    const float* __restrict__ cov6, const float* __restrict__ opac, const float* __restrict__ shs,
+    const float* __restrict__ colors, int32_t* __restrict__ radii, uint32_t* __restrict__ tiles_touched,
+    float4* __restrict__ recA, float4* __restrict__ recB, float4* __restrict__ recC,
+    uint8_t* __restrict__ clamped, uint32_t* __restrict__ tile_count) {
+    extern __shared__ __attribute__((aligned(16))) float lds_sh[];
+    const int tid = threadIdx.x;
+    const int g0 = blockIdx.x * S360_BLOCK;
+    const int g = g0 + tid;
+    const int P = kp.P;
+    const int nb = min(S360_BLOCK, P - g0);  // Gaussians handled by this block
+
+    if (USE_SH) {
+        // coalesced stage of this block's SH slab: nb*M*3 contiguous floats
+        const int nfl = nb * kp.M * 3;
+        const float* src = shs + (size_t)g0 * kp.M * 3;
+        if ((((uintptr_t)src) & 15) == 0) {
+            const int n4 = nfl >> 2;
+            const float4* s4 = reinterpret_cast<const float4*>(src);
+            float4* d4 = reinterpret_cast<float4*>(lds_sh);
+            for (int i = tid; i < n4; i += S360_BLOCK) d4[i] = s4[i];
+            for (int i = (n4 << 2) + tid; i < nfl; i += S360_BLOCK) lds_sh[i] = src[i];
+        } else {
+            for (int i = tid; i < nfl; i += S360_BLOCK) lds_sh[i] = src[i];
+        }
+        __syncthreads();
+    }
+    if (g >= P) return;
+
+    const float mx = means[3 * g], my = means[3 * g + 1], mz = means[3 * g + 2];
+    float c6[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) c6[k] = cov6[6 * (size_t)g + k];
+    const float op = opac[g];
+
+    const bool shared_cam = (kp.flags & S360_FLAG_SHARED_CAMPOS) != 0;
+    float rgb[3] = {0.f, 0.f, 0.f};
+    uint32_t clampbits = 0;
+    bool have_rgb = false;
+    if (!USE_SH) {
+        rgb[0] = colors[3 * g];
+        rgb[1] = colors[3 * g + 1];
+        rgb[2] = colors[3 * g + 2];
+        have_rgb = true;
+    }
+
+    for (int v = 0; v < kp.V; ++v) {
+        const S360View& vw = views[v];
+        const size_t p = (size_t)v * P + g;
+        int radius = 0;
+        uint32_t touched = 0;
+        float pvx, pvy, pvz;
+        xform43(vw.viewmatrix, mx, my, mz, pvx, pvy, pvz);
+        if (pvz > 0.2f) {
+            const float* Pm = vw.projmatrix;
+            const float phx = Pm[0] * mx + Pm[4] * my + Pm[8] * mz + Pm[12];
+            const float phy = Pm[1] * mx + Pm[5] * my + Pm[9] * mz + Pm[13];
+            const float phw = Pm[3] * mx + Pm[7] * my + Pm[11] * mz + Pm[15];
+            const float pw = 1.0f / (phw + 0.0000001f);
+            const float prx = phx * pw, pry = phy * pw;
+            Geo ge;
+            geo_compute(vw.viewmatrix, vw.tanfovx, vw.tanfovy, kp.W, kp.H, mx, my, mz, c6, ge);
+            const float det = ge.a * ge.c - ge.b * ge.b;
+            if (det != 0.0f) {
+                const float det_inv = 1.0f / det;
+                const float conA = ge.c * det_inv, conB = -ge.b * det_inv, conC = ge.a * det_inv;
+                const float mid = 0.5f * (ge.a + ge.c);
+                const float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
+                const float lam1 = mid + sq, lam2 = mid - sq;
+                const int rad = (int)ceilf(3.0f * sqrtf(fmaxf(lam1, lam2)));
+                const float px = ((prx + 1.0f) * (float)kp.W - 1.0f) * 0.5f;
+                const float py = ((pry + 1.0f) * (float)kp.H - 1.0f) * 0.5f;
+                const float rr = (float)rad;
+                const int minx = min(kp.gx, max(0, (int)((px - rr) / 16.0f)));
+                const int miny = min(kp.gy, max(0, (int)((py - rr) / 16.0f)));
+                const int maxx = min(kp.gx, max(0, (int)((px + rr + 15.0f) / 16.0f)));
+                const int maxy = min(kp.gy, max(0, (int)((py + rr + 15.0f) / 16.0f)));
+                const int area = (maxx - minx) * (maxy - miny);
+                if (area != 0) {
+                    if (USE_SH && (!have_rgb || !shared_cam)) {
+                        const float dx = mx - vw.campos[0], dy = my - vw.campos[1], dz = mz - vw.campos[2];
+                        const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+                        const float x = dx * inv, y = dy * inv, z = dz * inv;
+                        float Y[25];
+                        sh_basis(kp.deg, x, y, z, Y);
+                        const int n = (kp.deg + 1) * (kp.deg + 1);
+                        const float* sh = lds_sh + tid * kp.M * 3;
+                        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+                        // sequential (unfused) accumulation: same rounding as the CPU oracle
+                        for (int k = 0; k < n; ++k) {
+                            a0 += Y[k] * sh[k * 3 + 0];
+                            a1 += Y[k] * sh[k * 3 + 1];
+                            a2 += Y[k] * sh[k * 3 + 2];
+                        }
+                        a0 += 0.5f;
+                        a1 += 0.5f;
+                        a2 += 0.5f;
+                        clampbits = (a0 < 0.f ? 1u : 0u) | (a1 < 0.f ? 2u : 0u) | (a2 < 0.f ? 4u : 0u);
+                        rgb[0] = fmaxf(a0, 0.f);
+                        rgb[1] = fmaxf(a1, 0.f);
+                        rgb[2] = fmaxf(a2, 0.f);
+                        have_rgb = true;
+                    }
+                    radius = rad;
+                    touched = (uint32_t)area;
+                    recA[p] = make_float4(px, py, conA, conB);
+                    recB[p] = make_float4(conC, op, rgb[0], rgb[1]);
+                    recC[p] = make_float4(rgb[2], pvz, __uint_as_float((uint32_t)minx | ((uint32_t)miny << 16)),
+                                          __uint_as_float((uint32_t)maxx | ((uint32_t)maxy << 16)));
+                    clamped[p] = (uint8_t)clampbits;
+                    uint32_t* tc = tile_count + (size_t)v * kp.T;
+                    for (int y = miny; y < maxy; ++y)
+                        for (int x = minx; x < maxx; ++x) atomicAdd(&tc[y * kp.gx + x], 1u);
+                }
+            }
+        }
+        if (radii) radii[p] = radius;
+        tiles_touched[p] = touched;
+    }
+}
+
+// ------------------------------------------------------------------------------ scans
+// Inclusive scan of n uint32 in three launches: per-block totals, scan of totals, final pass.
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = S360_BLOCK * SCAN_ITEMS;  // 2048 elements per block
+
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* lds, uint32_t& total) {
+    // wave-level inclusive scan by shuffles, then 4 wave totals through LDS
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = (uint32_t)__shfl_up((int)inc, o);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < S360_BLOCK / 64; ++w) {
+        const uint32_t s = lds[w];
+        if (w < wave) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    total = tot;
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(S360_BLOCK) void k_scan_block_sums(const uint32_t* __restrict__ in, uint32_t* __restrict__ sums,
+                                                               size_t n) {
+    __shared__ uint32_t lds[8];
+    const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i)
+        if (base + i < n) s += in[base + i];
+    uint32_t tot;
+    block_exclusive_scan(s, lds, tot);
+    if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+
+// single block: exclusive scan of `sums` in place; optionally writes the grand total to *total_out
+__global__ __launch_bounds__(S360_BLOCK) void k_scan_sums(uint32_t* __restrict__ sums, int n, uint32_t* __restrict__ total_out) {
+    __shared__ uint32_t lds[8];
+    uint32_t carry = 0;
+    for (int b = 0; b < n; b += S360_BLOCK) {
+        const int i = b + threadIdx.x;
+        const uint32_t v = i < n ? sums[i] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_exclusive_scan(v, lds, tot);
+        if (i < n) sums[i] = carry + ex;
+        carry += tot;
+    }
+    if (total_out && threadIdx.x == 0) *total_out = carry;
+}
+
+__global__ __launch_bounds__(S360_BLOCK) void k_scan_final(const uint32_t* __restrict__ in, const uint32_t* __restrict__ sums,
+                                                          uint32_t* __restrict__ out, size_t n) {
+    __shared__ uint32_t lds[8];
+    const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS];
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        v[i] = base + i < n ? in[base + i] : 0u;
+        s += v[i];
+    }
+    uint32_t tot;
+    uint32_t run = block_exclusive_scan(s, lds, tot) + sums[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        run += v[i];
+        if (base + i < n) out[base + i] = run;
+    }
+}
+
+// single block: tile_start[0..nt] = exclusive scan of tile_count; header bookkeeping.
+__global__ __launch_bounds__(S360_BLOCK) void k_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_start,
+                                                         uint32_t* __restrict__ tile_cursor, int nt, uint32_t cap,
+                                                         uint32_t* __restrict__ header) {
+    __shared__ uint32_t lds[8];
+    __shared__ uint32_t lds_max;
+    if (threadIdx.x == 0) lds_max = 0;
+    __syncthreads();
+    uint32_t carry = 0, mx = 0;
+    for (int b = 0; b < nt; b += S360_BLOCK) {
+        const int i = b + threadIdx.x;
+        const uint32_t v = i < nt ? tile_count[i] : 0u;
+        mx = max(mx, v);
+        uint32_t tot;
+        const uint32_t ex = block_exclusive_scan(v, lds, tot);
+        if (i < nt) {
+            tile_start[i] = carry + ex;
+            tile_cursor[i] = 0;
+        }
+        carry += tot;
+    }
+    atomicMax(&lds_max, mx);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        tile_start[nt] = carry;
+        header[0] = carry;                    // num_instances ("num_rendered")
+        header[1] = carry > cap ? 1u : 0u;    // overflow flag
+        header[2] = lds_max;                  // longest tile list
+    }
+}
+
+// ------------------------------------------------------------------------------ emit
+__global__ __launch_bounds__(S360_BLOCK) void k_emit(KParams kp, const uint32_t* __restrict__ tiles_touched,
+                                                    const float4* __restrict__ recC, const uint32_t* __restrict__ tile_start,
+                                                    uint32_t* __restrict__ tile_cursor, uint64_t* __restrict__ keys) {
+    const size_t p = (size_t)blockIdx.x * S360_BLOCK + threadIdx.x;
+    const size_t np = (size_t)kp.V * kp.P;
+    if (p >= np) return;
+    if (tiles_touched[p] == 0) return;
+    const float4 rc = recC[p];
+    const uint32_t rmin = __float_as_uint(rc.z), rmax = __float_as_uint(rc.w);
+    const int minx = rmin & 0xFFFF, miny = rmin >> 16, maxx = rmax & 0xFFFF, maxy = rmax >> 16;
+    const int v = (int)(p / kp.P);
+    const uint64_t key = ((uint64_t)__float_as_uint(rc.y) << 32) | (uint64_t)(uint32_t)p;
+    const size_t tb = (size_t)v * kp.T;
+    for (int y = miny; y < maxy; ++y)
+        for (int x = minx; x < maxx; ++x) {
+            const size_t t = tb + y * kp.gx + x;
+            const uint32_t pos = tile_start[t] + atomicAdd(&tile_cursor[t], 1u);
+            if (pos < kp.cap) keys[pos] = key;
+        }
+}
+
+// ------------------------------------------------------------------------------ per-tile sort
+// One workgroup per tile whose list length n satisfies lo < n <= CAP: bitonic sort of the unique
+// 64-bit keys in LDS, then writes the sorted keys back and the pair list.
+template <int CAP>
+__global__ __launch_bounds__(S360_BLOCK) void k_sort_tiles(const uint32_t* __restrict__ tile_start, uint64_t* __restrict__ keys,
+                                                          uint32_t* __restrict__ list, uint32_t lo, uint32_t cap) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds_k[];
+    const uint32_t s = min(tile_start[blockIdx.x], cap), e = min(tile_start[blockIdx.x + 1], cap);
+    const uint32_t n = e - s;
+    if (n <= lo || n > (uint32_t)CAP) return;
+    uint32_t npad = 1;
+    while (npad < n) npad <<= 1;
+    for (uint32_t i = threadIdx.x; i < npad; i += S360_BLOCK) lds_k[i] = i < n ? keys[s + i] : ~0ull;
+    __syncthreads();
+    for (uint32_t k = 2; k <= npad; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = threadIdx.x; t < (npad >> 1); t += S360_BLOCK) {
+                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // index with bit j clear
+                const uint32_t l = i | j;
+                const uint64_t a = lds_k[i], b = lds_k[l];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) {
+                    lds_k[i] = b;
+                    lds_k[l] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < n; i += S360_BLOCK) {
+        const uint64_t k = lds_k[i];
+        keys[s + i] = k;
+        list[s + i] = (uint32_t)k;
+    }
+}
+
+// Fallback for tile lists that exceed the LDS capacity: the same bitonic network run by one
+// workgroup directly on global memory (padding handled by index guards).  Rare and slow.
+__global__ __launch_bounds__(S360_BLOCK) void k_sort_tiles_global(const uint32_t* __restrict__ tile_start, uint64_t* __restrict__ keys,
+                                                                 uint32_t* __restrict__ list, uint32_t lo, uint32_t cap) {
+    const uint32_t s = min(tile_start[blockIdx.x], cap), e = min(tile_start[blockIdx.x + 1], cap);
+    const uint32_t n = e - s;
+    if (n <= lo) return;
+    uint32_t npad = 1;
+    while (npad < n) npad <<= 1;
+    uint64_t* kk = keys + s;
+    for (uint32_t k = 2; k <= npad; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = threadIdx.x; t < (npad >> 1); t += S360_BLOCK) {
+                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const uint32_t l = i | j;
+                // virtual padding = +inf keys at indices >= n
+                const uint64_t a = i < n ? kk[i] : ~0ull, b = l < n ? kk[l] : ~0ull;
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) {
+                    if (i < n) kk[i] = b;
+                    if (l < n) kk[l] = a;
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < n; i += S360_BLOCK) list[s + i] = (uint32_t)kk[i];
+}
+
+// ------------------------------------------------------------------------------ composite
+__global__ __launch_bounds__(S360_BLOCK) void k_render(KParams kp, const S360View* __restrict__ views,
+                                                      const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ list,
+                                                      const float4* __restrict__ recA, const float4* __restrict__ recB,
+                                                      const float4* __restrict__ recC, float* __restrict__ images,
+                                                      float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+                                                      uint32_t* __restrict__ tile_max_contrib) {
+    __shared__ float4 sA[S360_BLOCK];
+    __shared__ float4 sB[S360_BLOCK];
+    __shared__ float sC[S360_BLOCK];
+    __shared__ uint32_t s_maxc;
+
+    const int t = blockIdx.x;
+    const int v = t / kp.T, rem = t - v * kp.T;
+    const int ty = rem / kp.gx, tx = rem - ty * kp.gx;
+    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int px = tx * 16 + lx, py = ty * 16 + ly;
+    const bool inside = px < kp.W && py < kp.H;
+    const float pxf = (float)px, pyf = (float)py;
+
+    const uint32_t start = min(tile_start[t], kp.cap), end = min(tile_start[t + 1], kp.cap);
+    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
+    uint32_t contributor = 0, last = 0;
+    bool done = !inside;
+    if (threadIdx.x == 0) s_maxc = 0;
+
+    for (uint32_t b = start; b < end; b += S360_BLOCK) {
+        // barrier + early out when every pixel of the tile is saturated
+        if (__syncthreads_count(done ? 1 : 0) == S360_BLOCK) break;
+        const uint32_t idx = b + threadIdx.x;
+        if (idx < end) {
+            const uint32_t p = list[idx];
+            sA[threadIdx.x] = recA[p];
+            sB[threadIdx.x] = recB[p];
+            sC[threadIdx.x] = recC[p].x;
+        }
+        __syncthreads();
+        const int cnt = (int)min((uint32_t)S360_BLOCK, end - b);
+        if (!done) {
+            for (int j = 0; j < cnt; ++j) {
+                ++contributor;
+                const float4 a = sA[j];
+                const float4 bb = sB[j];
+                const float dx = a.x - pxf, dy = a.y - pyf;
+                const float power = -0.5f * (a.z * dx * dx + bb.x * dy * dy) - a.w * dx * dy;
+                if (power > 0.0f) continue;
+                const float alpha = fminf(0.99f, bb.y * __expf(power));
+                if (alpha < 1.0f / 255.0f) continue;
+                const float test_T = T * (1.0f - alpha);
+                if (test_T < 0.0001f) {
+                    done = true;
+                    break;
+                }
+                const float w = alpha * T;
+                C0 += bb.z * w;
+                C1 += bb.w * w;
+                C2 += sC[j] * w;
+                T = test_T;
+                last = contributor;
+            }
+        }
+    }
+    if (inside) {
+        const S360View& vw = views[v];
+        const size_t hw = (size_t)kp.H * kp.W;
+        const size_t pix = (size_t)py * kp.W + px;
+        float* img = images + (size_t)v * 3 * hw;
+        img[pix] = C0 + T * vw.bg[0];
+        img[hw + pix] = C1 + T * vw.bg[1];
+        img[2 * hw + pix] = C2 + T * vw.bg[2];
+        final_T[(size_t)v * hw + pix] = T;
+        n_contrib[(size_t)v * hw + pix] = last;
+    }
+    const uint32_t wm = wave_max_u32(inside ? last : 0u);
+    if (lane_id() == 0) atomicMax(&s_maxc, wm);
+    __syncthreads();
+    if (threadIdx.x == 0) tile_max_contrib[t] = s_maxc;
+}
+
+}  // namespace s360
+
+// ------------------------------------------------------------------------------ host side
+using namespace s360;
+
+static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+extern "C" int s360_layout(const S360Params* prm, S360Layout* out) {
+    if (!prm || !out) return S360_E_BADARG;
+    if (prm->P < 0 || prm->V < 1 || prm->V > S360_MAX_VIEWS || prm->H < 1 || prm->W < 1) return S360_E_BADARG;
+    const size_t np = (size_t)prm->V * (size_t)(prm->P > 0 ? prm->P : 1);
+    const size_t gx = (prm->W + 15) / 16, gy = (prm->H + 15) / 16;
+    const size_t nt = (size_t)prm->V * gx * gy;
+    const size_t cap = prm->max_instances ? prm->max_instances : 1;
+    const size_t npix = (size_t)prm->V * prm->H * prm->W;
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        size_t r = o;
+        o = align_up(o + bytes);
+        return r;
+    };
+    out->header = take(64 * 4);
+    out->tiles_touched = take(np * 4);
+    out->offsets = take(np * 4);
+    out->scan_scratch = take((np / SCAN_TILE + 2) * 4);
+    out->rec_a = take(np * 16);
+    out->rec_b = take(np * 16);
+    out->rec_c = take(np * 16);
+    out->clamped = take(np);
+    out->tile_count = take(nt * 4);
+    out->tile_start = take((nt + 1) * 4);
+    out->tile_cursor = take(nt * 4);
+    out->keys = take(cap * 8);
+    out->list = take(cap * 4);
+    out->final_T = take(npix * 4);
+    out->n_contrib = take(npix * 4);
+    out->tile_max_contrib = take(nt * 4);
+    out->total_bytes = o;
+    // backward scratch: per-instance raster gradients (12 floats per instance)
+    out->backward_bytes = align_up(cap * 12 * 4) + 256;
+    return S360_OK;
+}
+
+#define S360_CHECK_LAUNCH()                                  \
+    do {                                                     \
+        if (hipGetLastError() != hipSuccess) return S360_E_LAUNCH; \
+    } while (0)
+
+extern "C" int s360_forward(const S360Params* prm, const S360View* views, const float* means3D, const float* cov6,
+                            const float* opacities, const float* shs, const float* colors_precomp, float* images,
+                            int32_t* radii, void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!prm || !views || !images || !workspace) return S360_E_BADARG;
+    if ((shs == nullptr) == (colors_precomp == nullptr)) return S360_E_BADARG;
+    if (prm->P > 0 && (!means3D || !cov6 || !opacities)) return S360_E_BADARG;
+    if (shs && (prm->M < 1 || prm->sh_degree < 0 || prm->sh_degree > 4 ||
+                (prm->sh_degree + 1) * (prm->sh_degree + 1) > prm->M))
+        return S360_E_BADARG;
+    if (prm->W > 65535 * 16 || prm->H > 65535 * 16) return S360_E_UNSUPPORTED;
+    S360Layout L;
+    int rc = s360_layout(prm, &L);
+    if (rc) return rc;
+    if (workspace_bytes < L.total_bytes) return S360_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream_;
+    char* ws = (char*)workspace;
+
+    KParams kp;
+    kp.P = prm->P; kp.V = prm->V; kp.H = prm->H; kp.W = prm->W; kp.deg = prm->sh_degree; kp.M = prm->M;
+    kp.gx = (prm->W + 15) / 16; kp.gy = (prm->H + 15) / 16; kp.T = kp.gx * kp.gy;
+    kp.flags = prm->flags; kp.cap = prm->max_instances;
+    const int nt = kp.V * kp.T;
+    const size_t np = (size_t)kp.V * kp.P;
+
+    uint32_t* header = (uint32_t*)(ws + L.header);
+    uint32_t* tiles_touched = (uint32_t*)(ws + L.tiles_touched);
+    uint32_t* offsets = (uint32_t*)(ws + L.offsets);
+    uint32_t* scratch = (uint32_t*)(ws + L.scan_scratch);
+    float4* recA = (float4*)(ws + L.rec_a);
+    float4* recB = (float4*)(ws + L.rec_b);
+    float4* recC = (float4*)(ws + L.rec_c);
+    uint8_t* clamped = (uint8_t*)(ws + L.clamped);
+    uint32_t* tile_count = (uint32_t*)(ws + L.tile_count);
+    uint32_t* tile_start = (uint32_t*)(ws + L.tile_start);
+    uint32_t* tile_cursor = (uint32_t*)(ws + L.tile_cursor);
+    uint64_t* keys = (uint64_t*)(ws + L.keys);
+    uint32_t* list = (uint32_t*)(ws + L.list);
+    float* final_T = (float*)(ws + L.final_T);
+    uint32_t* n_contrib = (uint32_t*)(ws + L.n_contrib);
+    uint32_t* tile_max_contrib = (uint32_t*)(ws + L.tile_max_contrib);
+
+    if (hipMemsetAsync(tile_count, 0, (size_t)nt * 4, st) != hipSuccess) return S360_E_LAUNCH;
+    if (kp.P > 0) {
+        const int nblk = (kp.P + S360_BLOCK - 1) / S360_BLOCK;
+        if (shs) {
+            const size_t lds = (size_t)S360_BLOCK * kp.M * 3 * 4;
+            if (lds > 160 * 1024) return S360_E_UNSUPPORTED;
+            hipFuncSetAttribute((const void*)k_preprocess<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipLaunchKernelGGL(k_preprocess<true>, dim3(nblk), dim3(S360_BLOCK), lds, st, kp, views, means3D, cov6,
+                               opacities, shs, colors_precomp, radii, tiles_touched, recA, recB, recC, clamped, tile_count);
+        } else {
+            hipLaunchKernelGGL(k_preprocess<false>, dim3(nblk), dim3(S360_BLOCK), 0, st, kp, views, means3D, cov6,
+                               opacities, shs, colors_precomp, radii, tiles_touched, recA, recB, recC, clamped, tile_count);
+        }
+        S360_CHECK_LAUNCH();
+        const int sblk = (int)((np + SCAN_TILE - 1) / SCAN_TILE);
+        hipLaunchKernelGGL(k_scan_block_sums, dim3(sblk), dim3(S360_BLOCK), 0, st, tiles_touched, scratch, np);
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(S360_BLOCK), 0, st, scratch, sblk, (uint32_t*)nullptr);
+        hipLaunchKernelGGL(k_scan_final, dim3(sblk), dim3(S360_BLOCK), 0, st, tiles_touched, scratch, offsets, np);
+        S360_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(S360_BLOCK), 0, st, tile_count, tile_start, tile_cursor, nt, kp.cap, header);
+    S360_CHECK_LAUNCH();
+    if (kp.P > 0) {
+        const int eblk = (int)((np + S360_BLOCK - 1) / S360_BLOCK);
+        hipLaunchKernelGGL(k_emit, dim3(eblk), dim3(S360_BLOCK), 0, st, kp, tiles_touched, recC, tile_start, tile_cursor, keys);
+        S360_CHECK_LAUNCH();
+        hipFuncSetAttribute((const void*)k_sort_tiles<16384>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(k_sort_tiles<2048>, dim3(nt), dim3(S360_BLOCK), 2048 * 8, st, tile_start, keys, list, 0u, kp.cap);
+        hipLaunchKernelGGL(k_sort_tiles<16384>, dim3(nt), dim3(S360_BLOCK), 16384 * 8, st, tile_start, keys, list, 2048u, kp.cap);
+        hipLaunchKernelGGL(k_sort_tiles_global, dim3(nt), dim3(S360_BLOCK), 0, st, tile_start, keys, list, 16384u, kp.cap);
+        S360_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(k_render, dim3(nt), dim3(S360_BLOCK), 0, st, kp, views, tile_start, list, recA, recB, recC, images,
+                       final_T, n_contrib, tile_max_contrib);
+    S360_CHECK_LAUNCH();
+    return S360_OK;
+}

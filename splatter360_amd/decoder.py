@@ -1,0 +1,157 @@
+"""Host-side mirror of the reference's decoder glue (src/model/decoder/cuda_splatting.py and
+decoder_splatting_cuda.py) on top of the HIP rasteriser, plus the fused six-face path.
+
+Drop-in layer (same names, argument meaning and error behaviour as the reference):
+    render_cuda, render_depth_cuda, get_projection_matrix, DecoderSplattingCUDA
+Fused layer (what the MI355X design adds — one rasteriser call per panorama instead of six
+Python-looped calls, shared per-Gaussian loads and SH evaluation, no host synchronisation):
+    render_cube_faces, render_cube_depth
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from math import isqrt
+from typing import Literal, Optional
+
+import torch
+from torch import Tensor
+
+from . import cameras, rasterizer
+from .cameras import get_fov, get_projection_matrix  # noqa: F401  (re-exported, reference names)
+
+DepthRenderingMode = Literal["depth", "disparity", "relative_disparity", "log"]
+
+
+def depth_to_relative_disparity(depth: Tensor, near: Tensor, far: Tensor, eps: float = 1e-10) -> Tensor:
+    """src/model/encoder/costvolume/conversions.py (relative disparity in [0,1])."""
+    disp_near = 1 / (near + eps)
+    disp_far = 1 / (far + eps)
+    disp = 1 / (depth + eps)
+    return 1 - (disp - disp_far) / (disp_near - disp_far + eps)
+
+
+def _triu_cov6(cov: Tensor) -> Tensor:
+    row, col = torch.triu_indices(3, 3)
+    return cov[..., row, col]
+
+
+def render_cuda(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, image_shape: tuple,
+                background_color: Tensor, gaussian_means: Tensor, gaussian_covariances: Tensor,
+                gaussian_sh_coefficients: Tensor, gaussian_opacities: Tensor, scale_invariant: bool = True,
+                use_sh: bool = True) -> Tensor:
+    """Same contract as the reference's render_cuda (cuda_splatting.py:47-127): batch of b
+    (camera, cloud) pairs -> [b,3,h,w].  One HIP rasteriser call per batch item, no .item() sync."""
+    assert use_sh or gaussian_sh_coefficients.shape[-1] == 1
+    vs = cameras.view_setup(extrinsics, intrinsics, near, far, scale_invariant)
+    scale = vs["scale"]
+    if scale_invariant:
+        gaussian_covariances = gaussian_covariances * (scale[:, None, None, None] ** 2)
+        gaussian_means = gaussian_means * scale[:, None, None]
+    n = gaussian_sh_coefficients.shape[-1]
+    degree = isqrt(n) - 1
+    shs = gaussian_sh_coefficients.transpose(2, 3).contiguous()  # "b g xyz n -> b g n xyz"
+    b = extrinsics.shape[0]
+    h, w = image_shape
+    images = []
+    for i in range(b):
+        views = rasterizer.pack_views(vs["view_matrix"][i], vs["full_projection"][i], vs["campos"][i],
+                                      vs["tan_fov_x"][i:i + 1], vs["tan_fov_y"][i:i + 1], background_color[i])
+        img, _ = rasterizer.rasterize_views(
+            gaussian_means[i], _triu_cov6(gaussian_covariances[i]), gaussian_opacities[i, ..., None],
+            shs[i] if use_sh else None, None if use_sh else shs[i, :, 0, :], views=views, image_height=h,
+            image_width=w, sh_degree=degree, shared_campos=True, want_radii=False)
+        images.append(img[0])
+    return torch.stack(images)
+
+
+def _depth_colors(extrinsics, means, near, far, mode):
+    cam = torch.einsum("bij,bgj->bgi", extrinsics.inverse(),
+                       torch.cat([means, torch.ones_like(means[..., :1])], dim=-1))
+    z = cam[..., 2]
+    if mode == "disparity":
+        z = 1 / z
+    elif mode == "relative_disparity":
+        z = depth_to_relative_disparity(z, near[:, None], far[:, None])
+    elif mode == "log":
+        z = z.minimum(near[:, None]).maximum(far[:, None]).log()  # reference quirk kept (:251)
+    return z
+
+
+def render_depth_cuda(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, image_shape: tuple,
+                      gaussian_means: Tensor, gaussian_covariances: Tensor, gaussian_opacities: Tensor,
+                      scale_invariant: bool = True, mode: DepthRenderingMode = "depth") -> Tensor:
+    """Reference's render_depth_cuda (cuda_splatting.py:226-269): alpha-premultiplied expected
+    depth -> [b,h,w]."""
+    z = _depth_colors(extrinsics, gaussian_means, near, far, mode)
+    b = z.shape[0]
+    result = render_cuda(extrinsics, intrinsics, near, far, image_shape,
+                         torch.zeros((b, 3), dtype=z.dtype, device=z.device), gaussian_means,
+                         gaussian_covariances, z[:, :, None, None].expand(-1, -1, 3, 1), gaussian_opacities,
+                         scale_invariant=scale_invariant, use_sh=False)
+    return result.mean(dim=1)
+
+
+# ----------------------------------------------------------------------------- fused path
+def cube_views(pano_c2w: Tensor, near: Tensor, far: Tensor, background: Tensor):
+    """[4,4] panorama pose (+ scalar near/far tensors, [3] background) -> (views[6,42], scale):
+    the six face cameras of cameras.cube_face_extrinsics with the reference's scale-invariant
+    rescale, packed for one V=6 rasteriser call.  Pure device math, no sync."""
+    ext = cameras.cube_face_extrinsics(pano_c2w[None])[0]
+    k = cameras.cube_face_intrinsics(1, device=pano_c2w.device)[0]
+    vs = cameras.view_setup(ext, k, near.reshape(1).expand(6), far.reshape(1).expand(6), True)
+    views = rasterizer.pack_views(vs["view_matrix"], vs["full_projection"], vs["campos"], vs["tan_fov_x"],
+                                  vs["tan_fov_y"], background)
+    return views, vs["scale"][0]
+
+
+def render_cube_faces(pano_c2w: Tensor, near: Tensor, far: Tensor, face_w: int, background: Tensor,
+                      gaussian_means: Tensor, gaussian_covariances: Tensor, gaussian_sh_coefficients: Tensor,
+                      gaussian_opacities: Tensor, *, max_instances: Optional[int] = None, check: str = "sync") -> Tensor:
+    """One panorama of ONE cloud: means[G,3], covariances[G,3,3], harmonics[G,3,d_sh] (the
+    reference's Gaussians layout, src/model/types.py:7-12), opacities[G] -> faces[6,3,fw,fw] in the
+    reference's rendered order (top, front, left, back, right, bottom).  Bit-for-bit the result of
+    six render_cuda calls (same boundary tensors), in one fused launch sequence."""
+    views, scale = cube_views(pano_c2w, near, far, background)
+    n = gaussian_sh_coefficients.shape[-1]
+    shs = gaussian_sh_coefficients.transpose(1, 2).contiguous()
+    faces, _ = rasterizer.rasterize_views(
+        gaussian_means * scale, _triu_cov6(gaussian_covariances * scale ** 2), gaussian_opacities[..., None], shs, None,
+        views=views, image_height=face_w, image_width=face_w, sh_degree=isqrt(n) - 1, shared_campos=True,
+        want_radii=False, max_instances=max_instances, check=check)
+    return faces
+
+
+@dataclass
+class DecoderOutput:
+    color: Tensor
+    depth: Optional[Tensor]
+
+
+class DecoderSplattingCUDA(torch.nn.Module):
+    """Mirror of the reference decoder (decoder_splatting_cuda.py:19-97): forward(gaussians,
+    extrinsics[b,v,4,4], intrinsics[b,v,3,3], near[b,v], far[b,v], (h,w), depth_mode)."""
+
+    def __init__(self, background_color=(0.0, 0.0, 0.0)):
+        super().__init__()
+        self.register_buffer("background_color", torch.tensor(background_color, dtype=torch.float32), persistent=False)
+
+    def forward(self, gaussians, extrinsics, intrinsics, near, far, image_shape, depth_mode=None) -> DecoderOutput:
+        b, v, _, _ = extrinsics.shape
+        colors = torch.zeros((b, v, 3, *image_shape), dtype=torch.float32, device=extrinsics.device)
+        bg = self.background_color[None].expand(b, 3)
+        for view_idx in range(v):
+            colors[:, view_idx] = render_cuda(
+                extrinsics[:, view_idx], intrinsics[:, view_idx], near[:, view_idx], far[:, view_idx], image_shape, bg,
+                gaussians.means, gaussians.covariances, gaussians.harmonics, gaussians.opacities)
+        depth = None if depth_mode is None else self.render_depth(gaussians, extrinsics, intrinsics, near, far,
+                                                                  image_shape, depth_mode)
+        return DecoderOutput(colors, depth)
+
+    def render_depth(self, gaussians, extrinsics, intrinsics, near, far, image_shape, mode="depth") -> Tensor:
+        b, v, _, _ = extrinsics.shape
+        depths = torch.zeros((b, v, *image_shape), dtype=torch.float32, device=extrinsics.device)
+        for view_idx in range(v):
+            depths[:, view_idx] = render_depth_cuda(
+                extrinsics[:, view_idx], intrinsics[:, view_idx], near[:, view_idx], far[:, view_idx], image_shape,
+                gaussians.means, gaussians.covariances, gaussians.opacities, mode=mode)
+        return depths

@@ -1,0 +1,251 @@
+"""PyTorch surface of the MI355X rasteriser: the drop-in `GaussianRasterizationSettings` /
+`GaussianRasterizer` pair the reference imports (src/model/decoder/cuda_splatting.py:5-8) and the
+multi-view primitive `rasterize_views` behind it (one call = V views of one cloud).
+
+PyTorch is plumbing here (device memory, streams, autograd bookkeeping); all arithmetic happens in
+libs360.so through the C ABI of include/s360.h.  There is no eager / CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple, Optional
+
+import torch
+from torch import Tensor, nn
+
+from . import _lib
+
+VIEW_FLOATS = 42
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    """Same fields, same order as upstream (constructed with keywords at cuda_splatting.py:99-112)."""
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: Tensor
+    scale_modifier: float
+    viewmatrix: Tensor
+    projmatrix: Tensor
+    sh_degree: int
+    campos: Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def pack_views(viewmatrix: Tensor, projmatrix: Tensor, campos: Tensor, tanfovx, tanfovy, bg: Tensor) -> Tensor:
+    """-> float32 [V,42] device tensor in S360View layout.  Tensors may carry a leading view dim;
+    tanfov may be python floats or [V] tensors.  No host synchronisation."""
+    vm = viewmatrix.reshape(-1, 16).float()
+    v = vm.shape[0]
+    dev = vm.device
+    pm = projmatrix.reshape(-1, 16).float().to(dev)
+    cp = campos.reshape(-1, 3).float().to(dev)
+    b = bg.reshape(-1, 3).float().to(dev).expand(v, 3)
+
+    def col(t):
+        if isinstance(t, Tensor):
+            return t.reshape(-1, 1).float().to(dev).expand(v, 1)
+        return torch.full((v, 1), float(t), dtype=torch.float32, device=dev)
+
+    return torch.cat([vm, pm, cp.expand(v, 3), col(tanfovx), col(tanfovy), b], dim=1).contiguous()
+
+
+def default_capacity(p: int, v: int) -> int:
+    """Initial capacity (instances = (Gaussian, tile) pairs) of the binning buffers."""
+    return int(min(2**32 - 1, max(1 << 16, 4 * p * v + (1 << 18))))
+
+
+class RasterState:
+    """Forward workspace + layout: upstream's geomBuffer/binningBuffer/imgBuffer, addressable."""
+
+    def __init__(self, prm: _lib.S360Params, lay: _lib.S360Layout, workspace: Tensor):
+        self.prm, self.layout, self.workspace = prm, lay, workspace
+
+    def _arr(self, off: int, count: int, dtype: torch.dtype) -> Tensor:
+        nbytes = count * torch.empty((), dtype=dtype).element_size()
+        return self.workspace[off:off + nbytes].view(dtype)
+
+    def header(self) -> Tensor:
+        return self._arr(self.layout.header, 64, torch.int32)
+
+    def tensors(self) -> dict:
+        """Named views of the integer / float intermediates (for parity tests and debugging)."""
+        p, l = self.prm, self.layout
+        npair = p.V * p.P
+        gx, gy = (p.W + 15) // 16, (p.H + 15) // 16
+        nt = p.V * gx * gy
+        cap = p.max_instances
+        return dict(
+            header=self.header(),
+            tiles_touched=self._arr(l.tiles_touched, npair, torch.int32).view(p.V, p.P),
+            offsets=self._arr(l.offsets, npair, torch.int32).view(p.V, p.P),
+            rec_a=self._arr(l.rec_a, npair * 4, torch.float32).view(p.V, p.P, 4),
+            rec_b=self._arr(l.rec_b, npair * 4, torch.float32).view(p.V, p.P, 4),
+            rec_c=self._arr(l.rec_c, npair * 4, torch.float32).view(p.V, p.P, 4),
+            clamped=self._arr(l.clamped, npair, torch.uint8).view(p.V, p.P),
+            tile_count=self._arr(l.tile_count, nt, torch.int32),
+            tile_start=self._arr(l.tile_start, nt + 1, torch.int32),
+            keys=self._arr(l.keys, cap, torch.int64),
+            list=self._arr(l.list, cap, torch.int32),
+            final_T=self._arr(l.final_T, p.V * p.H * p.W, torch.float32).view(p.V, p.H, p.W),
+            n_contrib=self._arr(l.n_contrib, p.V * p.H * p.W, torch.int32).view(p.V, p.H, p.W),
+            tile_max_contrib=self._arr(l.tile_max_contrib, nt, torch.int32),
+        )
+
+    def num_rendered(self) -> int:
+        """Host read of num_instances (synchronises)."""
+        return int(self.header()[0].item()) & 0xFFFFFFFF
+
+    def overflowed(self) -> bool:
+        return bool(self.header()[1].item())
+
+
+def _ptr(t: Optional[Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _f32c(t: Tensor, name: str) -> Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU (hip device); the rasteriser has no CPU path")
+    return t.detach().float().contiguous()
+
+
+def _forward_call(prm, views, means3D, cov6, opac, shs, colors, want_radii: bool):
+    lay = _lib.layout(prm)
+    dev = means3D.device
+    ws = torch.empty(lay.total_bytes, dtype=torch.uint8, device=dev)
+    images = torch.empty((prm.V, 3, prm.H, prm.W), dtype=torch.float32, device=dev)
+    radii = torch.empty((prm.V, prm.P), dtype=torch.int32, device=dev) if want_radii else None
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    rc = _lib.lib().s360_forward(C.byref(prm), _ptr(views), _ptr(means3D), _ptr(cov6), _ptr(opac), _ptr(shs),
+                                 _ptr(colors), _ptr(images), _ptr(radii), _ptr(ws), lay.total_bytes, stream)
+    _lib.check(rc, "s360_forward")
+    return images, radii, RasterState(prm, lay, ws)
+
+
+class _RasterizeViews(torch.autograd.Function):
+    """autograd node of one multi-view rasterisation (forward saves inputs + workspace)."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, cov6, views, cfg):
+        h, w, sh_degree, shared_campos, max_instances, check, want_radii = cfg
+        with torch.cuda.device(means3D.device):
+            m3 = _f32c(means3D, "means3D")
+            c6 = _f32c(cov6, "cov3D_precomp")
+            op = _f32c(opacities, "opacities").reshape(-1)
+            sh = None if shs is None else _f32c(shs, "shs")
+            col = None if colors_precomp is None else _f32c(colors_precomp, "colors_precomp")
+            vw = _f32c(views, "views")
+            p, v = int(m3.shape[0]), int(vw.shape[0])
+            if v > _lib.S360_MAX_VIEWS:
+                raise RuntimeError(f"at most {_lib.S360_MAX_VIEWS} views per call")
+            prm = _lib.S360Params()
+            prm.P, prm.V, prm.H, prm.W = p, v, int(h), int(w)
+            prm.sh_degree = int(sh_degree)
+            prm.M = 0 if sh is None else int(sh.shape[1])
+            prm.flags = _lib.FLAG_SHARED_CAMPOS if (shared_campos or v == 1) else 0
+            prm.max_instances = int(max_instances) if max_instances else default_capacity(p, v)
+            images, radii, state = _forward_call(prm, vw, m3, c6, op, sh, col, want_radii)
+            if check == "sync" and state.overflowed():
+                prm.max_instances = state.num_rendered()
+                images, radii, state = _forward_call(prm, vw, m3, c6, op, sh, col, want_radii)
+        ctx.state = state
+        ctx.has_means2D = means2D is not None
+        ctx.save_for_backward(m3, c6, op, sh, col, vw)
+        _RasterizeViews.last_state = state
+        if radii is None:
+            radii = torch.empty(0, dtype=torch.int32, device=images.device)
+        ctx.mark_non_differentiable(radii)
+        return images, radii
+
+    @staticmethod
+    def backward(ctx, grad_images, _grad_radii):
+        m3, c6, op, sh, col, vw = ctx.saved_tensors
+        state: RasterState = ctx.state
+        prm, lay = state.prm, state.layout
+        dev = m3.device
+        with torch.cuda.device(dev):
+            g = grad_images.detach().float().contiguous()
+            p, v = prm.P, prm.V
+            d_m3 = torch.empty((p, 3), dtype=torch.float32, device=dev)
+            d_c6 = torch.empty((p, 6), dtype=torch.float32, device=dev)
+            d_op = torch.empty((p,), dtype=torch.float32, device=dev)
+            need = ctx.needs_input_grad
+            d_m2 = torch.empty((v, p, 3), dtype=torch.float32, device=dev) if (ctx.has_means2D and need[1]) else None
+            d_sh = torch.empty_like(sh) if (sh is not None and need[2]) else None
+            d_col = torch.empty((p, 3), dtype=torch.float32, device=dev) if (col is not None and need[3]) else None
+            bws = torch.empty(lay.backward_bytes, dtype=torch.uint8, device=dev)
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            rc = _lib.lib().s360_backward(
+                C.byref(prm), _ptr(vw), _ptr(m3), _ptr(c6), _ptr(op), _ptr(sh), _ptr(col), _ptr(state.workspace),
+                lay.total_bytes, _ptr(g), _ptr(d_m3), _ptr(d_m2), _ptr(d_c6), _ptr(d_op), _ptr(d_sh), _ptr(d_col),
+                _ptr(bws), lay.backward_bytes, stream)
+            _lib.check(rc, "s360_backward")
+        if d_m2 is not None:
+            d_m2 = d_m2.sum(0) if v > 1 else d_m2[0]
+        return d_m3, d_m2, d_sh, d_col, d_op.view(-1, 1), d_c6, None, None
+
+
+_RasterizeViews.last_state = None
+
+
+def rasterize_views(means3D: Tensor, cov6: Tensor, opacities: Tensor, shs: Optional[Tensor] = None,
+                    colors_precomp: Optional[Tensor] = None, *, views: Tensor, image_height: int, image_width: int,
+                    sh_degree: int = 0, shared_campos: bool = False, max_instances: Optional[int] = None,
+                    check: str = "sync", want_radii: bool = True, means2D: Optional[Tensor] = None):
+    """Render V views ([V,42] packed, see pack_views) of one cloud.  Returns (images[V,3,H,W],
+    radii[V,P] int32).  opacities may be [P] or [P,1]; its gradient has the same shape.
+    check="sync": read the overflow flag after the forward (one host sync, like upstream's own
+    scan read-back) and re-run with the exact size if the binning capacity was exceeded;
+    check="lazy": never synchronise — validate later via last_state().overflowed()."""
+    if (shs is None) == (colors_precomp is None):
+        raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+    op2 = opacities.reshape(-1, 1)
+    cfg = (image_height, image_width, sh_degree, shared_campos, max_instances, check, want_radii)
+    return _RasterizeViews.apply(means3D, means2D, shs, colors_precomp, op2, cov6, views, cfg)
+
+
+def last_state() -> Optional[RasterState]:
+    """Workspace of the most recent forward (tests / lazy overflow validation)."""
+    return _RasterizeViews.last_state
+
+
+def _cov6_from_scale_rotation(scales: Tensor, rotations: Tensor, scale_modifier: float) -> Tensor:
+    """Upstream's computeCov3D for the (scales, rotations) input form: Sigma = R S^2 R^T with
+    S = scale_modifier*scales, quaternion (r,x,y,z) not re-normalised.  Plain torch (autograd)."""
+    r, x, y, z = rotations.unbind(-1)
+    rot = torch.stack([
+        1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+        2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+        2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], dim=-1).reshape(-1, 3, 3)
+    m = rot * (scale_modifier * scales)[:, None, :]
+    cov = m @ m.transpose(1, 2)
+    i, j = torch.triu_indices(3, 3)
+    return cov[:, i, j]
+
+
+class GaussianRasterizer(nn.Module):
+    """Drop-in for upstream's module (constructed at cuda_splatting.py:113, called with keywords
+    at :117-124).  Returns (image[3,H,W], radii[P])."""
+
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def forward(self, means3D, means2D=None, opacities=None, shs=None, colors_precomp=None, scales=None,
+                rotations=None, cov3D_precomp=None):
+        s = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or (
+                (scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        if cov3D_precomp is None:
+            cov3D_precomp = _cov6_from_scale_rotation(scales, rotations, s.scale_modifier)
+        views = pack_views(s.viewmatrix, s.projmatrix, s.campos, s.tanfovx, s.tanfovy, s.bg)
+        images, radii = rasterize_views(
+            means3D, cov3D_precomp, opacities, shs, colors_precomp, views=views, image_height=s.image_height,
+            image_width=s.image_width, sh_degree=s.sh_degree, shared_campos=True, means2D=means2D)
+        return images[0], radii[0]
