@@ -78,7 +78,7 @@ typedef struct S360Layout {
     size_t scan_scratch;        /* uint32[...] */
     size_t rec_a;               /* float4[V*P]  x, y, conic.a, conic.b */
     size_t rec_b;               /* float4[V*P]  conic.c, opacity, r, g */
-    size_t rec_c;               /* float4[V*P]  b, depth, rect_min (x | y<<16), rect_max (x | y<<16) */
+    size_t rec_c;               /* float4[V*P]  b, depth, radius (int32 bits), conservative cull radius */
     size_t clamped;             /* uint8[V*P]   bit c set: colour channel c was clamped at 0 */
     size_t tile_count;          /* uint32[V*T] */
     size_t tile_start;          /* uint32[V*T+1] exclusive scan (upstream ranges: [start[t], start[t+1])) */

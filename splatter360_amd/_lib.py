@@ -58,7 +58,8 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     """hipcc --offload-arch=gfx950 ... -> splatter360_amd/libs360.so (in-tree)."""
     if not force and not needs_build():
         return LIB_PATH
-    cmd = [_hipcc(), *HIPCC_FLAGS, *[str(_CSRC / s) for s in SOURCES], "-o", str(LIB_PATH)]
+    extra = os.environ.get("S360_HIPCC_EXTRA", "").split()
+    cmd = [_hipcc(), *HIPCC_FLAGS, *extra, *[str(_CSRC / s) for s in SOURCES], "-o", str(LIB_PATH)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or r.returncode:
         print(" ".join(cmd))

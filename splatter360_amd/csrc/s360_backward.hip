@@ -75,11 +75,12 @@ __global__ __launch_bounds__(S360_BLOCK) void k_render_bwd(
             const uint32_t idx = (uint32_t)(hi - threadIdx.x);
             const uint32_t p = list[start + idx];
             const float4 c = recC[p];
-            sA[threadIdx.x] = recA[p];
+            const float4 a4 = recA[p];
+            sA[threadIdx.x] = a4;
             sB[threadIdx.x] = recB[p];
             sC[threadIdx.x] = c.x;
-            const uint32_t rmin = __float_as_uint(c.z), rmax = __float_as_uint(c.w);
-            const int minx = rmin & 0xFFFF, miny = rmin >> 16, maxx = rmax & 0xFFFF;
+            int minx, miny, maxx, maxy;
+            tile_rect(a4.x, a4.y, __float_as_int(c.z), kp.gx, kp.gy, minx, miny, maxx, maxy);
             const uint32_t base = p == 0 ? 0u : offsets[p - 1];
             sInst[threadIdx.x] = base + (uint32_t)((ty - miny) * (maxx - minx) + (tx - minx));
         }

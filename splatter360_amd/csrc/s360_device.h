@@ -164,6 +164,17 @@ __device__ __forceinline__ void geo_compute(const float* V, float tanfovx, float
     g.c += 0.3f;
 }
 
+// Tile rectangle of a splat (same float expression everywhere it is needed: preprocess, emit and
+// the backward instance index all recompute it from the stored centre and integer radius).
+__device__ __forceinline__ void tile_rect(float px, float py, int radius, int gx, int gy, int& minx, int& miny,
+                                          int& maxx, int& maxy) {
+    const float rr = (float)radius;
+    minx = min(gx, max(0, (int)((px - rr) / 16.0f)));
+    miny = min(gy, max(0, (int)((py - rr) / 16.0f)));
+    maxx = min(gx, max(0, (int)((px + rr + 15.0f) / 16.0f)));
+    maxy = min(gy, max(0, (int)((py + rr + 15.0f) / 16.0f)));
+}
+
 // ---- wave64 primitives -------------------------------------------------------------------
 template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF, bool BOUND = true>
 __device__ __forceinline__ float dpp_f(float v) {

@@ -22,13 +22,18 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess(
     const float* __restrict__ cov6, const float* __restrict__ opac, const float* __restrict__ shs,
     const float* __restrict__ colors, int32_t* __restrict__ radii, uint32_t* __restrict__ tiles_touched,
     float4* __restrict__ recA, float4* __restrict__ recB, float4* __restrict__ recC,
-    uint8_t* __restrict__ clamped, uint32_t* __restrict__ tile_count) {
+    uint8_t* __restrict__ clamped, uint32_t* __restrict__ tile_count, int lds_hist) {
+    // dynamic LDS: [SH slab: 256*M*3 floats (USE_SH)] [tile histogram: V*T uint32 (lds_hist)]
     extern __shared__ __attribute__((aligned(16))) float lds_sh[];
     const int tid = threadIdx.x;
     const int g0 = blockIdx.x * S360_BLOCK;
     const int g = g0 + tid;
     const int P = kp.P;
     const int nb = min(S360_BLOCK, P - g0);  // Gaussians handled by this block
+    uint32_t* hist = reinterpret_cast<uint32_t*>(lds_sh + (USE_SH ? S360_BLOCK * kp.M * 3 : 0));
+    const int nhist = kp.V * kp.T;
+    if (lds_hist)
+        for (int i = tid; i < nhist; i += S360_BLOCK) hist[i] = 0u;
 
     if (USE_SH) {
         // coalesced stage of this block's SH slab: nb*M*3 contiguous floats
@@ -43,10 +48,9 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess(
         } else {
             for (int i = tid; i < nfl; i += S360_BLOCK) lds_sh[i] = src[i];
         }
-        __syncthreads();
     }
-    if (g >= P) return;
-
+    __syncthreads();
+    if (g < P) {
     const float mx = means[3 * g], my = means[3 * g + 1], mz = means[3 * g + 2];
     float c6[6];
 #pragma unroll
@@ -90,11 +94,8 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess(
                 const int rad = (int)ceilf(3.0f * sqrtf(fmaxf(lam1, lam2)));
                 const float px = ((prx + 1.0f) * (float)kp.W - 1.0f) * 0.5f;
                 const float py = ((pry + 1.0f) * (float)kp.H - 1.0f) * 0.5f;
-                const float rr = (float)rad;
-                const int minx = min(kp.gx, max(0, (int)((px - rr) / 16.0f)));
-                const int miny = min(kp.gy, max(0, (int)((py - rr) / 16.0f)));
-                const int maxx = min(kp.gx, max(0, (int)((px + rr + 15.0f) / 16.0f)));
-                const int maxy = min(kp.gy, max(0, (int)((py + rr + 15.0f) / 16.0f)));
+                int minx, miny, maxx, maxy;
+                tile_rect(px, py, rad, kp.gx, kp.gy, minx, miny, maxx, maxy);
                 const int area = (maxx - minx) * (maxy - miny);
                 if (area != 0) {
                     if (USE_SH && (!have_rgb || !shared_cam)) {
@@ -125,10 +126,14 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess(
                     touched = (uint32_t)area;
                     recA[p] = make_float4(px, py, conA, conB);
                     recB[p] = make_float4(conC, op, rgb[0], rgb[1]);
-                    recC[p] = make_float4(rgb[2], pvz, __uint_as_float((uint32_t)minx | ((uint32_t)miny << 16)),
-                                          __uint_as_float((uint32_t)maxx | ((uint32_t)maxy << 16)));
+                    // conservative cull radius: alpha = o*exp(power) <= o*exp(-|d|^2 / (2 lambda_max)), so
+                    // outside |d| > sqrt(2 lambda_max ln(255 o)) the 1/255 test always rejects.
+                    const float l255 = __logf(255.0f * op);
+                    const float rcull = (255.0f * op > 1.0f) ? sqrtf(2.0f * fmaxf(lam1, lam2) * l255) * 1.001f + 0.01f : -1.0f;
+                    recC[p] = make_float4(rgb[2], pvz, __int_as_float(rad), rcull);
                     clamped[p] = (uint8_t)clampbits;
-                    uint32_t* tc = tile_count + (size_t)v * kp.T;
+                    // block-local histogram in LDS; one global atomic per (block, touched tile) below
+                    uint32_t* tc = (lds_hist ? hist : tile_count) + (size_t)v * kp.T;
                     for (int y = miny; y < maxy; ++y)
                         for (int x = minx; x < maxx; ++x) atomicAdd(&tc[y * kp.gx + x], 1u);
                 }
@@ -136,6 +141,14 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess(
         }
         if (radii) radii[p] = radius;
         tiles_touched[p] = touched;
+    }
+    }  // g < P
+    if (lds_hist) {
+        __syncthreads();
+        for (int i = tid; i < nhist; i += S360_BLOCK) {
+            const uint32_t c = hist[i];
+            if (c) atomicAdd(&tile_count[i], c);
+        }
     }
 }
 
@@ -247,32 +260,67 @@ __global__ __launch_bounds__(S360_BLOCK) void k_tile_scan(const uint32_t* __rest
 }
 
 // ------------------------------------------------------------------------------ emit
+// grid (ceil(P/256), V).  LDS_BIN: block-local two-pass binning — count the block's instances per
+// tile in LDS, reserve one contiguous range per (block, tile) with a single returning global
+// atomic, then place.  (Order inside a tile's bucket is irrelevant: the bucket is sorted next.)
+template <bool LDS_BIN>
 __global__ __launch_bounds__(S360_BLOCK) void k_emit(KParams kp, const uint32_t* __restrict__ tiles_touched,
-                                                    const float4* __restrict__ recC, const uint32_t* __restrict__ tile_start,
+                                                    const float4* __restrict__ recA, const float4* __restrict__ recC,
+                                                    const uint32_t* __restrict__ tile_start,
                                                     uint32_t* __restrict__ tile_cursor, uint64_t* __restrict__ keys) {
-    const size_t p = (size_t)blockIdx.x * S360_BLOCK + threadIdx.x;
-    const size_t np = (size_t)kp.V * kp.P;
-    if (p >= np) return;
-    if (tiles_touched[p] == 0) return;
-    const float4 rc = recC[p];
-    const uint32_t rmin = __float_as_uint(rc.z), rmax = __float_as_uint(rc.w);
-    const int minx = rmin & 0xFFFF, miny = rmin >> 16, maxx = rmax & 0xFFFF, maxy = rmax >> 16;
-    const int v = (int)(p / kp.P);
-    const uint64_t key = ((uint64_t)__float_as_uint(rc.y) << 32) | (uint64_t)(uint32_t)p;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_bin[];  // [T] counts/cursors, [T] bases
+    const int v = blockIdx.y;
+    const int g = blockIdx.x * S360_BLOCK + threadIdx.x;
     const size_t tb = (size_t)v * kp.T;
-    for (int y = miny; y < maxy; ++y)
-        for (int x = minx; x < maxx; ++x) {
-            const size_t t = tb + y * kp.gx + x;
-            const uint32_t pos = tile_start[t] + atomicAdd(&tile_cursor[t], 1u);
-            if (pos < kp.cap) keys[pos] = key;
+    uint32_t* cnt = lds_bin;
+    uint32_t* base = lds_bin + kp.T;
+    if (LDS_BIN) {
+        for (int i = threadIdx.x; i < kp.T; i += S360_BLOCK) cnt[i] = 0u;
+        __syncthreads();
+    }
+    const size_t p = (size_t)v * kp.P + g;
+    const bool act = g < kp.P && tiles_touched[p] != 0;
+    int minx = 0, miny = 0, maxx = 0, maxy = 0;
+    uint64_t key = 0;
+    if (act) {
+        const float4 rc = recC[p];
+        const float4 ra = recA[p];
+        tile_rect(ra.x, ra.y, __float_as_int(rc.z), kp.gx, kp.gy, minx, miny, maxx, maxy);
+        key = ((uint64_t)__float_as_uint(rc.y) << 32) | (uint64_t)(uint32_t)p;
+    }
+    if (LDS_BIN) {
+        for (int y = miny; y < maxy; ++y)
+            for (int x = minx; x < maxx; ++x) atomicAdd(&cnt[y * kp.gx + x], 1u);
+        __syncthreads();
+        for (int i = threadIdx.x; i < kp.T; i += S360_BLOCK) {
+            const uint32_t c = cnt[i];
+            if (c) {
+                base[i] = tile_start[tb + i] + atomicAdd(&tile_cursor[tb + i], c);
+                cnt[i] = 0u;
+            }
         }
+        __syncthreads();
+        for (int y = miny; y < maxy; ++y)
+            for (int x = minx; x < maxx; ++x) {
+                const int t = y * kp.gx + x;
+                const uint32_t pos = base[t] + atomicAdd(&cnt[t], 1u);
+                if (pos < kp.cap) keys[pos] = key;
+            }
+    } else {
+        for (int y = miny; y < maxy; ++y)
+            for (int x = minx; x < maxx; ++x) {
+                const size_t t = tb + y * kp.gx + x;
+                const uint32_t pos = tile_start[t] + atomicAdd(&tile_cursor[t], 1u);
+                if (pos < kp.cap) keys[pos] = key;
+            }
+    }
 }
 
 // ------------------------------------------------------------------------------ per-tile sort
 // One workgroup per tile whose list length n satisfies lo < n <= CAP: bitonic sort of the unique
 // 64-bit keys in LDS, then writes the sorted keys back and the pair list.
-template <int CAP>
-__global__ __launch_bounds__(S360_BLOCK) void k_sort_tiles(const uint32_t* __restrict__ tile_start, uint64_t* __restrict__ keys,
+template <int CAP, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_sort_tiles(const uint32_t* __restrict__ tile_start, uint64_t* __restrict__ keys,
                                                           uint32_t* __restrict__ list, uint32_t lo, uint32_t cap) {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds_k[];
     const uint32_t s = min(tile_start[blockIdx.x], cap), e = min(tile_start[blockIdx.x + 1], cap);
@@ -280,11 +328,11 @@ __global__ __launch_bounds__(S360_BLOCK) void k_sort_tiles(const uint32_t* __res
     if (n <= lo || n > (uint32_t)CAP) return;
     uint32_t npad = 1;
     while (npad < n) npad <<= 1;
-    for (uint32_t i = threadIdx.x; i < npad; i += S360_BLOCK) lds_k[i] = i < n ? keys[s + i] : ~0ull;
+    for (uint32_t i = threadIdx.x; i < npad; i += THREADS) lds_k[i] = i < n ? keys[s + i] : ~0ull;
     __syncthreads();
     for (uint32_t k = 2; k <= npad; k <<= 1) {
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t t = threadIdx.x; t < (npad >> 1); t += S360_BLOCK) {
+            for (uint32_t t = threadIdx.x; t < (npad >> 1); t += THREADS) {
                 const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // index with bit j clear
                 const uint32_t l = i | j;
                 const uint64_t a = lds_k[i], b = lds_k[l];
@@ -297,7 +345,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_sort_tiles(const uint32_t* __res
             __syncthreads();
         }
     }
-    for (uint32_t i = threadIdx.x; i < n; i += S360_BLOCK) {
+    for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
         const uint64_t k = lds_k[i];
         keys[s + i] = k;
         list[s + i] = (uint32_t)k;
@@ -335,6 +383,11 @@ __global__ __launch_bounds__(S360_BLOCK) void k_sort_tiles_global(const uint32_t
 }
 
 // ------------------------------------------------------------------------------ composite
+// One workgroup per 16x16 tile; wave w owns the 16x4 pixel strip w.  Each batch of 256 list
+// entries is staged into LDS once; while staging, every entry is tested against the four strips
+// with its conservative cull radius and the four 64-bit ballots per staging wave are published, so
+// a wave only walks (scalar bit-scan) the entries that can reach its strip.  Culled entries would
+// have failed the alpha >= 1/255 test for every pixel of the strip, so results are unchanged.
 __global__ __launch_bounds__(S360_BLOCK) void k_render(KParams kp, const S360View* __restrict__ views,
                                                       const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ list,
                                                       const float4* __restrict__ recA, const float4* __restrict__ recB,
@@ -344,6 +397,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_render(KParams kp, const S360Vie
     __shared__ float4 sA[S360_BLOCK];
     __shared__ float4 sB[S360_BLOCK];
     __shared__ float sC[S360_BLOCK];
+    __shared__ unsigned long long sMask[4][4];  // [staging wave][strip]
     __shared__ uint32_t s_maxc;
 
     const int t = blockIdx.x;
@@ -353,10 +407,12 @@ __global__ __launch_bounds__(S360_BLOCK) void k_render(KParams kp, const S360Vie
     const int px = tx * 16 + lx, py = ty * 16 + ly;
     const bool inside = px < kp.W && py < kp.H;
     const float pxf = (float)px, pyf = (float)py;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float x0 = (float)(tx * 16), y0 = (float)(ty * 16);
 
     const uint32_t start = min(tile_start[t], kp.cap), end = min(tile_start[t + 1], kp.cap);
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
-    uint32_t contributor = 0, last = 0;
+    uint32_t last = 0;
     bool done = !inside;
     if (threadIdx.x == 0) s_maxc = 0;
 
@@ -364,35 +420,64 @@ __global__ __launch_bounds__(S360_BLOCK) void k_render(KParams kp, const S360Vie
         // barrier + early out when every pixel of the tile is saturated
         if (__syncthreads_count(done ? 1 : 0) == S360_BLOCK) break;
         const uint32_t idx = b + threadIdx.x;
+        bool m0 = false, m1 = false, m2 = false, m3 = false;
         if (idx < end) {
             const uint32_t p = list[idx];
-            sA[threadIdx.x] = recA[p];
+            const float4 a = recA[p];
+            const float4 c = recC[p];
+            sA[threadIdx.x] = a;
             sB[threadIdx.x] = recB[p];
-            sC[threadIdx.x] = recC[p].x;
+            sC[threadIdx.x] = c.x;
+            const float r = c.w;
+            const bool xin = !(a.x + r < x0 || a.x - r > x0 + 15.0f);
+            m0 = xin && !(a.y + r < y0 || a.y - r > y0 + 3.0f);
+            m1 = xin && !(a.y + r < y0 + 4.0f || a.y - r > y0 + 7.0f);
+            m2 = xin && !(a.y + r < y0 + 8.0f || a.y - r > y0 + 11.0f);
+            m3 = xin && !(a.y + r < y0 + 12.0f || a.y - r > y0 + 15.0f);
+        }
+#ifdef S360_DBG_NOCULL
+        m0 = m1 = m2 = m3 = idx < end;
+#endif
+        const unsigned long long b0 = __ballot(m0), b1 = __ballot(m1), b2 = __ballot(m2), b3 = __ballot(m3);
+        if (lane == 0) {
+            sMask[wave][0] = b0;
+            sMask[wave][1] = b1;
+            sMask[wave][2] = b2;
+            sMask[wave][3] = b3;
         }
         __syncthreads();
-        const int cnt = (int)min((uint32_t)S360_BLOCK, end - b);
-        if (!done) {
-            for (int j = 0; j < cnt; ++j) {
-                ++contributor;
-                const float4 a = sA[j];
-                const float4 bb = sB[j];
-                const float dx = a.x - pxf, dy = a.y - pyf;
-                const float power = -0.5f * (a.z * dx * dx + bb.x * dy * dy) - a.w * dx * dy;
-                if (power > 0.0f) continue;
-                const float alpha = fminf(0.99f, bb.y * __expf(power));
-                if (alpha < 1.0f / 255.0f) continue;
-                const float test_T = T * (1.0f - alpha);
-                if (test_T < 0.0001f) {
-                    done = true;
-                    break;
+        const uint32_t rel = b - start;  // list position of batch element 0
+        if (__ballot(!done) != 0ull) {
+#pragma unroll 1
+            for (int chunk = 0; chunk < 4; ++chunk) {
+                unsigned long long m = sMask[chunk][wave];
+                // (readfirstlane returns a signed int: cast to uint32_t before widening)
+                m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(m >> 32)) << 32) |
+                    (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m);
+                while (m) {
+                    const int bit = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const int j = chunk * 64 + bit;
+                    if (done) continue;
+                    const float4 a = sA[j];
+                    const float4 bb = sB[j];
+                    const float dx = a.x - pxf, dy = a.y - pyf;
+                    const float power = -0.5f * (a.z * dx * dx + bb.x * dy * dy) - a.w * dx * dy;
+                    if (power > 0.0f) continue;
+                    const float alpha = fminf(0.99f, bb.y * __expf(power));
+                    if (alpha < 1.0f / 255.0f) continue;
+                    const float test_T = T * (1.0f - alpha);
+                    if (test_T < 0.0001f) {
+                        done = true;
+                        continue;
+                    }
+                    const float w = alpha * T;
+                    C0 += bb.z * w;
+                    C1 += bb.w * w;
+                    C2 += sC[j] * w;
+                    T = test_T;
+                    last = rel + (uint32_t)j + 1u;
                 }
-                const float w = alpha * T;
-                C0 += bb.z * w;
-                C1 += bb.w * w;
-                C2 += sC[j] * w;
-                T = test_T;
-                last = contributor;
             }
         }
     }
@@ -408,7 +493,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_render(KParams kp, const S360Vie
         n_contrib[(size_t)v * hw + pix] = last;
     }
     const uint32_t wm = wave_max_u32(inside ? last : 0u);
-    if (lane_id() == 0) atomicMax(&s_maxc, wm);
+    if (lane == 0) atomicMax(&s_maxc, wm);
     __syncthreads();
     if (threadIdx.x == 0) tile_max_contrib[t] = s_maxc;
 }
@@ -505,15 +590,20 @@ extern "C" int s360_forward(const S360Params* prm, const S360View* views, const 
     if (hipMemsetAsync(tile_count, 0, (size_t)nt * 4, st) != hipSuccess) return S360_E_LAUNCH;
     if (kp.P > 0) {
         const int nblk = (kp.P + S360_BLOCK - 1) / S360_BLOCK;
+        const size_t hist_bytes = (size_t)nt * 4;
+        const int lds_hist = hist_bytes <= 48 * 1024 ? 1 : 0;
         if (shs) {
-            const size_t lds = (size_t)S360_BLOCK * kp.M * 3 * 4;
-            if (lds > 160 * 1024) return S360_E_UNSUPPORTED;
-            hipFuncSetAttribute((const void*)k_preprocess<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            size_t lds = (size_t)S360_BLOCK * kp.M * 3 * 4;
+            if (lds > 160 * 1024 - (lds_hist ? hist_bytes : 0)) return S360_E_UNSUPPORTED;
+            lds += lds_hist ? hist_bytes : 0;
+            (void)hipFuncSetAttribute((const void*)k_preprocess<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             hipLaunchKernelGGL(k_preprocess<true>, dim3(nblk), dim3(S360_BLOCK), lds, st, kp, views, means3D, cov6,
-                               opacities, shs, colors_precomp, radii, tiles_touched, recA, recB, recC, clamped, tile_count);
+                               opacities, shs, colors_precomp, radii, tiles_touched, recA, recB, recC, clamped, tile_count,
+                               lds_hist);
         } else {
-            hipLaunchKernelGGL(k_preprocess<false>, dim3(nblk), dim3(S360_BLOCK), 0, st, kp, views, means3D, cov6,
-                               opacities, shs, colors_precomp, radii, tiles_touched, recA, recB, recC, clamped, tile_count);
+            hipLaunchKernelGGL(k_preprocess<false>, dim3(nblk), dim3(S360_BLOCK), lds_hist ? hist_bytes : 0, st, kp, views,
+                               means3D, cov6, opacities, shs, colors_precomp, radii, tiles_touched, recA, recB, recC, clamped,
+                               tile_count, lds_hist);
         }
         S360_CHECK_LAUNCH();
         const int sblk = (int)((np + SCAN_TILE - 1) / SCAN_TILE);
@@ -525,12 +615,18 @@ extern "C" int s360_forward(const S360Params* prm, const S360View* views, const 
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(S360_BLOCK), 0, st, tile_count, tile_start, tile_cursor, nt, kp.cap, header);
     S360_CHECK_LAUNCH();
     if (kp.P > 0) {
-        const int eblk = (int)((np + S360_BLOCK - 1) / S360_BLOCK);
-        hipLaunchKernelGGL(k_emit, dim3(eblk), dim3(S360_BLOCK), 0, st, kp, tiles_touched, recC, tile_start, tile_cursor, keys);
+        const dim3 egrid((kp.P + S360_BLOCK - 1) / S360_BLOCK, kp.V);
+        if ((size_t)kp.T * 8 <= 64 * 1024)
+            hipLaunchKernelGGL(k_emit<true>, egrid, dim3(S360_BLOCK), (size_t)kp.T * 8, st, kp, tiles_touched, recA, recC,
+                               tile_start, tile_cursor, keys);
+        else
+            hipLaunchKernelGGL(k_emit<false>, egrid, dim3(S360_BLOCK), 0, st, kp, tiles_touched, recA, recC, tile_start,
+                               tile_cursor, keys);
         S360_CHECK_LAUNCH();
-        hipFuncSetAttribute((const void*)k_sort_tiles<16384>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL(k_sort_tiles<2048>, dim3(nt), dim3(S360_BLOCK), 2048 * 8, st, tile_start, keys, list, 0u, kp.cap);
-        hipLaunchKernelGGL(k_sort_tiles<16384>, dim3(nt), dim3(S360_BLOCK), 16384 * 8, st, tile_start, keys, list, 2048u, kp.cap);
+        (void)hipFuncSetAttribute((const void*)k_sort_tiles<16384, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL((k_sort_tiles<1024, 256>), dim3(nt), dim3(256), 1024 * 8, st, tile_start, keys, list, 0u, kp.cap);
+        hipLaunchKernelGGL((k_sort_tiles<4096, 512>), dim3(nt), dim3(512), 4096 * 8, st, tile_start, keys, list, 1024u, kp.cap);
+        hipLaunchKernelGGL((k_sort_tiles<16384, 1024>), dim3(nt), dim3(1024), 16384 * 8, st, tile_start, keys, list, 4096u, kp.cap);
         hipLaunchKernelGGL(k_sort_tiles_global, dim3(nt), dim3(S360_BLOCK), 0, st, tile_start, keys, list, 16384u, kp.cap);
         S360_CHECK_LAUNCH();
     }
