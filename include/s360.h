@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define S360_ABI_VERSION 1
+#define S360_ABI_VERSION 2
 #define S360_MAX_VIEWS 8
 #define S360_TILE 16
 
@@ -42,11 +42,21 @@ enum {
 };
 
 /* flags */
-#define S360_FLAG_SHARED_CAMPOS 1u /* all V views share campos: SH->RGB evaluated once per Gaussian */
+#define S360_FLAG_SHARED_CAMPOS 1u    /* all V views share campos (and scale): SH->RGB evaluated once per Gaussian */
+#define S360_FLAG_COV9 2u             /* covariances given (and their gradient returned) as [P,3,3] row-major, the
+                                         reference's Gaussians.covariances layout (src/model/types.py:9); only the
+                                         upper triangle is read / receives gradient, exactly like the
+                                         cov[:, row, col] gather at cuda_splatting.py:115,123 */
+#define S360_FLAG_SH_CHANNEL_MAJOR 4u /* SH given (and gradient returned) as [P,3,M], the reference's
+                                         Gaussians.harmonics layout (types.py:10) — no "b g xyz n -> b g n xyz"
+                                         rearrange copy (cuda_splatting.py:75) */
 
 /*
- * One camera, exactly the per-call fields of GaussianRasterizationSettings
- * (cuda_splatting.py:99-112).  42 floats, lives in DEVICE memory (array of V).
+ * One camera: the per-call fields of GaussianRasterizationSettings (cuda_splatting.py:99-112)
+ * plus the scale-invariant factor of cuda_splatting.py:64-71.  44 floats, DEVICE memory (array
+ * of V).  `scale` multiplies means3D (and scale^2 the covariances) inside the kernels — pass the
+ * UNSCALED cloud and scale = 1/near to fuse the reference's three full-size rescale copies; pass
+ * 1.0 when the cloud is already scaled (drop-in rasteriser call).
  * viewmatrix / projmatrix are the flat [4,4] tensors handed over at cuda_splatting.py:86-87
  * (row-vector convention: element [r][c] of the transposed matrix at index 4*r+c).
  */
@@ -56,6 +66,8 @@ typedef struct S360View {
     float campos[3];
     float tanfovx, tanfovy;
     float bg[3];
+    float scale;
+    float _pad[3];
 } S360View;
 
 typedef struct S360Params {
@@ -101,8 +113,9 @@ int s360_layout(const S360Params* prm, S360Layout* out);
 /*
  * Forward: replaces upstream `rasterize_gaussians(...)` as reached from
  * GaussianRasterizer.forward (call site cuda_splatting.py:117-124).
- *   views[V] (device)  means3D[P,3]  cov6[P,6] (cov3D_precomp, order 00,01,02,11,12,22)
- *   opacities[P]  shs[P,M,3] or NULL  colors_precomp[P,3] or NULL (exactly one non-NULL)
+ *   views[V] (device)  means3D[P,3]  cov6[P,6] (cov3D_precomp, order 00,01,02,11,12,22; [P,3,3] with
+ *   S360_FLAG_COV9)  opacities[P]  shs[P,M,3] ([P,3,M] with S360_FLAG_SH_CHANNEL_MAJOR) or NULL
+ *   colors_precomp[P,3] or NULL (exactly one of shs / colors_precomp non-NULL)
  * Outputs: images[V,3,H,W], radii[V,P] (int32), plus state in `workspace`.
  */
 int s360_forward(const S360Params* prm, const S360View* views, const float* means3D,
@@ -116,7 +129,8 @@ int s360_forward(const S360Params* prm, const S360View* views, const float* mean
  *   dL_dimages[V,3,H,W]
  * Outputs (all written, no accumulation into caller data):
  *   d_means3D[P,3]  d_means2D[V,P,3] (NDC-scaled screen-space gradient, z = 0)
- *   d_cov6[P,6]  d_opacities[P]  d_shs[P,M,3] or NULL  d_colors[P,3] or NULL
+ *   d_cov6[P,6]  d_opacities[P]  d_shs[P,M,3] or NULL  d_colors[P,3] or NULL  (d_cov6 / d_shs in the
+ *   layouts selected by the flags; gradients are w.r.t. the UNSCALED inputs)
  * Gradients are summed over the V views with a fixed (deterministic) order.
  */
 int s360_backward(const S360Params* prm, const S360View* views, const float* means3D,

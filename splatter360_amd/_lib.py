@@ -20,6 +20,9 @@ HIPCC_FLAGS = ("--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 
 S360_MAX_VIEWS = 8
 FLAG_SHARED_CAMPOS = 1
+FLAG_COV9 = 2
+FLAG_SH_CHANNEL_MAJOR = 4
+ABI_VERSION = 2
 
 
 class S360Params(C.Structure):
@@ -96,7 +99,7 @@ def lib() -> C.CDLL:
     l.s360_cube2erp_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, C.POINTER(i32), vp]
     l.s360_cube2erp_backward.restype = C.c_int
     l.s360_cube2erp_backward.argtypes = [vp, vp, vp, i32, i32, i32, i32, C.POINTER(i32), vp]
-    if l.s360_abi_version() != 1:
+    if l.s360_abi_version() != ABI_VERSION:
         raise RuntimeError("libs360.so ABI version mismatch")
     _lib = l
     return l

@@ -196,10 +196,13 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess_bwd(
     const bool shared_cam = (kp.flags & S360_FLAG_SHARED_CAMPOS) != 0;
     const int n_sh = (kp.deg + 1) * (kp.deg + 1);
     if (g < P) {
-        const float mx = means[3 * g], my = means[3 * g + 1], mz = means[3 * g + 2];
-        float c6[6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) c6[k] = cov6[6 * (size_t)g + k];
+        const float mx0 = means[3 * g], my0 = means[3 * g + 1], mz0 = means[3 * g + 2];
+        float c60[6];
+        const bool cov9 = (kp.flags & S360_FLAG_COV9) != 0;
+        // SH element (k, c) inside this Gaussian's slab for either layout
+        const int sk = (kp.flags & S360_FLAG_SH_CHANNEL_MAJOR) ? 1 : 3;
+        const int sc_ = (kp.flags & S360_FLAG_SH_CHANNEL_MAJOR) ? kp.M : 1;
+        load_cov6(cov6, g, cov9, c60);
         float dm0 = 0.f, dm1 = 0.f, dm2 = 0.f, dop = 0.f;
         float dc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         float drgb_sum[3] = {0.f, 0.f, 0.f};  // clamp-masked, summed over views
@@ -211,6 +214,14 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess_bwd(
             const size_t p = (size_t)v * P + g;
             float gx_ = 0.f, gy_ = 0.f;
             float drgb_v[3] = {0.f, 0.f, 0.f};
+            // gradients w.r.t. the scaled cloud of this view; folded back with scale / scale^2 below
+            const float sc = views[v].scale, sc2 = sc * sc;
+            const float mx = mx0 * sc, my = my0 * sc, mz = mz0 * sc;
+            float c6[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) c6[k] = c60[k] * sc2;
+            float dmv0 = 0.f, dmv1 = 0.f, dmv2 = 0.f;
+            float dcv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (tiles_touched[p] != 0) {
                 any_visible = true;
                 if (first_visible < 0) first_visible = v;
@@ -237,12 +248,12 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess_bwd(
                     dL_dc = d2inv * (-a * a * gC + a * b * gB + (det - a * c) * gA);
                     dL_db = d2inv * (2.f * b * c * gA - (det + 2.f * b * b) * gB + 2.f * a * b * gC);
                     const float *M0 = ge.M0, *M1 = ge.M1;
-                    dc[0] += M0[0] * M0[0] * dL_da + M0[0] * M1[0] * dL_db + M1[0] * M1[0] * dL_dc;
-                    dc[3] += M0[1] * M0[1] * dL_da + M0[1] * M1[1] * dL_db + M1[1] * M1[1] * dL_dc;
-                    dc[5] += M0[2] * M0[2] * dL_da + M0[2] * M1[2] * dL_db + M1[2] * M1[2] * dL_dc;
-                    dc[1] += 2.f * M0[0] * M0[1] * dL_da + (M0[0] * M1[1] + M0[1] * M1[0]) * dL_db + 2.f * M1[0] * M1[1] * dL_dc;
-                    dc[2] += 2.f * M0[0] * M0[2] * dL_da + (M0[0] * M1[2] + M0[2] * M1[0]) * dL_db + 2.f * M1[0] * M1[2] * dL_dc;
-                    dc[4] += 2.f * M0[1] * M0[2] * dL_da + (M0[1] * M1[2] + M0[2] * M1[1]) * dL_db + 2.f * M1[1] * M1[2] * dL_dc;
+                    dcv[0] += M0[0] * M0[0] * dL_da + M0[0] * M1[0] * dL_db + M1[0] * M1[0] * dL_dc;
+                    dcv[3] += M0[1] * M0[1] * dL_da + M0[1] * M1[1] * dL_db + M1[1] * M1[1] * dL_dc;
+                    dcv[5] += M0[2] * M0[2] * dL_da + M0[2] * M1[2] * dL_db + M1[2] * M1[2] * dL_dc;
+                    dcv[1] += 2.f * M0[0] * M0[1] * dL_da + (M0[0] * M1[1] + M0[1] * M1[0]) * dL_db + 2.f * M1[0] * M1[1] * dL_dc;
+                    dcv[2] += 2.f * M0[0] * M0[2] * dL_da + (M0[0] * M1[2] + M0[2] * M1[0]) * dL_db + 2.f * M1[0] * M1[2] * dL_dc;
+                    dcv[4] += 2.f * M0[1] * M0[2] * dL_da + (M0[1] * M1[2] + M0[2] * M1[1]) * dL_db + 2.f * M1[1] * M1[2] * dL_dc;
                 }
                 float dM0[3], dM1[3];
 #pragma unroll
@@ -263,9 +274,9 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess_bwd(
                 const float dt1 = (ge.yin ? 1.f : 0.f) * (-ge.fy * tz2 * dJ12);
                 const float dt2 = -ge.fx * tz2 * dJ00 - ge.fy * tz2 * dJ11 + (2.f * ge.fx * ge.txc) * tz3 * dJ02 +
                                   (2.f * ge.fy * ge.tyc) * tz3 * dJ12;
-                dm0 += V[0] * dt0 + V[1] * dt1 + V[2] * dt2;
-                dm1 += V[4] * dt0 + V[5] * dt1 + V[6] * dt2;
-                dm2 += V[8] * dt0 + V[9] * dt1 + V[10] * dt2;
+                dmv0 += V[0] * dt0 + V[1] * dt1 + V[2] * dt2;
+                dmv1 += V[4] * dt0 + V[5] * dt1 + V[6] * dt2;
+                dmv2 += V[8] * dt0 + V[9] * dt1 + V[10] * dt2;
                 // projection chain (NDC-scaled screen-space gradient)
                 const float m2x = gx_ * (0.5f * (float)kp.W), m2y = gy_ * (0.5f * (float)kp.H);
                 gx_ = m2x;
@@ -276,9 +287,9 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess_bwd(
                 const float mhw = Pm[3] * mx + Pm[7] * my + Pm[11] * mz + Pm[15];
                 const float mw = 1.f / (mhw + 0.0000001f);
                 const float mul1 = mhx * mw * mw, mul2 = mhy * mw * mw;
-                dm0 += (Pm[0] * mw - Pm[3] * mul1) * m2x + (Pm[1] * mw - Pm[3] * mul2) * m2y;
-                dm1 += (Pm[4] * mw - Pm[7] * mul1) * m2x + (Pm[5] * mw - Pm[7] * mul2) * m2y;
-                dm2 += (Pm[8] * mw - Pm[11] * mul1) * m2x + (Pm[9] * mw - Pm[11] * mul2) * m2y;
+                dmv0 += (Pm[0] * mw - Pm[3] * mul1) * m2x + (Pm[1] * mw - Pm[3] * mul2) * m2y;
+                dmv1 += (Pm[4] * mw - Pm[7] * mul1) * m2x + (Pm[5] * mw - Pm[7] * mul2) * m2y;
+                dmv2 += (Pm[8] * mw - Pm[11] * mul1) * m2x + (Pm[9] * mw - Pm[11] * mul2) * m2y;
                 if (USE_SH) {
                     const uint32_t cb = clamped[p];
                     drgb_v[0] = (cb & 1u) ? 0.f : gr;
@@ -312,15 +323,20 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess_bwd(
                     const float* sh = lds_sh + tid * kp.M * 3;
                     float q0 = 0.f, q1 = 0.f, q2 = 0.f;
                     for (int k = 0; k < n_sh; ++k) {
-                        const float s = sh[k * 3] * drgb_v[0] + sh[k * 3 + 1] * drgb_v[1] + sh[k * 3 + 2] * drgb_v[2];
+                        const float s = sh[k * sk] * drgb_v[0] + sh[k * sk + sc_] * drgb_v[1] + sh[k * sk + 2 * sc_] * drgb_v[2];
                         q0 += bx[k] * s; q1 += by[k] * s; q2 += bz[k] * s;
                     }
                     const float dot = x * q0 + y * q1 + z * q2;
-                    dm0 += (q0 - x * dot) * inv;
-                    dm1 += (q1 - y * dot) * inv;
-                    dm2 += (q2 - z * dot) * inv;
+                    dmv0 += (q0 - x * dot) * inv;
+                    dmv1 += (q1 - y * dot) * inv;
+                    dmv2 += (q2 - z * dot) * inv;
                 }
             }
+            dm0 += sc * dmv0;
+            dm1 += sc * dmv1;
+            dm2 += sc * dmv2;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) dc[k] += sc2 * dcv[k];
         }
 
         if (want_sh) {
@@ -328,7 +344,8 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess_bwd(
             if (shared_cam) {
                 if (any_visible) {
                     const S360View& vw = views[first_visible];
-                    const float ddx = mx - vw.campos[0], ddy = my - vw.campos[1], ddz = mz - vw.campos[2];
+                    const float sc = vw.scale;
+                    const float ddx = mx0 * sc - vw.campos[0], ddy = my0 * sc - vw.campos[1], ddz = mz0 * sc - vw.campos[2];
                     const float inv = 1.f / sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
                     const float x = ddx * inv, y = ddy * inv, z = ddz * inv;
                     float Y[25], bx[25], by[25], bz[25];
@@ -336,17 +353,17 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess_bwd(
                     sh_basis_grad(kp.deg, x, y, z, bx, by, bz);
                     float q0 = 0.f, q1 = 0.f, q2 = 0.f;
                     for (int k = 0; k < n_sh; ++k) {
-                        const float s = sh[k * 3] * drgb_sum[0] + sh[k * 3 + 1] * drgb_sum[1] + sh[k * 3 + 2] * drgb_sum[2];
+                        const float s = sh[k * sk] * drgb_sum[0] + sh[k * sk + sc_] * drgb_sum[1] + sh[k * sk + 2 * sc_] * drgb_sum[2];
                         q0 += bx[k] * s; q1 += by[k] * s; q2 += bz[k] * s;
-                        sh[k * 3] = Y[k] * drgb_sum[0];
-                        sh[k * 3 + 1] = Y[k] * drgb_sum[1];
-                        sh[k * 3 + 2] = Y[k] * drgb_sum[2];
+                        sh[k * sk] = Y[k] * drgb_sum[0];
+                        sh[k * sk + sc_] = Y[k] * drgb_sum[1];
+                        sh[k * sk + 2 * sc_] = Y[k] * drgb_sum[2];
                     }
-                    for (int k = n_sh * 3; k < kp.M * 3; ++k) sh[k] = 0.f;
+                    for (int k = n_sh; k < kp.M; ++k) sh[k * sk] = sh[k * sk + sc_] = sh[k * sk + 2 * sc_] = 0.f;
                     const float dot = x * q0 + y * q1 + z * q2;
-                    dm0 += (q0 - x * dot) * inv;
-                    dm1 += (q1 - y * dot) * inv;
-                    dm2 += (q2 - z * dot) * inv;
+                    dm0 += sc * ((q0 - x * dot) * inv);
+                    dm1 += sc * ((q1 - y * dot) * inv);
+                    dm2 += sc * ((q2 - z * dot) * inv);
                 } else {
                     for (int k = 0; k < kp.M * 3; ++k) sh[k] = 0.f;
                 }
@@ -356,15 +373,16 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess_bwd(
                     const size_t p = (size_t)v * P + g;
                     if (tiles_touched[p] == 0) continue;
                     const S360View& vw = views[v];
-                    const float ddx = mx - vw.campos[0], ddy = my - vw.campos[1], ddz = mz - vw.campos[2];
+                    const float sc = vw.scale;
+                    const float ddx = mx0 * sc - vw.campos[0], ddy = my0 * sc - vw.campos[1], ddz = mz0 * sc - vw.campos[2];
                     const float inv = 1.f / sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
                     float Y[25];
                     sh_basis(kp.deg, ddx * inv, ddy * inv, ddz * inv, Y);
                     const float* dr = lds_drgb + (tid * kp.V + v) * 3;
                     for (int k = 0; k < n_sh; ++k) {
-                        sh[k * 3] += Y[k] * dr[0];
-                        sh[k * 3 + 1] += Y[k] * dr[1];
-                        sh[k * 3 + 2] += Y[k] * dr[2];
+                        sh[k * sk] += Y[k] * dr[0];
+                        sh[k * sk + sc_] += Y[k] * dr[1];
+                        sh[k * sk + 2 * sc_] += Y[k] * dr[2];
                     }
                 }
             }
@@ -372,8 +390,16 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess_bwd(
         d_means3D[3 * g] = dm0;
         d_means3D[3 * g + 1] = dm1;
         d_means3D[3 * g + 2] = dm2;
+        if (cov9) {
+            // adjoint of the upper-triangle gather: lower triangle receives no gradient
+            float* o = d_cov6 + 9 * (size_t)g;
+            o[0] = dc[0]; o[1] = dc[1]; o[2] = dc[2];
+            o[3] = 0.f;   o[4] = dc[3]; o[5] = dc[4];
+            o[6] = 0.f;   o[7] = 0.f;   o[8] = dc[5];
+        } else {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) d_cov6[6 * (size_t)g + k] = dc[k];
+            for (int k = 0; k < 6; ++k) d_cov6[6 * (size_t)g + k] = dc[k];
+        }
         d_opac[g] = dop;
         if (!USE_SH && d_colors) {
             d_colors[3 * g] = dcol_sum[0];

@@ -121,6 +121,18 @@ __device__ __forceinline__ void xform43(const float* m, float px, float py, floa
     oz = m[2] * px + m[6] * py + m[10] * pz + m[14];
 }
 
+// Upper triangle (00,01,02,11,12,22) of Gaussian g's covariance from either layout.
+__device__ __forceinline__ void load_cov6(const float* __restrict__ cov, int g, bool cov9, float* c6) {
+    if (cov9) {
+        const float* c = cov + 9 * (size_t)g;
+        c6[0] = c[0]; c6[1] = c[1]; c6[2] = c[2]; c6[3] = c[4]; c6[4] = c[5]; c6[5] = c[8];
+    } else {
+        const float* c = cov + 6 * (size_t)g;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) c6[k] = c[k];
+    }
+}
+
 // Per-(Gaussian, view) geometry shared by preprocess forward and backward.
 struct Geo {
     float tx, ty, tz, txc, tyc, fx, fy;

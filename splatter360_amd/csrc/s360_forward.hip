@@ -51,11 +51,11 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess(
     }
     __syncthreads();
     if (g < P) {
-    const float mx = means[3 * g], my = means[3 * g + 1], mz = means[3 * g + 2];
-    float c6[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) c6[k] = cov6[6 * (size_t)g + k];
+    const float mx0 = means[3 * g], my0 = means[3 * g + 1], mz0 = means[3 * g + 2];
+    float c60[6];
+    load_cov6(cov6, g, (kp.flags & S360_FLAG_COV9) != 0, c60);
     const float op = opac[g];
+    const bool ch_major = (kp.flags & S360_FLAG_SH_CHANNEL_MAJOR) != 0;
 
     const bool shared_cam = (kp.flags & S360_FLAG_SHARED_CAMPOS) != 0;
     float rgb[3] = {0.f, 0.f, 0.f};
@@ -73,6 +73,12 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess(
         const size_t p = (size_t)v * P + g;
         int radius = 0;
         uint32_t touched = 0;
+        // scale-invariant rescale fused here (cuda_splatting.py:68-69): same f32 products as torch
+        const float sc = vw.scale, sc2 = sc * sc;
+        const float mx = mx0 * sc, my = my0 * sc, mz = mz0 * sc;
+        float c6[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) c6[k] = c60[k] * sc2;
         float pvx, pvy, pvz;
         xform43(vw.viewmatrix, mx, my, mz, pvx, pvy, pvz);
         if (pvz > 0.2f) {
@@ -108,10 +114,18 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess(
                         const float* sh = lds_sh + tid * kp.M * 3;
                         float a0 = 0.f, a1 = 0.f, a2 = 0.f;
                         // sequential (unfused) accumulation: same rounding as the CPU oracle
-                        for (int k = 0; k < n; ++k) {
-                            a0 += Y[k] * sh[k * 3 + 0];
-                            a1 += Y[k] * sh[k * 3 + 1];
-                            a2 += Y[k] * sh[k * 3 + 2];
+                        if (ch_major) {
+                            for (int k = 0; k < n; ++k) {
+                                a0 += Y[k] * sh[k];
+                                a1 += Y[k] * sh[kp.M + k];
+                                a2 += Y[k] * sh[2 * kp.M + k];
+                            }
+                        } else {
+                            for (int k = 0; k < n; ++k) {
+                                a0 += Y[k] * sh[k * 3 + 0];
+                                a1 += Y[k] * sh[k * 3 + 1];
+                                a2 += Y[k] * sh[k * 3 + 2];
+                            }
                         }
                         a0 += 0.5f;
                         a1 += 0.5f;

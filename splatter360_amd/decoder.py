@@ -93,15 +93,16 @@ def render_depth_cuda(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far:
 
 # ----------------------------------------------------------------------------- fused path
 def cube_views(pano_c2w: Tensor, near: Tensor, far: Tensor, background: Tensor):
-    """[4,4] panorama pose (+ scalar near/far tensors, [3] background) -> (views[6,42], scale):
-    the six face cameras of cameras.cube_face_extrinsics with the reference's scale-invariant
-    rescale, packed for one V=6 rasteriser call.  Pure device math, no sync."""
+    """[4,4] panorama pose (+ scalar near/far tensors, [3] background) -> views[6,44]: the six
+    face cameras of cameras.cube_face_extrinsics with the reference's scale-invariant rescale
+    (camera side here, cloud side inside the kernels), packed for one V=6 rasteriser call.
+    Pure device math, no sync."""
     ext = cameras.cube_face_extrinsics(pano_c2w[None])[0]
     k = cameras.cube_face_intrinsics(1, device=pano_c2w.device)[0]
     vs = cameras.view_setup(ext, k, near.reshape(1).expand(6), far.reshape(1).expand(6), True)
     views = rasterizer.pack_views(vs["view_matrix"], vs["full_projection"], vs["campos"], vs["tan_fov_x"],
-                                  vs["tan_fov_y"], background)
-    return views, vs["scale"][0]
+                                  vs["tan_fov_y"], background, scale=vs["scale"])
+    return views
 
 
 def render_cube_faces(pano_c2w: Tensor, near: Tensor, far: Tensor, face_w: int, background: Tensor,
@@ -111,13 +112,13 @@ def render_cube_faces(pano_c2w: Tensor, near: Tensor, far: Tensor, face_w: int, 
     reference's Gaussians layout, src/model/types.py:7-12), opacities[G] -> faces[6,3,fw,fw] in the
     reference's rendered order (top, front, left, back, right, bottom).  Bit-for-bit the result of
     six render_cuda calls (same boundary tensors), in one fused launch sequence."""
-    views, scale = cube_views(pano_c2w, near, far, background)
+    views = cube_views(pano_c2w, near, far, background)
     n = gaussian_sh_coefficients.shape[-1]
-    shs = gaussian_sh_coefficients.transpose(1, 2).contiguous()
+    # zero-copy: the kernels read the reference's own layouts and apply the 1/near rescale in-register
     faces, _ = rasterizer.rasterize_views(
-        gaussian_means * scale, _triu_cov6(gaussian_covariances * scale ** 2), gaussian_opacities[..., None], shs, None,
-        views=views, image_height=face_w, image_width=face_w, sh_degree=isqrt(n) - 1, shared_campos=True,
-        want_radii=False, max_instances=max_instances, check=check)
+        gaussian_means, gaussian_covariances, gaussian_opacities, gaussian_sh_coefficients, None, views=views,
+        image_height=face_w, image_width=face_w, sh_degree=isqrt(n) - 1, shared_campos=True, want_radii=False,
+        max_instances=max_instances, check=check, cov9=True, sh_channel_major=True)
     return faces
 
 

@@ -15,7 +15,7 @@ from torch import Tensor, nn
 
 from . import _lib
 
-VIEW_FLOATS = 42
+VIEW_FLOATS = 44
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -34,9 +34,10 @@ class GaussianRasterizationSettings(NamedTuple):
     debug: bool
 
 
-def pack_views(viewmatrix: Tensor, projmatrix: Tensor, campos: Tensor, tanfovx, tanfovy, bg: Tensor) -> Tensor:
-    """-> float32 [V,42] device tensor in S360View layout.  Tensors may carry a leading view dim;
-    tanfov may be python floats or [V] tensors.  No host synchronisation."""
+def pack_views(viewmatrix: Tensor, projmatrix: Tensor, campos: Tensor, tanfovx, tanfovy, bg: Tensor,
+               scale=1.0) -> Tensor:
+    """-> float32 [V,44] device tensor in S360View layout.  Tensors may carry a leading view dim;
+    tanfov / scale may be python floats or [V] tensors.  No host synchronisation."""
     vm = viewmatrix.reshape(-1, 16).float()
     v = vm.shape[0]
     dev = vm.device
@@ -49,7 +50,8 @@ def pack_views(viewmatrix: Tensor, projmatrix: Tensor, campos: Tensor, tanfovx, 
             return t.reshape(-1, 1).float().to(dev).expand(v, 1)
         return torch.full((v, 1), float(t), dtype=torch.float32, device=dev)
 
-    return torch.cat([vm, pm, cp.expand(v, 3), col(tanfovx), col(tanfovy), b], dim=1).contiguous()
+    pad = torch.zeros((v, 3), dtype=torch.float32, device=dev)
+    return torch.cat([vm, pm, cp.expand(v, 3), col(tanfovx), col(tanfovy), b, col(scale), pad], dim=1).contiguous()
 
 
 def default_capacity(p: int, v: int) -> int:
@@ -130,7 +132,7 @@ class _RasterizeViews(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, cov6, views, cfg):
-        h, w, sh_degree, shared_campos, max_instances, check, want_radii = cfg
+        h, w, sh_degree, shared_campos, max_instances, check, want_radii, cov9, sh_channel_major = cfg
         with torch.cuda.device(means3D.device):
             m3 = _f32c(means3D, "means3D")
             c6 = _f32c(cov6, "cov3D_precomp")
@@ -144,8 +146,9 @@ class _RasterizeViews(torch.autograd.Function):
             prm = _lib.S360Params()
             prm.P, prm.V, prm.H, prm.W = p, v, int(h), int(w)
             prm.sh_degree = int(sh_degree)
-            prm.M = 0 if sh is None else int(sh.shape[1])
-            prm.flags = _lib.FLAG_SHARED_CAMPOS if (shared_campos or v == 1) else 0
+            prm.M = 0 if sh is None else int(sh.shape[2] if sh_channel_major else sh.shape[1])
+            prm.flags = (_lib.FLAG_SHARED_CAMPOS if (shared_campos or v == 1) else 0) | (
+                _lib.FLAG_COV9 if cov9 else 0) | (_lib.FLAG_SH_CHANNEL_MAJOR if sh_channel_major else 0)
             prm.max_instances = int(max_instances) if max_instances else default_capacity(p, v)
             images, radii, state = _forward_call(prm, vw, m3, c6, op, sh, col, want_radii)
             if check == "sync" and state.overflowed():
@@ -170,7 +173,7 @@ class _RasterizeViews(torch.autograd.Function):
             g = grad_images.detach().float().contiguous()
             p, v = prm.P, prm.V
             d_m3 = torch.empty((p, 3), dtype=torch.float32, device=dev)
-            d_c6 = torch.empty((p, 6), dtype=torch.float32, device=dev)
+            d_c6 = torch.empty_like(c6)
             d_op = torch.empty((p,), dtype=torch.float32, device=dev)
             need = ctx.needs_input_grad
             d_m2 = torch.empty((v, p, 3), dtype=torch.float32, device=dev) if (ctx.has_means2D and need[1]) else None
@@ -194,8 +197,10 @@ _RasterizeViews.last_state = None
 def rasterize_views(means3D: Tensor, cov6: Tensor, opacities: Tensor, shs: Optional[Tensor] = None,
                     colors_precomp: Optional[Tensor] = None, *, views: Tensor, image_height: int, image_width: int,
                     sh_degree: int = 0, shared_campos: bool = False, max_instances: Optional[int] = None,
-                    check: str = "sync", want_radii: bool = True, means2D: Optional[Tensor] = None):
-    """Render V views ([V,42] packed, see pack_views) of one cloud.  Returns (images[V,3,H,W],
+                    check: str = "sync", want_radii: bool = True, means2D: Optional[Tensor] = None,
+                    cov9: bool = False, sh_channel_major: bool = False):
+    """Render V views ([V,44] packed, see pack_views) of one cloud.  cov9: cov6 is [P,3,3];
+    sh_channel_major: shs is [P,3,M] (the reference's Gaussians layouts, consumed without copies).  Returns (images[V,3,H,W],
     radii[V,P] int32).  opacities may be [P] or [P,1]; its gradient has the same shape.
     check="sync": read the overflow flag after the forward (one host sync, like upstream's own
     scan read-back) and re-run with the exact size if the binning capacity was exceeded;
@@ -203,7 +208,8 @@ def rasterize_views(means3D: Tensor, cov6: Tensor, opacities: Tensor, shs: Optio
     if (shs is None) == (colors_precomp is None):
         raise Exception("Please provide excatly one of either SHs or precomputed colors!")
     op2 = opacities.reshape(-1, 1)
-    cfg = (image_height, image_width, sh_degree, shared_campos, max_instances, check, want_radii)
+    cfg = (image_height, image_width, sh_degree, shared_campos, max_instances, check, want_radii, cov9,
+           sh_channel_major)
     return _RasterizeViews.apply(means3D, means2D, shs, colors_precomp, op2, cov6, views, cfg)
 
 
