@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X panoramic Gaussian-splat render path.
+
+Metric (BASELINE.json): Msplats/s forward+backward at 1 048 576 Gaussians, 1024x512 ERP
+(= six 256x256 cube faces + cube->ERP stitch), L2 pixel loss on the faces (the reference's loss,
+src/loss/loss_mse.py:30-31), 1/2/4/8 GPUs with one target view per GPU (weak scaling) and an RCCL
+all-reduce of the per-Gaussian gradients.
+
+A "step" is one pass of the hot path per rank: fused six-face forward, stitch, loss, backward
+(+ gradient all-reduce when N > 1).  Inputs are resident in HBM before the timed region.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `value` comes from the un-instrumented timed region; the per-kernel
+durations behind `roofline` come from a second pass of the same K steps with HIP events recorded
+on the launch stream (s360_profile_*), so the numbers can be compared with
+profiles/*kernel_stats* (rocprofv3 --kernel-trace --stats of this same command).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import torch  # noqa: E402
+
+from splatter360_amd import _lib, decoder, distributed, rasterizer, stitch, synthetic  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 measured-achievable
+# SURVEY.md §8(d) compulsory bytes per splat at G = 1 048 576, ERP 1024x512
+BYTES_FWD, BYTES_BWD = 350.5, 684.5
+FWD_KERNELS = ("preprocess", "scan", "tile_scan", "emit", "sort_tiles", "render", "cube2erp")
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--mode", choices=("fwdbwd", "fwd"), default="fwdbwd")
+    ap.add_argument("--pano-h", type=int, default=512, help="context/target ERP height (width = 2h)")
+    ap.add_argument("--face", type=int, default=0, help="cube face size (default pano_h/2)")
+    ap.add_argument("--cpu-baseline", type=int, default=1)
+    return ap.parse_args()
+
+
+def cpu_baseline(cloud, face_w, near, far, mode):
+    """The CPU oracle (C restatement, OpenMP) on ONE ERP view of the same cloud: six faces forward
+    (+ backward), timed on this host's cores."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import numpy as np
+    from helpers import boundary_tensors, face_settings  # settings exactly as the reference glue builds them
+    from oracle import oracle
+    oracle.set_parallel_backward(True)
+    cores = os.cpu_count() or 1
+    t0 = time.time()
+    for face in range(6):
+        S = face_settings(face, face_w, face_w, near=near, far=far)
+        means, cov6, shs, opac = boundary_tensors(cloud, S["scale"])
+        orc = oracle.rasterize(S, means3D=means, cov3D_precomp=cov6, opacities=opac, shs=shs)
+        f = orc.forward()
+        if mode == "fwdbwd":
+            orc.backward((2.0 / f["image"].size) * (f["image"] - 0.5))
+        del orc
+    dt = time.time() - t0
+    oracle.set_parallel_backward(False)
+    g = cloud["means"].shape[0]
+    return dict(value=g / dt / 1e6, unit="Msplats/s", cores=cores, kind="port",
+                sample=f"1 ERP view (6 faces {face_w}x{face_w}) of the same {g}-Gaussian cloud, {mode}, "
+                       f"oracle/s360_oracle.c with OpenMP, {dt:.1f} s incl. boundary-tensor prep")
+
+
+def main():
+    a = parse()
+    rank, local_rank, world = distributed.init()
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    _lib.lib()
+
+    pano_h, pano_w = a.pano_h, 2 * a.pano_h
+    face_w = a.face or pano_h // 2
+    cloud = synthetic.encoder_like_cloud(pano_h, pano_w, n_context=2, d_sh=25, seed=0)
+    G = cloud["means"].shape[0]
+    params = [torch.tensor(cloud[k], device=dev, requires_grad=(a.mode == "fwdbwd"))
+              for k in ("means", "covariances", "harmonics", "opacities")]
+    # one target panorama per rank (identity rotation, small per-rank offsets)
+    pose = torch.tensor(synthetic.target_pano_pose((0.05 * rank, 0.02 * rank, -0.03 * rank)), device=dev)
+    near, far = torch.tensor(0.1, device=dev), torch.tensor(10.0, device=dev)
+    bg = torch.zeros(3, device=dev)
+    gt = torch.full((6, 3, face_w, face_w), 0.5, device=dev)
+    c2e = stitch.Cube2Equirec(face_w, pano_h, pano_w).to(dev)
+    out = {}
+
+    def step():
+        for p in params:
+            p.grad = None
+        faces = decoder.render_cube_faces(pose, near, far, face_w, bg, *params, check="lazy")
+        out["erp"] = c2e.stitch_rendered(faces.detach())
+        if a.mode == "fwdbwd":
+            loss = ((faces - gt) ** 2).mean()
+            loss.backward()
+            distributed.allreduce_gradients([p.grad for p in params])
+        out["faces"] = faces
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        distributed.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    sync()
+    dt = distributed.max_over_ranks(time.perf_counter() - t0, dev)
+    ms_per_step = dt / a.steps * 1e3
+
+    st = rasterizer.last_state()
+    if st.overflowed():
+        raise SystemExit("binning capacity overflowed during the timed region: result invalid")
+    L = st.num_rendered()
+    tt = st.tensors()
+    visible_pairs = int((tt["tiles_touched"] > 0).sum().item())
+    assert torch.isfinite(out["faces"]).all() and torch.isfinite(out["erp"]).all()
+
+    # ---- second pass: same steps with HIP events around every kernel group -----------------
+    _lib.profile_enable(True)
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    prof = _lib.profile_collect()
+    _lib.profile_enable(False)
+    kernels = {k: dict(avg_us=ms / n * 1e3, launches=n) for k, (ms, n) in prof.items() if n}
+    dom = max(kernels, key=lambda k: kernels[k]["avg_us"] * kernels[k]["launches"])
+    # kernel-interface (compulsory) bytes per launch, for the per-kernel table
+    hw = 6 * face_w * face_w
+    iface = dict(
+        preprocess=G * 340 + 6 * G * 4 + visible_pairs * 49,
+        render=L * (4 + 48) + hw * (12 + 8),
+        sort_tiles=L * (8 + 8 + 4),
+        emit=6 * G * 4 + visible_pairs * 32 + L * 8,
+        render_bwd=L * (4 + 48 + 4) + hw * (12 + 8) + L * 48,
+        preprocess_bwd=G * 340 + L * 48 + 6 * G * 8 + G * (340 + 12),
+        cube2erp=hw * 12 + pano_h * pano_w * (12 + 12),
+    )
+    for k, v in kernels.items():
+        if k in iface:
+            v["interface_bytes"] = iface[k]
+            v["interface_GBps"] = iface[k] / (v["avg_us"] * 1e-6) / 1e9
+    per_splat = BYTES_FWD if dom in FWD_KERNELS else BYTES_BWD
+    dom_s = kernels[dom]["avg_us"] * 1e-6
+    achieved = per_splat * G / dom_s / 1e9
+    traffic = None
+    pmc = ROOT / "profiles" / "pmc_latest.json"
+    if pmc.exists():
+        try:
+            traffic = json.loads(pmc.read_text()).get(dom, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    bytes_step = (BYTES_FWD + (BYTES_BWD if a.mode == "fwdbwd" else 0.0)) * G
+
+    value = G * world / (dt / a.steps) / 1e6
+    res = {
+        "metric": "Msplats/s fwd+bwd @1M Gaussians, 1024x512 ERP" if a.mode == "fwdbwd" else "Msplats/s fwd @1M Gaussians, 1024x512 ERP",
+        "value": value, "unit": "Msplats/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[2]: {G} encoder-like synthetic Gaussians (seed 0, deg-4 SH), "
+                               f"{pano_w}x{pano_h} ERP = 6 faces {face_w}x{face_w} + stitch, {a.mode}, L2 loss on faces",
+                   "gaussians": G, "erp": [pano_w, pano_h], "face": face_w, "views_per_gpu": 1,
+                   "parallelism": f"view-sharded x{world}" + (", RCCL all-reduce of Gaussian grads" if world > 1 and a.mode == "fwdbwd" else ""),
+                   "num_rendered": L, "visible_pairs": visible_pairs},
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "note": f"{per_splat} B/splat (SURVEY §8d, {'fwd' if dom in FWD_KERNELS else 'bwd'} phase) x {G} splats / "
+                             f"avg launch {kernels[dom]['avg_us']:.1f} us of the dominant kernel; that kernel is VALU/LDS-bound "
+                             "(alpha-composite), see DESIGN.md"},
+        "path_roofline": {"bytes_per_step": bytes_step, "achieved_GBps": bytes_step / (dt / a.steps) / 1e9 ,
+                          "frac_of_8TBps": bytes_step / (dt / a.steps) / 1e9 / HBM_PEAK_GBPS},
+        "kernels": kernels,
+    }
+    if rank == 0 and world == 1 and a.cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(cloud, face_w, 0.1, 10.0, a.mode)
+    elif rank == 0:
+        res["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -150,16 +150,31 @@ int s360_backward(const S360Params* prm, const S360View* views, const float* mea
  *   (src/model/model_wrapper_erp.py:135-145) to faces given in rendered order (U B L F R D)
  *   without materialising the permuted copy.  face_map_host is read on the HOST.
  *   grid[eh,ew,3] = Cube2Equirec.sample_grid (u, v, face-z);  erp[C,eh,ew].
+ *   strides_host (HOST, 3 x int64, element units, may be NULL = dense [6,C,fw,fw]): strides between
+ *   faces, channels and rows of `faces`; {fw, fw*6*fw, 6*fw} reads the reference's own
+ *   [C,fw,6*fw] "faces side by side" input of Cube2Equirec.forward (layers.py:108-113) in place.
  */
 int s360_cube2erp_forward(const float* faces, const float* grid, float* erp, int32_t channels,
                           int32_t face_w, int32_t equ_h, int32_t equ_w,
-                          const int32_t* face_map_host, void* stream);
+                          const int32_t* face_map_host, const int64_t* strides_host, void* stream);
 
 /* Adjoint of the stitch: d_faces[6,C,fw,fw] (same face order / face_map as forward) is
  * ZEROED then accumulated with float atomics (non-deterministic summation order). */
 int s360_cube2erp_backward(const float* d_erp, const float* grid, float* d_faces,
                            int32_t channels, int32_t face_w, int32_t equ_h, int32_t equ_w,
-                           const int32_t* face_map_host, void* stream);
+                           const int32_t* face_map_host, const int64_t* strides_host, void* stream);
+
+/*
+ * Optional measurement aid (no reference counterpart; the reference's Benchmarker is an
+ * un-synchronised wall clock, src/misc/benchmarker.py:15-33).  While enabled, every kernel group
+ * is bracketed by HIP events recorded on the launch stream; s360_profile_collect() synchronises
+ * on those events and returns, per slot, the summed milliseconds and the number of launches since
+ * the previous collect.  Arrays must hold s360_profile_slots() entries.
+ */
+int s360_profile_slots(void);
+const char* s360_profile_slot_name(int slot);
+int s360_profile_enable(int on);
+int s360_profile_collect(float* total_ms, int32_t* calls);
 
 #ifdef __cplusplus
 }

@@ -47,6 +47,7 @@ def _lib(dtype):
     lib.orc_num_rendered.restype = C.c_uint64
     lib.orc_num_rendered.argtypes = [C.c_void_p]
     lib.orc_backward.argtypes = [C.c_void_p] * 8
+    lib.orc_set_parallel_backward.argtypes = [C.c_int]
     for fn in ("radii", "tiles_touched", "offsets", "rect", "xy", "depth", "conic_opacity", "rgb",
                "clamped", "keys", "values", "ranges", "image", "final_T", "n_contrib",
                "grad_xy_pix", "grad_conic", "grad_opacity_raster", "grad_rgb"):
@@ -169,6 +170,12 @@ class OracleRasterizer:
             "raster_opacity": _view(lib.orc_grad_opacity_raster(h), (P,), dt),
             "raster_rgb": _view(lib.orc_grad_rgb(h), (P, 3), dt),
         }
+
+
+def set_parallel_backward(on: bool, dtype=np.float32) -> None:
+    """Timing aid for the CPU baseline: OpenMP + atomics in the oracle's backward (non-deterministic
+    summation order).  Parity tests keep the default serial, deterministic mode."""
+    _lib(dtype).orc_set_parallel_backward(int(bool(on)))
 
 
 def rasterize(settings: dict, *, means3D, cov3D_precomp, opacities, shs=None, colors_precomp=None,

@@ -486,6 +486,11 @@ EXPORT const real* orc_grad_rgb(Orc* o) { return o->g_rgb; }
  *   d_cov6[P,6], d_sh[P,M,3] (or NULL), d_colors[P,3] (or NULL), d_opacity[P].
  * Per-pixel contributions are summed in pixel-index order (deterministic).
  */
+/* 0 (default): serial, pixel-index summation order (deterministic, used by the parity tests).
+ * 1: OpenMP over pixels with atomic accumulation (used only to TIME the CPU baseline). */
+static int g_parallel_backward = 0;
+EXPORT void orc_set_parallel_backward(int on) { g_parallel_backward = on; }
+
 EXPORT void orc_backward(Orc* o, const real* dL_dimage, real* d_means3D, real* d_means2D,
                          real* d_cov6, real* d_sh, real* d_colors, real* d_opacity) {
     const OrcParams* p = &o->prm;
@@ -496,6 +501,9 @@ EXPORT void orc_backward(Orc* o, const real* dL_dimage, real* d_means3D, real* d
     memset(o->g_op, 0, sizeof(real) * (size_t)P);
     memset(o->g_rgb, 0, sizeof(real) * 3 * (size_t)P);
     /* --- render backward: back-to-front replay per pixel --- */
+    const int par = g_parallel_backward;
+#define ACC(dst, val) do { real v_ = (val); if (par) { _Pragma("omp atomic") dst += v_; } else dst += v_; } while (0)
+#pragma omp parallel for schedule(dynamic, 64) if (par)
     for (int pix = 0; pix < H * W; ++pix) {
         int py = pix / W, px = pix % W;
         int tile = (py / TILE) * gx + (px / TILE);
@@ -525,7 +533,7 @@ EXPORT void orc_backward(Orc* o, const real* dL_dimage, real* d_means3D, real* d
                 accum[c] = last_alpha * last_color[c] + (R(1) - last_alpha) * accum[c];
                 last_color[c] = col;
                 dL_dalpha += (col - accum[c]) * dpix[c];
-                o->g_rgb[3 * id + c] += dchannel_dcolor * dpix[c];
+                ACC(o->g_rgb[3 * id + c], dchannel_dcolor * dpix[c]);
             }
             dL_dalpha *= T;
             last_alpha = alpha;
@@ -534,15 +542,16 @@ EXPORT void orc_backward(Orc* o, const real* dL_dimage, real* d_means3D, real* d
             real gdx = G * dx, gdy = G * dy;
             real dG_ddelx = -gdx * co[0] - gdy * co[1];
             real dG_ddely = -gdy * co[2] - gdx * co[1];
-            o->g_xy[2 * id] += dL_dG * dG_ddelx;
-            o->g_xy[2 * id + 1] += dL_dG * dG_ddely;
-            o->g_conic[3 * id + 0] += -R(0.5) * gdx * dx * dL_dG;
-            o->g_conic[3 * id + 1] += -gdx * dy * dL_dG; /* true d/dB (no half factor) */
-            o->g_conic[3 * id + 2] += -R(0.5) * gdy * dy * dL_dG;
-            o->g_op[id] += G * dL_dalpha;
+            ACC(o->g_xy[2 * id], dL_dG * dG_ddelx);
+            ACC(o->g_xy[2 * id + 1], dL_dG * dG_ddely);
+            ACC(o->g_conic[3 * id + 0], -R(0.5) * gdx * dx * dL_dG);
+            ACC(o->g_conic[3 * id + 1], -gdx * dy * dL_dG); /* true d/dB (no half factor) */
+            ACC(o->g_conic[3 * id + 2], -R(0.5) * gdy * dy * dL_dG);
+            ACC(o->g_op[id], G * dL_dalpha);
         }
     }
     /* --- per-Gaussian backward --- */
+#pragma omp parallel for schedule(static, 1024) if (par)
     for (int i = 0; i < P; ++i) {
         real* dm = d_means3D + 3 * i;
         dm[0] = dm[1] = dm[2] = R(0);

@@ -39,7 +39,8 @@ class S360Layout(C.Structure):
 
 
 EXPORTS = ("s360_abi_version", "s360_error_string", "s360_layout", "s360_forward", "s360_backward",
-           "s360_cube2erp_forward", "s360_cube2erp_backward")
+           "s360_cube2erp_forward", "s360_cube2erp_backward", "s360_profile_slots", "s360_profile_slot_name",
+           "s360_profile_enable", "s360_profile_collect")
 
 
 def _hipcc() -> str:
@@ -96,9 +97,13 @@ def lib() -> C.CDLL:
     l.s360_backward.restype = C.c_int
     l.s360_backward.argtypes = [C.POINTER(S360Params)] + [vp] * 7 + [sz] + [vp] * 8 + [sz, vp]
     l.s360_cube2erp_forward.restype = C.c_int
-    l.s360_cube2erp_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, C.POINTER(i32), vp]
+    l.s360_cube2erp_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(C.c_int64), vp]
     l.s360_cube2erp_backward.restype = C.c_int
-    l.s360_cube2erp_backward.argtypes = [vp, vp, vp, i32, i32, i32, i32, C.POINTER(i32), vp]
+    l.s360_cube2erp_backward.argtypes = [vp, vp, vp, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(C.c_int64), vp]
+    l.s360_profile_slot_name.restype = C.c_char_p
+    l.s360_profile_slot_name.argtypes = [C.c_int]
+    l.s360_profile_enable.argtypes = [C.c_int]
+    l.s360_profile_collect.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int32)]
     if l.s360_abi_version() != ABI_VERSION:
         raise RuntimeError("libs360.so ABI version mismatch")
     _lib = l
@@ -114,3 +119,16 @@ def layout(prm: S360Params) -> S360Layout:
     out = S360Layout()
     check(lib().s360_layout(C.byref(prm), C.byref(out)), "s360_layout")
     return out
+
+
+def profile_enable(on: bool) -> None:
+    check(lib().s360_profile_enable(int(bool(on))), "s360_profile_enable")
+
+
+def profile_collect() -> dict:
+    """{slot_name: (total_ms, launches)} since the previous collect (host-synchronising)."""
+    n = lib().s360_profile_slots()
+    ms = (C.c_float * n)()
+    calls = (C.c_int32 * n)()
+    check(lib().s360_profile_collect(ms, calls), "s360_profile_collect")
+    return {lib().s360_profile_slot_name(i).decode(): (float(ms[i]), int(calls[i])) for i in range(n)}

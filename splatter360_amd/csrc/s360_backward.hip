@@ -12,6 +12,7 @@
 //                      writes each 340-byte gradient exactly once (SH slab staged through LDS).
 // No float atomics anywhere: gradients are bit-reproducible run to run.
 #include "s360_device.h"
+#include "s360_prof.h"
 
 namespace s360 {
 
@@ -468,10 +469,17 @@ extern "C" int s360_backward(const S360Params* prm, const S360View* views, const
     const uint32_t* tile_max_contrib = (const uint32_t*)(ws + L.tile_max_contrib);
     float4* inst_grad = (float4*)bwd_workspace;
 
-    hipLaunchKernelGGL(k_zero_inst, dim3(2048), dim3(S360_BLOCK), 0, st, inst_grad, header, kp.cap);
+    {
+        ProfScope ps(PS_ZERO_INST, st);
+        hipLaunchKernelGGL(k_zero_inst, dim3(2048), dim3(S360_BLOCK), 0, st, inst_grad, header, kp.cap);
+    }
+    {
+    ProfScope ps(PS_RENDER_BWD, st);
     hipLaunchKernelGGL(k_render_bwd, dim3(nt), dim3(S360_BLOCK), 0, st, kp, views, tile_start, list, offsets, recA, recB,
                        recC, final_T, n_contrib, tile_max_contrib, dL_dimages, inst_grad);
+    }
     S360_CHECK_LAUNCH();
+    ProfScope ps(PS_PREPROCESS_BWD, st);
     const int nblk = (kp.P + S360_BLOCK - 1) / S360_BLOCK;
     if (shs) {
         size_t lds = d_shs ? (size_t)S360_BLOCK * kp.M * 3 * 4 : 0;

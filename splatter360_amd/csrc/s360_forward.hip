@@ -12,6 +12,7 @@
 //                   equals a stable radix sort by (tile, depth) with ascending-index emission)
 //   k_render        1 workgroup (4 waves) per 16x16 tile, LDS-staged batches of 256 splats
 #include "s360_device.h"
+#include "s360_prof.h"
 
 namespace s360 {
 
@@ -603,6 +604,8 @@ extern "C" int s360_forward(const S360Params* prm, const S360View* views, const 
 
     if (hipMemsetAsync(tile_count, 0, (size_t)nt * 4, st) != hipSuccess) return S360_E_LAUNCH;
     if (kp.P > 0) {
+        {
+        ProfScope ps(PS_PREPROCESS, st);
         const int nblk = (kp.P + S360_BLOCK - 1) / S360_BLOCK;
         const size_t hist_bytes = (size_t)nt * 4;
         const int lds_hist = hist_bytes <= 48 * 1024 ? 1 : 0;
@@ -619,24 +622,33 @@ extern "C" int s360_forward(const S360Params* prm, const S360View* views, const 
                                means3D, cov6, opacities, shs, colors_precomp, radii, tiles_touched, recA, recB, recC, clamped,
                                tile_count, lds_hist);
         }
+        }
         S360_CHECK_LAUNCH();
+        ProfScope ps(PS_SCAN, st);
         const int sblk = (int)((np + SCAN_TILE - 1) / SCAN_TILE);
         hipLaunchKernelGGL(k_scan_block_sums, dim3(sblk), dim3(S360_BLOCK), 0, st, tiles_touched, scratch, np);
         hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(S360_BLOCK), 0, st, scratch, sblk, (uint32_t*)nullptr);
         hipLaunchKernelGGL(k_scan_final, dim3(sblk), dim3(S360_BLOCK), 0, st, tiles_touched, scratch, offsets, np);
         S360_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(S360_BLOCK), 0, st, tile_count, tile_start, tile_cursor, nt, kp.cap, header);
+    {
+        ProfScope ps(PS_TILE_SCAN, st);
+        hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(S360_BLOCK), 0, st, tile_count, tile_start, tile_cursor, nt, kp.cap, header);
+    }
     S360_CHECK_LAUNCH();
     if (kp.P > 0) {
         const dim3 egrid((kp.P + S360_BLOCK - 1) / S360_BLOCK, kp.V);
+        {
+        ProfScope ps(PS_EMIT, st);
         if ((size_t)kp.T * 8 <= 64 * 1024)
             hipLaunchKernelGGL(k_emit<true>, egrid, dim3(S360_BLOCK), (size_t)kp.T * 8, st, kp, tiles_touched, recA, recC,
                                tile_start, tile_cursor, keys);
         else
             hipLaunchKernelGGL(k_emit<false>, egrid, dim3(S360_BLOCK), 0, st, kp, tiles_touched, recA, recC, tile_start,
                                tile_cursor, keys);
+        }
         S360_CHECK_LAUNCH();
+        ProfScope ps(PS_SORT, st);
         (void)hipFuncSetAttribute((const void*)k_sort_tiles<16384, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL((k_sort_tiles<1024, 256>), dim3(nt), dim3(256), 1024 * 8, st, tile_start, keys, list, 0u, kp.cap);
         hipLaunchKernelGGL((k_sort_tiles<4096, 512>), dim3(nt), dim3(512), 4096 * 8, st, tile_start, keys, list, 1024u, kp.cap);
@@ -644,8 +656,11 @@ extern "C" int s360_forward(const S360Params* prm, const S360View* views, const 
         hipLaunchKernelGGL(k_sort_tiles_global, dim3(nt), dim3(S360_BLOCK), 0, st, tile_start, keys, list, 16384u, kp.cap);
         S360_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(k_render, dim3(nt), dim3(S360_BLOCK), 0, st, kp, views, tile_start, list, recA, recB, recC, images,
-                       final_T, n_contrib, tile_max_contrib);
+    {
+        ProfScope ps(PS_RENDER, st);
+        hipLaunchKernelGGL(k_render, dim3(nt), dim3(S360_BLOCK), 0, st, kp, views, tile_start, list, recA, recB, recC, images,
+                           final_T, n_contrib, tile_max_contrib);
+    }
     S360_CHECK_LAUNCH();
     return S360_OK;
 }

@@ -9,12 +9,17 @@
 // The face-z coordinate lands on an integer face +- 6e-8, so up to two faces are blended with
 // a ~1e-7 weight — reproduced here rather than "fixed" (SURVEY.md §8 a10).
 #include "s360_device.h"
+#include "s360_prof.h"
+
+#include <mutex>
+#include <vector>
 
 namespace s360 {
 
 struct FaceMap {
     int src[6];   // source face index for Cube2Equirec slot s
     int flip[6];  // 1: read the face flipped on both image axes
+    long long fs, cs, rs;  // element strides between faces / channels / rows of the face tensor
 };
 
 __device__ __forceinline__ float unnorm_clip(float g, int size) {
@@ -32,7 +37,6 @@ __global__ __launch_bounds__(S360_BLOCK) void k_cube2erp_fwd(const float* __rest
     const int x0 = (int)x0f, y0 = (int)y0f, z0 = (int)z0f;
     const float fx = ix - x0f, fy = iy - y0f, fz = iz - z0f;
     const float wx[2] = {1.0f - fx, fx}, wy[2] = {1.0f - fy, fy}, wz[2] = {1.0f - fz, fz};
-    const size_t fsz = (size_t)fw * fw;
     for (int c = 0; c < C; ++c) {
         float acc = 0.f;
 #pragma unroll
@@ -40,7 +44,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_cube2erp_fwd(const float* __rest
             const int z = z0 + dz;
             if (z < 0 || z > 5) continue;
             const int sf = fm.src[z];
-            const float* fp = faces + ((size_t)sf * C + c) * fsz;
+            const float* fp = faces + (size_t)sf * fm.fs + (size_t)c * fm.cs;
 #pragma unroll
             for (int dy = 0; dy < 2; ++dy) {
                 const int y = y0 + dy;
@@ -50,7 +54,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_cube2erp_fwd(const float* __rest
                     const int x = x0 + dx;
                     if (x < 0 || x >= fw) continue;
                     const int yy = fm.flip[z] ? fw - 1 - y : y, xx = fm.flip[z] ? fw - 1 - x : x;
-                    acc += fp[(size_t)yy * fw + xx] * (wx[dx] * wy[dy] * wz[dz]);
+                    acc += fp[(size_t)yy * fm.rs + xx] * (wx[dx] * wy[dy] * wz[dz]);
                 }
             }
         }
@@ -68,14 +72,13 @@ __global__ __launch_bounds__(S360_BLOCK) void k_cube2erp_bwd(const float* __rest
     const int x0 = (int)x0f, y0 = (int)y0f, z0 = (int)z0f;
     const float fx = ix - x0f, fy = iy - y0f, fz = iz - z0f;
     const float wx[2] = {1.0f - fx, fx}, wy[2] = {1.0f - fy, fy}, wz[2] = {1.0f - fz, fz};
-    const size_t fsz = (size_t)fw * fw;
     for (int c = 0; c < C; ++c) {
         const float g = d_erp[(size_t)c * n + i];
 #pragma unroll
         for (int dz = 0; dz < 2; ++dz) {
             const int z = z0 + dz;
             if (z < 0 || z > 5) continue;
-            float* fp = d_faces + ((size_t)fm.src[z] * C + c) * fsz;
+            float* fp = d_faces + (size_t)fm.src[z] * fm.fs + (size_t)c * fm.cs;
 #pragma unroll
             for (int dy = 0; dy < 2; ++dy) {
                 const int y = y0 + dy;
@@ -87,14 +90,17 @@ __global__ __launch_bounds__(S360_BLOCK) void k_cube2erp_bwd(const float* __rest
                     const float w = wx[dx] * wy[dy] * wz[dz];
                     if (w == 0.f) continue;
                     const int yy = fm.flip[z] ? fw - 1 - y : y, xx = fm.flip[z] ? fw - 1 - x : x;
-                    atomicAdd(&fp[(size_t)yy * fw + xx], g * w);
+                    atomicAdd(&fp[(size_t)yy * fm.rs + xx], g * w);
                 }
             }
         }
     }
 }
 
-static bool make_face_map(const int32_t* face_map_host, FaceMap& fm) {
+static bool make_face_map(const int32_t* face_map_host, const int64_t* strides_host, int C, int fw, FaceMap& fm) {
+    fm.fs = strides_host ? strides_host[0] : (long long)C * fw * fw;
+    fm.cs = strides_host ? strides_host[1] : (long long)fw * fw;
+    fm.rs = strides_host ? strides_host[2] : (long long)fw;
     for (int s = 0; s < 6; ++s) {
         const int v = face_map_host ? face_map_host[s] : s;
         fm.src[s] = v & 7;
@@ -109,11 +115,13 @@ static bool make_face_map(const int32_t* face_map_host, FaceMap& fm) {
 using namespace s360;
 
 extern "C" int s360_cube2erp_forward(const float* faces, const float* grid, float* erp, int32_t channels, int32_t face_w,
-                                     int32_t equ_h, int32_t equ_w, const int32_t* face_map_host, void* stream) {
+                                     int32_t equ_h, int32_t equ_w, const int32_t* face_map_host,
+                                     const int64_t* strides_host, void* stream) {
     if (!faces || !grid || !erp || channels < 1 || face_w < 1 || equ_h < 1 || equ_w < 1) return S360_E_BADARG;
     FaceMap fm;
-    if (!make_face_map(face_map_host, fm)) return S360_E_BADARG;
+    if (!make_face_map(face_map_host, strides_host, channels, face_w, fm)) return S360_E_BADARG;
     const size_t n = (size_t)equ_h * equ_w;
+    ProfScope ps(PS_STITCH, (hipStream_t)stream);
     hipLaunchKernelGGL(k_cube2erp_fwd, dim3((unsigned)((n + S360_BLOCK - 1) / S360_BLOCK)), dim3(S360_BLOCK), 0,
                        (hipStream_t)stream, faces, grid, erp, channels, face_w, equ_h, equ_w, fm);
     return hipGetLastError() == hipSuccess ? S360_OK : S360_E_LAUNCH;
@@ -121,16 +129,89 @@ extern "C" int s360_cube2erp_forward(const float* faces, const float* grid, floa
 
 extern "C" int s360_cube2erp_backward(const float* d_erp, const float* grid, float* d_faces, int32_t channels,
                                       int32_t face_w, int32_t equ_h, int32_t equ_w, const int32_t* face_map_host,
-                                      void* stream) {
+                                      const int64_t* strides_host, void* stream) {
     if (!d_erp || !grid || !d_faces || channels < 1 || face_w < 1 || equ_h < 1 || equ_w < 1) return S360_E_BADARG;
+    if (strides_host) return S360_E_UNSUPPORTED;  // the adjoint writes a dense [6,C,fw,fw] tensor it zeroes itself
     FaceMap fm;
-    if (!make_face_map(face_map_host, fm)) return S360_E_BADARG;
+    if (!make_face_map(face_map_host, strides_host, channels, face_w, fm)) return S360_E_BADARG;
     const size_t n = (size_t)equ_h * equ_w;
+    ProfScope ps(PS_STITCH_BWD, (hipStream_t)stream);
     if (hipMemsetAsync(d_faces, 0, (size_t)6 * channels * face_w * face_w * sizeof(float), (hipStream_t)stream) != hipSuccess)
         return S360_E_LAUNCH;
     hipLaunchKernelGGL(k_cube2erp_bwd, dim3((unsigned)((n + S360_BLOCK - 1) / S360_BLOCK)), dim3(S360_BLOCK), 0,
                        (hipStream_t)stream, d_erp, grid, d_faces, channels, face_w, equ_h, equ_w, fm);
     return hipGetLastError() == hipSuccess ? S360_OK : S360_E_LAUNCH;
+}
+
+// ---------------------------------------------------------------------------- profiler
+namespace s360 {
+namespace {
+struct Rec {
+    int slot;
+    hipEvent_t a, b;
+};
+std::mutex g_mu;
+bool g_on = false;
+std::vector<Rec> g_recs;          // completed or open records of the current window
+std::vector<hipEvent_t> g_pool;   // recycled events
+hipEvent_t get_event() {
+    if (!g_pool.empty()) {
+        hipEvent_t e = g_pool.back();
+        g_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+}  // namespace
+bool prof_enabled() { return g_on; }
+void prof_mark(int slot, hipStream_t st, bool end) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!end) {
+        Rec r{slot, get_event(), get_event()};
+        (void)hipEventRecord(r.a, st);
+        g_recs.push_back(r);
+    } else {
+        for (size_t i = g_recs.size(); i-- > 0;)
+            if (g_recs[i].slot == slot) {
+                (void)hipEventRecord(g_recs[i].b, st);
+                break;
+            }
+    }
+}
+}  // namespace s360
+
+static const char* kSlotNames[PS_NSLOTS] = {"preprocess", "scan", "tile_scan", "emit", "sort_tiles", "render",
+                                            "zero_inst",  "render_bwd", "preprocess_bwd", "cube2erp", "cube2erp_bwd"};
+
+extern "C" int s360_profile_slots(void) { return PS_NSLOTS; }
+extern "C" const char* s360_profile_slot_name(int slot) { return slot >= 0 && slot < PS_NSLOTS ? kSlotNames[slot] : ""; }
+extern "C" int s360_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(s360::g_mu);
+    s360::g_on = on != 0;
+    return S360_OK;
+}
+extern "C" int s360_profile_collect(float* total_ms, int32_t* calls) {
+    if (!total_ms || !calls) return S360_E_BADARG;
+    std::lock_guard<std::mutex> lk(s360::g_mu);
+    for (int i = 0; i < PS_NSLOTS; ++i) {
+        total_ms[i] = 0.f;
+        calls[i] = 0;
+    }
+    for (auto& r : s360::g_recs) {
+        if (hipEventSynchronize(r.b) == hipSuccess) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+                total_ms[r.slot] += ms;
+                calls[r.slot] += 1;
+            }
+        }
+        s360::g_pool.push_back(r.a);
+        s360::g_pool.push_back(r.b);
+    }
+    s360::g_recs.clear();
+    return S360_OK;
 }
 
 extern "C" int s360_abi_version(void) { return S360_ABI_VERSION; }

@@ -42,6 +42,25 @@ def render_cuda(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tenso
     """Same contract as the reference's render_cuda (cuda_splatting.py:47-127): batch of b
     (camera, cloud) pairs -> [b,3,h,w].  One HIP rasteriser call per batch item, no .item() sync."""
     assert use_sh or gaussian_sh_coefficients.shape[-1] == 1
+    vs, calls = rasterizer_boundary(extrinsics, intrinsics, near, far, gaussian_means, gaussian_covariances,
+                                    gaussian_sh_coefficients, gaussian_opacities, scale_invariant, use_sh)
+    h, w = image_shape
+    images = []
+    for i, kw in enumerate(calls):
+        views = rasterizer.pack_views(vs["view_matrix"][i], vs["full_projection"][i], vs["campos"][i],
+                                      vs["tan_fov_x"][i:i + 1], vs["tan_fov_y"][i:i + 1], background_color[i])
+        img, _ = rasterizer.rasterize_views(
+            kw["means3D"], kw["cov3D_precomp"], kw["opacities"], kw["shs"], kw["colors_precomp"], views=views,
+            image_height=h, image_width=w, sh_degree=kw["sh_degree"], shared_campos=True, want_radii=False)
+        images.append(img[0])
+    return torch.stack(images)
+
+
+def rasterizer_boundary(extrinsics, intrinsics, near, far, gaussian_means, gaussian_covariances,
+                        gaussian_sh_coefficients, gaussian_opacities, scale_invariant=True, use_sh=True):
+    """The tensors render_cuda hands to the rasteriser, per batch item (cuda_splatting.py:64-75,
+    115-123): camera setup dict + [{means3D, cov3D_precomp, opacities, shs | colors_precomp,
+    sh_degree}].  Pure torch (runs on CPU too): pinned against tests/golden/boundary_render_cuda.npz."""
     vs = cameras.view_setup(extrinsics, intrinsics, near, far, scale_invariant)
     scale = vs["scale"]
     if scale_invariant:
@@ -50,18 +69,12 @@ def render_cuda(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tenso
     n = gaussian_sh_coefficients.shape[-1]
     degree = isqrt(n) - 1
     shs = gaussian_sh_coefficients.transpose(2, 3).contiguous()  # "b g xyz n -> b g n xyz"
-    b = extrinsics.shape[0]
-    h, w = image_shape
-    images = []
-    for i in range(b):
-        views = rasterizer.pack_views(vs["view_matrix"][i], vs["full_projection"][i], vs["campos"][i],
-                                      vs["tan_fov_x"][i:i + 1], vs["tan_fov_y"][i:i + 1], background_color[i])
-        img, _ = rasterizer.rasterize_views(
-            gaussian_means[i], _triu_cov6(gaussian_covariances[i]), gaussian_opacities[i, ..., None],
-            shs[i] if use_sh else None, None if use_sh else shs[i, :, 0, :], views=views, image_height=h,
-            image_width=w, sh_degree=degree, shared_campos=True, want_radii=False)
-        images.append(img[0])
-    return torch.stack(images)
+    calls = []
+    for i in range(extrinsics.shape[0]):
+        calls.append(dict(means3D=gaussian_means[i], cov3D_precomp=_triu_cov6(gaussian_covariances[i]),
+                          opacities=gaussian_opacities[i, ..., None], shs=shs[i] if use_sh else None,
+                          colors_precomp=None if use_sh else shs[i, :, 0, :], sh_degree=degree))
+    return vs, calls
 
 
 def _depth_colors(extrinsics, means, near, far, mode):

@@ -133,6 +133,8 @@ class _RasterizeViews(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, cov6, views, cfg):
         h, w, sh_degree, shared_campos, max_instances, check, want_radii, cov9, sh_channel_major = cfg
+        if not means3D.is_cuda:
+            raise RuntimeError("means3D must live on the GPU (hip device); the rasteriser has no CPU path")
         with torch.cuda.device(means3D.device):
             m3 = _f32c(means3D, "means3D")
             c6 = _f32c(cov6, "cov3D_precomp")

@@ -1,0 +1,60 @@
+"""The C-ABI library: loads on a machine without a GPU, exports every symbol include/s360.h
+declares, and its host-only entry points behave (no compute calls here)."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import pytest
+
+from splatter360_amd import _lib
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _declared():
+    txt = (ROOT / "include" / "s360.h").read_text()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(s360_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.lib()
+    names = _declared()
+    assert len(names) >= 11 and set(_lib.EXPORTS) == set(names)
+    for n in names:
+        assert hasattr(lib, n), n
+    assert lib.s360_abi_version() == _lib.ABI_VERSION
+    assert lib.s360_error_string(0) == b"ok" and lib.s360_error_string(-2) == b"workspace too small"
+
+
+def test_layout_is_monotone_and_aligned():
+    prm = _lib.S360Params(P=1000, V=6, H=64, W=64, sh_degree=4, M=25, flags=1, max_instances=5000)
+    lay = _lib.layout(prm)
+    offs = [getattr(lay, n) for n, _ in _lib.S360Layout._fields_ if n not in ("total_bytes", "backward_bytes")]
+    assert offs == sorted(offs) and all(o % 256 == 0 for o in offs)
+    assert lay.total_bytes >= offs[-1] + 6 * 16 * 4 and lay.backward_bytes >= 5000 * 48
+    assert C.sizeof(_lib.S360Params) == 32
+
+
+def test_bad_arguments_are_rejected_before_any_gpu_work():
+    lib = _lib.lib()
+    bad = _lib.S360Params(P=10, V=9, H=64, W=64, sh_degree=4, M=25, flags=0, max_instances=100)
+    out = _lib.S360Layout()
+    assert lib.s360_layout(C.byref(bad), C.byref(out)) == -1
+    ok = _lib.S360Params(P=10, V=1, H=64, W=64, sh_degree=4, M=25, flags=0, max_instances=100)
+    # null views / images / workspace
+    assert lib.s360_forward(C.byref(ok), None, None, None, None, None, None, None, None, None, 0, None) == -1
+    assert lib.s360_cube2erp_forward(None, None, None, 3, 64, 128, 256, None, None, None) == -1
+    with pytest.raises(RuntimeError):
+        _lib.check(-4, "x")
+
+
+def test_rasterizer_refuses_cpu_tensors():
+    import torch
+    from splatter360_amd import rasterizer
+    views = torch.zeros(1, rasterizer.VIEW_FLOATS)
+    with pytest.raises(RuntimeError):
+        rasterizer.rasterize_views(torch.zeros(4, 3), torch.zeros(4, 6), torch.zeros(4), colors_precomp=torch.zeros(4, 3),
+                                   views=views, image_height=16, image_width=16)
+    with pytest.raises(Exception):
+        rasterizer.rasterize_views(torch.zeros(4, 3), torch.zeros(4, 6), torch.zeros(4), views=views, image_height=16, image_width=16)
