@@ -98,7 +98,8 @@ def main():
               for k in ("means", "covariances", "harmonics", "opacities")]
     # one target panorama per rank (identity rotation, small per-rank offsets)
     pose = torch.tensor(synthetic.target_pano_pose((0.05 * rank, 0.02 * rank, -0.03 * rank)), device=dev)
-    near, far = torch.tensor(0.1, device=dev), torch.tensor(10.0, device=dev)
+    # what the reference's dataloader hands the decoder for one target panorama: 6 face cameras
+    ext, K, near, far = decoder.cube_cameras(pose, 0.1, 10.0)
     bg = torch.zeros(3, device=dev)
     gt = torch.full((6, 3, face_w, face_w), 0.5, device=dev)
     c2e = stitch.Cube2Equirec(face_w, pano_h, pano_w).to(dev)
@@ -107,7 +108,7 @@ def main():
     def step():
         for p in params:
             p.grad = None
-        faces = decoder.render_cube_faces(pose, near, far, face_w, bg, *params, check="lazy")
+        faces = decoder.render_views_fused(ext, K, near, far, (face_w, face_w), bg, *params, check="lazy")
         out["erp"] = c2e.stitch_rendered(faces.detach())
         if a.mode == "fwdbwd":
             loss = ((faces - gt) ** 2).mean()

@@ -37,6 +37,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_render_bwd(
     __shared__ float sC[BWD_BATCH];
     __shared__ uint32_t sInst[BWD_BATCH];
     __shared__ float4 sAcc[4][BWD_BATCH][GREC / 4];
+    __shared__ unsigned long long sMask[BWD_BATCH / 64][4];  // [staging wave][strip]
 
     const int t = blockIdx.x;
     const int v = t / kp.T, rem = t - v * kp.T;
@@ -68,10 +69,14 @@ __global__ __launch_bounds__(S360_BLOCK) void k_render_bwd(
     float T = T_final;
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_alpha = 0.f;
 
+    const float x0 = (float)(tx * 16), y0 = (float)(ty * 16);
+    const uint32_t wave_last = wave_max_u32(last);  // no lane of this wave needs entries >= wave_last
+
     // batches walk the list back to front; batch element j is list entry (hi - j)
     for (int64_t hi = (int64_t)maxc - 1; hi >= 0; hi -= BWD_BATCH) {
         const int cnt = (int)min((int64_t)BWD_BATCH, hi + 1);
         __syncthreads();
+        bool m0 = false, m1 = false, m2 = false, m3 = false;
         if ((int)threadIdx.x < cnt) {
             const uint32_t idx = (uint32_t)(hi - threadIdx.x);
             const uint32_t p = list[start + idx];
@@ -84,14 +89,37 @@ __global__ __launch_bounds__(S360_BLOCK) void k_render_bwd(
             tile_rect(a4.x, a4.y, __float_as_int(c.z), kp.gx, kp.gy, minx, miny, maxx, maxy);
             const uint32_t base = p == 0 ? 0u : offsets[p - 1];
             sInst[threadIdx.x] = base + (uint32_t)((ty - miny) * (maxx - minx) + (tx - minx));
+            // same conservative strip test as the forward composite
+            const float r = c.w;
+            const bool xin = !(a4.x + r < x0 || a4.x - r > x0 + 15.0f);
+            m0 = xin && !(a4.y + r < y0 || a4.y - r > y0 + 3.0f);
+            m1 = xin && !(a4.y + r < y0 + 4.0f || a4.y - r > y0 + 7.0f);
+            m2 = xin && !(a4.y + r < y0 + 8.0f || a4.y - r > y0 + 11.0f);
+            m3 = xin && !(a4.y + r < y0 + 12.0f || a4.y - r > y0 + 15.0f);
         }
         {
+            const unsigned long long b0 = __ballot(m0), b1 = __ballot(m1), b2 = __ballot(m2), b3 = __ballot(m3);
+            if (lane == 0 && wave < BWD_BATCH / 64) {
+                sMask[wave][0] = b0;
+                sMask[wave][1] = b1;
+                sMask[wave][2] = b2;
+                sMask[wave][3] = b3;
+            }
             float4* z = &sAcc[0][0][0];
             for (int i = threadIdx.x; i < 4 * BWD_BATCH * (GREC / 4); i += S360_BLOCK) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();
-        for (int j = 0; j < cnt; ++j) {
+#pragma unroll 1
+        for (int chunk = 0; chunk < BWD_BATCH / 64; ++chunk) {
+            unsigned long long m = sMask[chunk][wave];
+            m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(m >> 32)) << 32) |
+                (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m);
+            while (m) {
+                const int bit = __builtin_ctzll(m);
+                m &= m - 1;
+                const int j = chunk * 64 + bit;
             const uint32_t contributor = (uint32_t)(hi - j);  // 0-based position in the list
+            if (contributor >= wave_last) continue;          // wave-uniform
             float g_x = 0.f, g_y = 0.f, g_A = 0.f, g_B = 0.f, g_C = 0.f, g_op = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f;
             bool active = false;
             if (contributor < last) {
@@ -145,6 +173,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_render_bwd(
                 sAcc[wave][j][0] = make_float4(g_x, g_y, g_A, g_B);
                 sAcc[wave][j][1] = make_float4(g_C, g_op, g_r, g_g);
                 sAcc[wave][j][2] = make_float4(g_b, 0.f, 0.f, 0.f);
+            }
             }
         }
         __syncthreads();
@@ -485,7 +514,14 @@ extern "C" int s360_backward(const S360Params* prm, const S360View* views, const
         size_t lds = d_shs ? (size_t)S360_BLOCK * kp.M * 3 * 4 : 0;
         if (d_shs && !(kp.flags & S360_FLAG_SHARED_CAMPOS)) lds += (size_t)S360_BLOCK * kp.V * 3 * 4;
         if (lds > 160 * 1024) return S360_E_UNSUPPORTED;
-        (void)hipFuncSetAttribute((const void*)k_preprocess_bwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        {
+            static bool attr_done[64] = {};
+            int dev = 0;
+            if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !attr_done[dev]) {
+                (void)hipFuncSetAttribute((const void*)k_preprocess_bwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attr_done[dev] = true;
+            }
+        }
         hipLaunchKernelGGL(k_preprocess_bwd<true>, dim3(nblk), dim3(S360_BLOCK), lds, st, kp, views, means3D, cov6, shs,
                            tiles_touched, offsets, clamped, inst_grad, d_means3D, d_means2D, d_cov6, d_opacities, d_shs,
                            d_colors);

@@ -121,6 +121,19 @@ __device__ __forceinline__ void xform43(const float* m, float px, float py, floa
     oz = m[2] * px + m[6] * py + m[10] * pz + m[14];
 }
 
+// 75 consecutive floats (one Gaussian's degree-4 SH slab, only 4-byte aligned) as 18 x 16-byte + 3 loads.
+struct __attribute__((packed, aligned(4))) F4U {
+    float x, y, z, w;
+};
+__device__ __forceinline__ void load75(const float* __restrict__ p, float* c) {
+#pragma unroll
+    for (int i = 0; i < 18; ++i) {
+        const F4U v = *reinterpret_cast<const F4U*>(p + 4 * i);
+        c[4 * i] = v.x; c[4 * i + 1] = v.y; c[4 * i + 2] = v.z; c[4 * i + 3] = v.w;
+    }
+    c[72] = p[72]; c[73] = p[73]; c[74] = p[74];
+}
+
 // Upper triangle (00,01,02,11,12,22) of Gaussian g's covariance from either layout.
 __device__ __forceinline__ void load_cov6(const float* __restrict__ cov, int g, bool cov9, float* c6) {
     if (cov9) {
@@ -202,6 +215,11 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
     v += dpp_f<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
     v += dpp_f<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3
     return v;
+}
+
+// broadcast lane `l` (wave-uniform) of a VGPR into an SGPR
+__device__ __forceinline__ float rl(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 
 __device__ __forceinline__ float readlane63(float v) {

@@ -24,32 +24,20 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess(
     const float* __restrict__ colors, int32_t* __restrict__ radii, uint32_t* __restrict__ tiles_touched,
     float4* __restrict__ recA, float4* __restrict__ recB, float4* __restrict__ recC,
     uint8_t* __restrict__ clamped, uint32_t* __restrict__ tile_count, int lds_hist) {
-    // dynamic LDS: [SH slab: 256*M*3 floats (USE_SH)] [tile histogram: V*T uint32 (lds_hist)]
+    // dynamic LDS: tile histogram V*T uint32 (lds_hist).  SH coefficients are NOT staged: every lane
+    // streams its own Gaussian's 300-byte slab with 16-byte loads (all bytes of every cache line are
+    // consumed by the same lane within a few instructions, so HBM traffic stays 1x) — this keeps the
+    // kernel register-limited (12 waves/CU) instead of LDS-limited (4 waves/CU with a 77 KB slab).
     extern __shared__ __attribute__((aligned(16))) float lds_sh[];
     const int tid = threadIdx.x;
     const int g0 = blockIdx.x * S360_BLOCK;
     const int g = g0 + tid;
     const int P = kp.P;
-    const int nb = min(S360_BLOCK, P - g0);  // Gaussians handled by this block
-    uint32_t* hist = reinterpret_cast<uint32_t*>(lds_sh + (USE_SH ? S360_BLOCK * kp.M * 3 : 0));
+    uint32_t* hist = reinterpret_cast<uint32_t*>(lds_sh);
     const int nhist = kp.V * kp.T;
     if (lds_hist)
         for (int i = tid; i < nhist; i += S360_BLOCK) hist[i] = 0u;
 
-    if (USE_SH) {
-        // coalesced stage of this block's SH slab: nb*M*3 contiguous floats
-        const int nfl = nb * kp.M * 3;
-        const float* src = shs + (size_t)g0 * kp.M * 3;
-        if ((((uintptr_t)src) & 15) == 0) {
-            const int n4 = nfl >> 2;
-            const float4* s4 = reinterpret_cast<const float4*>(src);
-            float4* d4 = reinterpret_cast<float4*>(lds_sh);
-            for (int i = tid; i < n4; i += S360_BLOCK) d4[i] = s4[i];
-            for (int i = (n4 << 2) + tid; i < nfl; i += S360_BLOCK) lds_sh[i] = src[i];
-        } else {
-            for (int i = tid; i < nfl; i += S360_BLOCK) lds_sh[i] = src[i];
-        }
-    }
     __syncthreads();
     if (g < P) {
     const float mx0 = means[3 * g], my0 = means[3 * g + 1], mz0 = means[3 * g + 2];
@@ -112,10 +100,28 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess(
                         float Y[25];
                         sh_basis(kp.deg, x, y, z, Y);
                         const int n = (kp.deg + 1) * (kp.deg + 1);
-                        const float* sh = lds_sh + tid * kp.M * 3;
+                        const float* sh = shs + (size_t)g * kp.M * 3;
                         float a0 = 0.f, a1 = 0.f, a2 = 0.f;
                         // sequential (unfused) accumulation: same rounding as the CPU oracle
-                        if (ch_major) {
+                        if (kp.M == 25 && kp.deg == 4) {
+                            float c[75];
+                            load75(sh, c);
+                            if (ch_major) {
+#pragma unroll
+                                for (int k = 0; k < 25; ++k) {
+                                    a0 += Y[k] * c[k];
+                                    a1 += Y[k] * c[25 + k];
+                                    a2 += Y[k] * c[50 + k];
+                                }
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < 25; ++k) {
+                                    a0 += Y[k] * c[k * 3 + 0];
+                                    a1 += Y[k] * c[k * 3 + 1];
+                                    a2 += Y[k] * c[k * 3 + 2];
+                                }
+                            }
+                        } else if (ch_major) {
                             for (int k = 0; k < n; ++k) {
                                 a0 += Y[k] * sh[k];
                                 a1 += Y[k] * sh[kp.M + k];
@@ -245,8 +251,8 @@ __global__ __launch_bounds__(S360_BLOCK) void k_scan_final(const uint32_t* __res
 
 // single block: tile_start[0..nt] = exclusive scan of tile_count; header bookkeeping.
 __global__ __launch_bounds__(S360_BLOCK) void k_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_start,
-                                                         uint32_t* __restrict__ tile_cursor, int nt, uint32_t cap,
-                                                         uint32_t* __restrict__ header) {
+                                                         uint32_t* __restrict__ tile_cursor, uint32_t* __restrict__ tile_max_contrib,
+                                                         int nt, uint32_t cap, uint32_t* __restrict__ header) {
     __shared__ uint32_t lds[8];
     __shared__ uint32_t lds_max;
     if (threadIdx.x == 0) lds_max = 0;
@@ -261,6 +267,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_tile_scan(const uint32_t* __rest
         if (i < nt) {
             tile_start[i] = carry + ex;
             tile_cursor[i] = 0;
+            tile_max_contrib[i] = 0;
         }
         carry += tot;
     }
@@ -336,7 +343,10 @@ __global__ __launch_bounds__(S360_BLOCK) void k_emit(KParams kp, const uint32_t*
 // 64-bit keys in LDS, then writes the sorted keys back and the pair list.
 template <int CAP, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_sort_tiles(const uint32_t* __restrict__ tile_start, uint64_t* __restrict__ keys,
-                                                          uint32_t* __restrict__ list, uint32_t lo, uint32_t cap) {
+                                                          uint32_t* __restrict__ list, uint32_t lo, uint32_t cap, uint32_t* __restrict__ dbg) {
+#ifdef S360_DBG_TIMING
+    const long long t_begin = wall_clock64();
+#endif
     extern __shared__ __attribute__((aligned(16))) uint64_t lds_k[];
     const uint32_t s = min(tile_start[blockIdx.x], cap), e = min(tile_start[blockIdx.x + 1], cap);
     const uint32_t n = e - s;
@@ -365,6 +375,9 @@ __global__ __launch_bounds__(THREADS) void k_sort_tiles(const uint32_t* __restri
         keys[s + i] = k;
         list[s + i] = (uint32_t)k;
     }
+#ifdef S360_DBG_TIMING
+    if (threadIdx.x == 0) dbg[blockIdx.x] = (uint32_t)(wall_clock64() - t_begin);
+#endif
 }
 
 // Fallback for tile lists that exceed the LDS capacity: the same bitonic network run by one
@@ -398,23 +411,30 @@ __global__ __launch_bounds__(S360_BLOCK) void k_sort_tiles_global(const uint32_t
 }
 
 // ------------------------------------------------------------------------------ composite
-// One workgroup per 16x16 tile; wave w owns the 16x4 pixel strip w.  Each batch of 256 list
-// entries is staged into LDS once; while staging, every entry is tested against the four strips
-// with its conservative cull radius and the four 64-bit ballots per staging wave are published, so
-// a wave only walks (scalar bit-scan) the entries that can reach its strip.  Culled entries would
-// have failed the alpha >= 1/255 test for every pixel of the strip, so results are unchanged.
+// Wave-autonomous strips.  A workgroup is the four 16x4 pixel strips of one 16x16 tile, but the
+// four waves never synchronise: each wave walks the tile's depth-sorted list on its own, 64 entries
+// at a time, with lane l fetching entry l straight into registers (list index prefetched two
+// chunks ahead, splat records one chunk ahead).  The wave's register file is the broadcast source:
+//   * cull   : every lane tests ITS entry against the strip with the conservative cull radius;
+//              the ballot is the work list (culled entries fail alpha >= 1/255 on every pixel of
+//              the strip, so skipping them changes nothing);
+//   * dense  : surviving entries are broadcast one at a time with v_readlane (SGPR operands, no
+//              LDS, no exec-mask juggling) while the 64 pixels sit in the lanes;
+//   * sparse : once <= SPARSE_PIXELS pixels of the strip are still unsaturated the roles flip —
+//              64 ENTRIES in the lanes, one live pixel per iteration, and only entries passing the
+//              tests are replayed in list order.  Same arithmetic per (pixel, entry) pair.
+// A wave retires as soon as its own 64 pixels are saturated (no tile-wide barrier to wait for).
+constexpr int SPARSE_PIXELS = 12;
+
 __global__ __launch_bounds__(S360_BLOCK) void k_render(KParams kp, const S360View* __restrict__ views,
                                                       const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ list,
                                                       const float4* __restrict__ recA, const float4* __restrict__ recB,
                                                       const float4* __restrict__ recC, float* __restrict__ images,
                                                       float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                                                      uint32_t* __restrict__ tile_max_contrib) {
-    __shared__ float4 sA[S360_BLOCK];
-    __shared__ float4 sB[S360_BLOCK];
-    __shared__ float sC[S360_BLOCK];
-    __shared__ unsigned long long sMask[4][4];  // [staging wave][strip]
-    __shared__ uint32_t s_maxc;
-
+                                                      uint32_t* __restrict__ tile_max_contrib, uint32_t* __restrict__ dbg) {
+#ifdef S360_DBG_TIMING
+    const long long t_begin = wall_clock64();
+#endif
     const int t = blockIdx.x;
     const int v = t / kp.T, rem = t - v * kp.T;
     const int ty = rem / kp.gx, tx = rem - ty * kp.gx;
@@ -423,75 +443,90 @@ __global__ __launch_bounds__(S360_BLOCK) void k_render(KParams kp, const S360Vie
     const bool inside = px < kp.W && py < kp.H;
     const float pxf = (float)px, pyf = (float)py;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const float x0 = (float)(tx * 16), y0 = (float)(ty * 16);
+    const float x0 = (float)(tx * 16), ys0 = (float)(ty * 16 + wave * 4);  // strip origin
 
     const uint32_t start = min(tile_start[t], kp.cap), end = min(tile_start[t + 1], kp.cap);
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
     uint32_t last = 0;
     bool done = !inside;
-    if (threadIdx.x == 0) s_maxc = 0;
 
-    for (uint32_t b = start; b < end; b += S360_BLOCK) {
-        // barrier + early out when every pixel of the tile is saturated
-        if (__syncthreads_count(done ? 1 : 0) == S360_BLOCK) break;
-        const uint32_t idx = b + threadIdx.x;
-        bool m0 = false, m1 = false, m2 = false, m3 = false;
-        if (idx < end) {
-            const uint32_t p = list[idx];
-            const float4 a = recA[p];
-            const float4 c = recC[p];
-            sA[threadIdx.x] = a;
-            sB[threadIdx.x] = recB[p];
-            sC[threadIdx.x] = c.x;
-            const float r = c.w;
-            const bool xin = !(a.x + r < x0 || a.x - r > x0 + 15.0f);
-            m0 = xin && !(a.y + r < y0 || a.y - r > y0 + 3.0f);
-            m1 = xin && !(a.y + r < y0 + 4.0f || a.y - r > y0 + 7.0f);
-            m2 = xin && !(a.y + r < y0 + 8.0f || a.y - r > y0 + 11.0f);
-            m3 = xin && !(a.y + r < y0 + 12.0f || a.y - r > y0 + 15.0f);
+    // software pipeline: list indices two chunks ahead, records one chunk ahead
+    uint32_t p_n1 = 0, p_n2 = 0;
+    if (start + lane < end) p_n1 = list[start + lane];
+    if (start + 64 + lane < end) p_n2 = list[start + 64 + lane];
+    float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na, nc = na;
+    if (start + lane < end) {
+        na = recA[p_n1];
+        nb = recB[p_n1];
+        nc = recC[p_n1];
+    }
+    for (uint32_t b = start; b < end; b += 64) {
+        if (__ballot(!done) == 0ull) break;
+        const float4 ea = na, eb = nb;
+        const float ec = nc.x, er = nc.w;
+        const bool ev = b + lane < end;
+        // issue the next chunk's loads before touching this one
+        p_n1 = p_n2;
+        if (b + 64 + lane < end) {
+            na = recA[p_n1];
+            nb = recB[p_n1];
+            nc = recC[p_n1];
         }
-#ifdef S360_DBG_NOCULL
-        m0 = m1 = m2 = m3 = idx < end;
-#endif
-        const unsigned long long b0 = __ballot(m0), b1 = __ballot(m1), b2 = __ballot(m2), b3 = __ballot(m3);
-        if (lane == 0) {
-            sMask[wave][0] = b0;
-            sMask[wave][1] = b1;
-            sMask[wave][2] = b2;
-            sMask[wave][3] = b3;
-        }
-        __syncthreads();
-        const uint32_t rel = b - start;  // list position of batch element 0
-        if (__ballot(!done) != 0ull) {
-#pragma unroll 1
-            for (int chunk = 0; chunk < 4; ++chunk) {
-                unsigned long long m = sMask[chunk][wave];
-                // (readfirstlane returns a signed int: cast to uint32_t before widening)
-                m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(m >> 32)) << 32) |
-                    (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m);
-                while (m) {
-                    const int bit = __builtin_ctzll(m);
-                    m &= m - 1;
-                    const int j = chunk * 64 + bit;
-                    if (done) continue;
-                    const float4 a = sA[j];
-                    const float4 bb = sB[j];
-                    const float dx = a.x - pxf, dy = a.y - pyf;
-                    const float power = -0.5f * (a.z * dx * dx + bb.x * dy * dy) - a.w * dx * dy;
-                    if (power > 0.0f) continue;
-                    const float alpha = fminf(0.99f, bb.y * __expf(power));
-                    if (alpha < 1.0f / 255.0f) continue;
-                    const float test_T = T * (1.0f - alpha);
-                    if (test_T < 0.0001f) {
-                        done = true;
-                        continue;
-                    }
-                    const float w = alpha * T;
-                    C0 += bb.z * w;
-                    C1 += bb.w * w;
-                    C2 += sC[j] * w;
-                    T = test_T;
-                    last = rel + (uint32_t)j + 1u;
+        if (b + 128 + lane < end) p_n2 = list[b + 128 + lane];
+
+        const bool hit = ev && !(ea.x + er < x0 || ea.x - er > x0 + 15.0f || ea.y + er < ys0 || ea.y - er > ys0 + 3.0f);
+        unsigned long long m = __ballot(hit);
+        if (m == 0ull) continue;
+        const uint32_t rel = b - start;  // list position of this chunk's lane 0
+        const unsigned long long act = __ballot(!done);
+        if (__popcll(act) > SPARSE_PIXELS) {
+            while (m) {
+                const int bit = __builtin_ctzll(m);
+                m &= m - 1;
+                const float gx_ = rl(ea.x, bit), gy_ = rl(ea.y, bit);
+                const float cA = rl(ea.z, bit), cB = rl(ea.w, bit), cC = rl(eb.x, bit), op = rl(eb.y, bit);
+                const float dx = gx_ - pxf, dy = gy_ - pyf;
+                const float power = -0.5f * (cA * dx * dx + cC * dy * dy) - cB * dx * dy;
+                const float alpha = fminf(0.99f, op * __expf(power));
+                const bool valid = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+                if (__ballot(valid) == 0ull) continue;  // wave-uniform
+                const float test_T = T * (1.0f - alpha);
+                const bool stop = valid && test_T < 0.0001f;
+                const bool contrib = valid && !stop;
+                done = done || stop;
+                const float w = contrib ? alpha * T : 0.0f;
+                C0 += rl(eb.z, bit) * w;
+                C1 += rl(eb.w, bit) * w;
+                C2 += rl(ec, bit) * w;
+                T = contrib ? test_T : T;
+                last = contrib ? rel + (uint32_t)bit + 1u : last;
+            }
+        } else {
+            unsigned long long am = act;
+            while (am) {
+                const int pl = __builtin_ctzll(am);
+                am &= am - 1;
+                const float ppx = rl(pxf, pl), ppy = rl(pyf, pl);
+                const float dx = ea.x - ppx, dy = ea.y - ppy;
+                const float power = -0.5f * (ea.z * dx * dx + eb.x * dy * dy) - ea.w * dx * dy;
+                const float alpha = fminf(0.99f, eb.y * __expf(power));
+                unsigned long long vm = __ballot(hit && !(power > 0.0f) && !(alpha < 1.0f / 255.0f));
+                const bool mine = lane == pl;
+                while (vm) {
+                    const int eb_ = __builtin_ctzll(vm);
+                    vm &= vm - 1;
+                    const float a_s = rl(alpha, eb_);
+                    const float test_T = T * (1.0f - a_s);
+                    const bool stop = mine && test_T < 0.0001f;
+                    const bool contrib = mine && !stop;
+                    const float w = contrib ? a_s * T : 0.0f;
+                    C0 += rl(eb.z, eb_) * w;
+                    C1 += rl(eb.w, eb_) * w;
+                    C2 += rl(ec, eb_) * w;
+                    T = contrib ? test_T : T;
+                    last = contrib ? rel + (uint32_t)eb_ + 1u : last;
+                    done = done || stop;
+                    if (__ballot(stop) != 0ull) break;
                 }
             }
         }
@@ -508,9 +543,12 @@ __global__ __launch_bounds__(S360_BLOCK) void k_render(KParams kp, const S360Vie
         n_contrib[(size_t)v * hw + pix] = last;
     }
     const uint32_t wm = wave_max_u32(inside ? last : 0u);
-    if (lane == 0) atomicMax(&s_maxc, wm);
-    __syncthreads();
-    if (threadIdx.x == 0) tile_max_contrib[t] = s_maxc;
+    if (lane == 0 && wm) atomicMax(&tile_max_contrib[t], wm);  // zeroed by k_tile_scan
+#ifdef S360_DBG_TIMING
+    if (lane == 0) {
+        dbg[4 * t + wave] = (uint32_t)(wall_clock64() - t_begin);
+    }
+#endif
 }
 
 }  // namespace s360
@@ -519,6 +557,15 @@ __global__ __launch_bounds__(S360_BLOCK) void k_render(KParams kp, const S360Vie
 using namespace s360;
 
 static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// Kernels that ask for more than 64 KiB of dynamic LDS need the attribute once per device.
+static void ensure_func_attributes() {
+    static bool done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || done[dev]) return;
+    (void)hipFuncSetAttribute((const void*)k_sort_tiles<16384, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    done[dev] = true;
+}
 
 extern "C" int s360_layout(const S360Params* prm, S360Layout* out) {
     if (!prm || !out) return S360_E_BADARG;
@@ -610,10 +657,7 @@ extern "C" int s360_forward(const S360Params* prm, const S360View* views, const 
         const size_t hist_bytes = (size_t)nt * 4;
         const int lds_hist = hist_bytes <= 48 * 1024 ? 1 : 0;
         if (shs) {
-            size_t lds = (size_t)S360_BLOCK * kp.M * 3 * 4;
-            if (lds > 160 * 1024 - (lds_hist ? hist_bytes : 0)) return S360_E_UNSUPPORTED;
-            lds += lds_hist ? hist_bytes : 0;
-            (void)hipFuncSetAttribute((const void*)k_preprocess<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            const size_t lds = lds_hist ? hist_bytes : 0;
             hipLaunchKernelGGL(k_preprocess<true>, dim3(nblk), dim3(S360_BLOCK), lds, st, kp, views, means3D, cov6,
                                opacities, shs, colors_precomp, radii, tiles_touched, recA, recB, recC, clamped, tile_count,
                                lds_hist);
@@ -633,7 +677,7 @@ extern "C" int s360_forward(const S360Params* prm, const S360View* views, const 
     }
     {
         ProfScope ps(PS_TILE_SCAN, st);
-        hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(S360_BLOCK), 0, st, tile_count, tile_start, tile_cursor, nt, kp.cap, header);
+        hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(S360_BLOCK), 0, st, tile_count, tile_start, tile_cursor, tile_max_contrib, nt, kp.cap, header);
     }
     S360_CHECK_LAUNCH();
     if (kp.P > 0) {
@@ -649,17 +693,17 @@ extern "C" int s360_forward(const S360Params* prm, const S360View* views, const 
         }
         S360_CHECK_LAUNCH();
         ProfScope ps(PS_SORT, st);
-        (void)hipFuncSetAttribute((const void*)k_sort_tiles<16384, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL((k_sort_tiles<1024, 256>), dim3(nt), dim3(256), 1024 * 8, st, tile_start, keys, list, 0u, kp.cap);
-        hipLaunchKernelGGL((k_sort_tiles<4096, 512>), dim3(nt), dim3(512), 4096 * 8, st, tile_start, keys, list, 1024u, kp.cap);
-        hipLaunchKernelGGL((k_sort_tiles<16384, 1024>), dim3(nt), dim3(1024), 16384 * 8, st, tile_start, keys, list, 4096u, kp.cap);
+        ensure_func_attributes();
+        hipLaunchKernelGGL((k_sort_tiles<1024, 256>), dim3(nt), dim3(256), 1024 * 8, st, tile_start, keys, list, 0u, kp.cap, tile_cursor);
+        hipLaunchKernelGGL((k_sort_tiles<4096, 512>), dim3(nt), dim3(512), 4096 * 8, st, tile_start, keys, list, 1024u, kp.cap, tile_cursor);
+        hipLaunchKernelGGL((k_sort_tiles<16384, 1024>), dim3(nt), dim3(1024), 16384 * 8, st, tile_start, keys, list, 4096u, kp.cap, tile_cursor);
         hipLaunchKernelGGL(k_sort_tiles_global, dim3(nt), dim3(S360_BLOCK), 0, st, tile_start, keys, list, 16384u, kp.cap);
         S360_CHECK_LAUNCH();
     }
     {
         ProfScope ps(PS_RENDER, st);
         hipLaunchKernelGGL(k_render, dim3(nt), dim3(S360_BLOCK), 0, st, kp, views, tile_start, list, recA, recB, recC, images,
-                           final_T, n_contrib, tile_max_contrib);
+                           final_T, n_contrib, tile_max_contrib, (uint32_t*)keys);
     }
     S360_CHECK_LAUNCH();
     return S360_OK;

@@ -5,7 +5,7 @@ Drop-in layer (same names, argument meaning and error behaviour as the reference
     render_cuda, render_depth_cuda, get_projection_matrix, DecoderSplattingCUDA
 Fused layer (what the MI355X design adds — one rasteriser call per panorama instead of six
 Python-looped calls, shared per-Gaussian loads and SH evaluation, no host synchronisation):
-    render_cube_faces, render_cube_depth
+    cube_cameras, pack_camera_views, render_views_fused, render_cube_faces
 """
 from __future__ import annotations
 
@@ -105,34 +105,55 @@ def render_depth_cuda(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far:
 
 
 # ----------------------------------------------------------------------------- fused path
-def cube_views(pano_c2w: Tensor, near: Tensor, far: Tensor, background: Tensor):
-    """[4,4] panorama pose (+ scalar near/far tensors, [3] background) -> views[6,44]: the six
-    face cameras of cameras.cube_face_extrinsics with the reference's scale-invariant rescale
-    (camera side here, cloud side inside the kernels), packed for one V=6 rasteriser call.
-    Pure device math, no sync."""
+def cube_cameras(pano_c2w: Tensor, near, far):
+    """[4,4] panorama pose -> (extrinsics[6,4,4], intrinsics[6,3,3], near[6], far[6]) of its six
+    face cameras — what the reference's dataset hands the decoder for one target panorama
+    (dataset_hm3d.py:280-314, "extrinsics_cubes" / "intrinsics_cubes" / "near_cubes")."""
+    dev = pano_c2w.device
     ext = cameras.cube_face_extrinsics(pano_c2w[None])[0]
-    k = cameras.cube_face_intrinsics(1, device=pano_c2w.device)[0]
-    vs = cameras.view_setup(ext, k, near.reshape(1).expand(6), far.reshape(1).expand(6), True)
-    views = rasterizer.pack_views(vs["view_matrix"], vs["full_projection"], vs["campos"], vs["tan_fov_x"],
-                                  vs["tan_fov_y"], background, scale=vs["scale"])
-    return views
+    k = cameras.cube_face_intrinsics(1, device=dev)[0]
+    n = torch.as_tensor(near, dtype=torch.float32, device=dev).reshape(-1).expand(6)
+    f = torch.as_tensor(far, dtype=torch.float32, device=dev).reshape(-1).expand(6)
+    return ext, k, n, f
+
+
+def pack_camera_views(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, background: Tensor,
+                      scale_invariant: bool = True) -> Tensor:
+    """V cameras (extrinsics[V,4,4] c2w, normalised intrinsics[V,3,3], near/far[V], background [3] or
+    [V,3]) -> views[V,44] for one rasteriser call: the camera half of render_cuda
+    (cuda_splatting.py:64-71,80-87) for all V views at once; the cloud half of the scale-invariant
+    rescale happens inside the kernels (S360View.scale).  Device math only, no host sync."""
+    vs = cameras.view_setup(extrinsics, intrinsics, near, far, scale_invariant)
+    return rasterizer.pack_views(vs["view_matrix"], vs["full_projection"], vs["campos"], vs["tan_fov_x"],
+                                 vs["tan_fov_y"], background, scale=vs["scale"])
+
+
+def render_views_fused(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, image_shape: tuple,
+                       background: Tensor, gaussian_means: Tensor, gaussian_covariances: Tensor,
+                       gaussian_sh_coefficients: Tensor, gaussian_opacities: Tensor, *, shared_campos: bool = True,
+                       max_instances: Optional[int] = None, check: str = "sync") -> Tensor:
+    """V <= 8 views of ONE cloud in one fused rasteriser call: means[G,3], covariances[G,3,3],
+    harmonics[G,3,d_sh] (the reference's Gaussians layout, src/model/types.py:7-12, read in place),
+    opacities[G] -> [V,3,h,w].  With the six face cameras of a panorama (shared_campos=True: one camera
+    centre) this is bit-for-bit the result of six reference-style render_cuda calls."""
+    views = pack_camera_views(extrinsics, intrinsics, near, far, background)
+    n = gaussian_sh_coefficients.shape[-1]
+    h, w = image_shape
+    images, _ = rasterizer.rasterize_views(
+        gaussian_means, gaussian_covariances, gaussian_opacities, gaussian_sh_coefficients, None, views=views,
+        image_height=h, image_width=w, sh_degree=isqrt(n) - 1, shared_campos=shared_campos, want_radii=False,
+        max_instances=max_instances, check=check, cov9=True, sh_channel_major=True)
+    return images
 
 
 def render_cube_faces(pano_c2w: Tensor, near: Tensor, far: Tensor, face_w: int, background: Tensor,
                       gaussian_means: Tensor, gaussian_covariances: Tensor, gaussian_sh_coefficients: Tensor,
                       gaussian_opacities: Tensor, *, max_instances: Optional[int] = None, check: str = "sync") -> Tensor:
-    """One panorama of ONE cloud: means[G,3], covariances[G,3,3], harmonics[G,3,d_sh] (the
-    reference's Gaussians layout, src/model/types.py:7-12), opacities[G] -> faces[6,3,fw,fw] in the
-    reference's rendered order (top, front, left, back, right, bottom).  Bit-for-bit the result of
-    six render_cuda calls (same boundary tensors), in one fused launch sequence."""
-    views = cube_views(pano_c2w, near, far, background)
-    n = gaussian_sh_coefficients.shape[-1]
-    # zero-copy: the kernels read the reference's own layouts and apply the 1/near rescale in-register
-    faces, _ = rasterizer.rasterize_views(
-        gaussian_means, gaussian_covariances, gaussian_opacities, gaussian_sh_coefficients, None, views=views,
-        image_height=face_w, image_width=face_w, sh_degree=isqrt(n) - 1, shared_campos=True, want_radii=False,
-        max_instances=max_instances, check=check, cov9=True, sh_channel_major=True)
-    return faces
+    """Convenience: panorama pose -> faces[6,3,fw,fw] in the reference's rendered order (top, front,
+    left, back, right, bottom)."""
+    ext, k, n, f = cube_cameras(pano_c2w, near, far)
+    return render_views_fused(ext, k, n, f, (face_w, face_w), background, gaussian_means, gaussian_covariances,
+                              gaussian_sh_coefficients, gaussian_opacities, max_instances=max_instances, check=check)
 
 
 @dataclass
