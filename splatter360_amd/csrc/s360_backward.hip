@@ -14,32 +14,56 @@
 #include "s360_device.h"
 #include "s360_prof.h"
 
+#include <cstdlib>
+
 namespace s360 {
 
-constexpr int BWD_BATCH = 128;
-constexpr int GREC = 12;  // floats per instance record: gx gy gA gB | gC gop gr gg | gb - - -
+constexpr int GREC = 12;  // floats per partial record: gx gy gA gB | gC gop gr gg | gb - - -
 
-__global__ __launch_bounds__(S360_BLOCK) void k_zero_inst(float4* __restrict__ inst_grad, const uint32_t* __restrict__ header,
-                                                         uint32_t cap) {
-    const size_t n4 = (size_t)min(header[0], cap) * (GREC / 4);
-    for (size_t i = (size_t)blockIdx.x * S360_BLOCK + threadIdx.x; i < n4; i += (size_t)gridDim.x * S360_BLOCK)
-        inst_grad[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+// valid[instance*4 + strip] = 1 when that strip's wave wrote a partial record for the instance
+__global__ __launch_bounds__(S360_BLOCK) void k_zero_valid(uint32_t* __restrict__ valid_words, const uint32_t* __restrict__ header,
+                                                          uint32_t cap) {
+    const size_t n = (size_t)min(header[0], cap);  // one 32-bit word (4 strip flags) per instance
+    for (size_t i = (size_t)blockIdx.x * S360_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * S360_BLOCK) valid_words[i] = 0u;
 }
 
+// Single workgroup: order[] = tile ids sorted by descending work estimate (LDS bitonic on
+// (weight << 32 | tile)).  Workgroups are dispatched in index order, round-robin over the CUs, so
+// dealing the tiles heavy-first gives every CU a similar mix (LPT-style static balancing).
+__global__ __launch_bounds__(1024) void k_order_tiles(const uint32_t* __restrict__ weight, uint32_t* __restrict__ order, int nt) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds_o[];
+    uint32_t npad = 1;
+    while (npad < (uint32_t)nt) npad <<= 1;
+    for (uint32_t i = threadIdx.x; i < npad; i += 1024)
+        lds_o[i] = i < (uint32_t)nt ? (((uint64_t)(~weight[i]) << 32) | i) : ~0ull;  // ~weight: descending
+    __syncthreads();
+    for (uint32_t k = 2; k <= npad; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = threadIdx.x; t < (npad >> 1); t += 1024) {
+                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+                const uint64_t a = lds_o[i], c = lds_o[l];
+                if ((a > c) == ((i & k) == 0)) {
+                    lds_o[i] = c;
+                    lds_o[l] = a;
+                }
+            }
+            __syncthreads();
+        }
+    for (uint32_t i = threadIdx.x; i < (uint32_t)nt; i += 1024) order[i] = (uint32_t)lds_o[i];
+}
+
+// Wave-autonomous like the forward composite: wave w replays strip w of the tile back to front from
+// final_T / n_contrib, 64 list entries at a time with lane l holding entry (hi - l) in registers.
+// Per surviving entry the 9 raster gradients are reduced over the strip's 64 pixels with DPP adds and
+// lane 63 stores ONE partial record for (instance, strip); k_preprocess_bwd adds the (up to four)
+// strip partials of every instance in a fixed order.  No LDS, no barriers, no float atomics.
 __global__ __launch_bounds__(S360_BLOCK) void k_render_bwd(
     KParams kp, const S360View* __restrict__ views, const uint32_t* __restrict__ tile_start,
     const uint32_t* __restrict__ list, const uint32_t* __restrict__ offsets, const float4* __restrict__ recA,
     const float4* __restrict__ recB, const float4* __restrict__ recC, const float* __restrict__ final_T,
-    const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ tile_max_contrib,
-    const float* __restrict__ dL_dimages, float4* __restrict__ inst_grad) {
-    __shared__ float4 sA[BWD_BATCH];
-    __shared__ float4 sB[BWD_BATCH];
-    __shared__ float sC[BWD_BATCH];
-    __shared__ uint32_t sInst[BWD_BATCH];
-    __shared__ float4 sAcc[4][BWD_BATCH][GREC / 4];
-    __shared__ unsigned long long sMask[BWD_BATCH / 64][4];  // [staging wave][strip]
-
-    const int t = blockIdx.x;
+    const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dimages, float4* __restrict__ part,
+    uint8_t* __restrict__ valid, const uint32_t* __restrict__ order) {
+    const int t = order ? (int)order[blockIdx.x] : (int)blockIdx.x;
     const int v = t / kp.T, rem = t - v * kp.T;
     const int ty = rem / kp.gx, tx = rem - ty * kp.gx;
     const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
@@ -47,11 +71,9 @@ __global__ __launch_bounds__(S360_BLOCK) void k_render_bwd(
     const bool inside = px < kp.W && py < kp.H;
     const float pxf = (float)px, pyf = (float)py;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float x0 = (float)(tx * 16), ys0 = (float)(ty * 16 + wave * 4);
 
     const uint32_t start = min(tile_start[t], kp.cap);
-    const uint32_t maxc = tile_max_contrib[t];  // entries [0, maxc) of this tile's list can contribute
-    if (maxc == 0) return;
-
     const size_t hw = (size_t)kp.H * kp.W;
     const size_t pix = (size_t)py * kp.W + px;
     const S360View& vw = views[v];
@@ -65,138 +87,139 @@ __global__ __launch_bounds__(S360_BLOCK) void k_render_bwd(
         dp1 = dimg[hw + pix];
         dp2 = dimg[2 * hw + pix];
     }
+    const uint32_t wave_last = wave_max_u32(last);  // entries [0, wave_last) can matter to this strip
+    if (wave_last == 0) return;
     const float bg_dot = vw.bg[0] * dp0 + vw.bg[1] * dp1 + vw.bg[2] * dp2;
     float T = T_final;
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_alpha = 0.f;
 
-    const float x0 = (float)(tx * 16), y0 = (float)(ty * 16);
-    const uint32_t wave_last = wave_max_u32(last);  // no lane of this wave needs entries >= wave_last
+    // chunk k holds list positions hi-63 .. hi (lane l <-> position hi - l), hi = wave_last-1-64k
+    const int64_t hi0 = (int64_t)wave_last - 1;
+    uint32_t p_n1 = 0, p_n2 = 0;
+    if (hi0 - lane >= 0) p_n1 = list[start + (uint32_t)(hi0 - lane)];
+    if (hi0 - 64 - lane >= 0) p_n2 = list[start + (uint32_t)(hi0 - 64 - lane)];
+    float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na, nc = na;
+    uint32_t nbase = 0;
+    if (hi0 - lane >= 0) {
+        na = recA[p_n1];
+        nb = recB[p_n1];
+        nc = recC[p_n1];
+        nbase = p_n1 == 0 ? 0u : offsets[p_n1 - 1];
+    }
+    for (int64_t hi = hi0; hi >= 0; hi -= 64) {
+        const float4 ea = na, eb = nb;
+        const float ec = nc.x, er = nc.w;
+        const int erad = __float_as_int(nc.z);
+        const uint32_t ebase = nbase;
+        const bool ev = hi - lane >= 0;
+        p_n1 = p_n2;
+        if (hi - 64 - lane >= 0) {
+            na = recA[p_n1];
+            nb = recB[p_n1];
+            nc = recC[p_n1];
+            nbase = p_n1 == 0 ? 0u : offsets[p_n1 - 1];
+        }
+        if (hi - 128 - lane >= 0) p_n2 = list[start + (uint32_t)(hi - 128 - lane)];
 
-    // batches walk the list back to front; batch element j is list entry (hi - j)
-    for (int64_t hi = (int64_t)maxc - 1; hi >= 0; hi -= BWD_BATCH) {
-        const int cnt = (int)min((int64_t)BWD_BATCH, hi + 1);
-        __syncthreads();
-        bool m0 = false, m1 = false, m2 = false, m3 = false;
-        if ((int)threadIdx.x < cnt) {
-            const uint32_t idx = (uint32_t)(hi - threadIdx.x);
-            const uint32_t p = list[start + idx];
-            const float4 c = recC[p];
-            const float4 a4 = recA[p];
-            sA[threadIdx.x] = a4;
-            sB[threadIdx.x] = recB[p];
-            sC[threadIdx.x] = c.x;
-            int minx, miny, maxx, maxy;
-            tile_rect(a4.x, a4.y, __float_as_int(c.z), kp.gx, kp.gy, minx, miny, maxx, maxy);
-            const uint32_t base = p == 0 ? 0u : offsets[p - 1];
-            sInst[threadIdx.x] = base + (uint32_t)((ty - miny) * (maxx - minx) + (tx - minx));
-            // same conservative strip test as the forward composite
-            const float r = c.w;
-            const bool xin = !(a4.x + r < x0 || a4.x - r > x0 + 15.0f);
-            m0 = xin && !(a4.y + r < y0 || a4.y - r > y0 + 3.0f);
-            m1 = xin && !(a4.y + r < y0 + 4.0f || a4.y - r > y0 + 7.0f);
-            m2 = xin && !(a4.y + r < y0 + 8.0f || a4.y - r > y0 + 11.0f);
-            m3 = xin && !(a4.y + r < y0 + 12.0f || a4.y - r > y0 + 15.0f);
-        }
-        {
-            const unsigned long long b0 = __ballot(m0), b1 = __ballot(m1), b2 = __ballot(m2), b3 = __ballot(m3);
-            if (lane == 0 && wave < BWD_BATCH / 64) {
-                sMask[wave][0] = b0;
-                sMask[wave][1] = b1;
-                sMask[wave][2] = b2;
-                sMask[wave][3] = b3;
-            }
-            float4* z = &sAcc[0][0][0];
-            for (int i = threadIdx.x; i < 4 * BWD_BATCH * (GREC / 4); i += S360_BLOCK) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        __syncthreads();
-#pragma unroll 1
-        for (int chunk = 0; chunk < BWD_BATCH / 64; ++chunk) {
-            unsigned long long m = sMask[chunk][wave];
-            m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(m >> 32)) << 32) |
-                (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m);
-            while (m) {
-                const int bit = __builtin_ctzll(m);
-                m &= m - 1;
-                const int j = chunk * 64 + bit;
-            const uint32_t contributor = (uint32_t)(hi - j);  // 0-based position in the list
-            if (contributor >= wave_last) continue;          // wave-uniform
+        const bool hit = ev && !(ea.x + er < x0 || ea.x - er > x0 + 15.0f || ea.y + er < ys0 || ea.y - er > ys0 + 3.0f);
+        unsigned long long m = __ballot(hit);
+        if (m == 0ull) continue;
+        // slot of this lane's entry: position of tile (tx,ty) inside the splat's tile rectangle,
+        // in emission order, after the splat's first instance
+        int minx, miny, maxx, maxy;
+        tile_rect(ea.x, ea.y, erad, kp.gx, kp.gy, minx, miny, maxx, maxy);
+        const uint32_t einst = ebase + (uint32_t)((ty - miny) * (maxx - minx) + (tx - minx));
+        while (m) {
+            const int bit = __builtin_ctzll(m);
+            m &= m - 1;
+            const uint32_t contributor = (uint32_t)(hi - bit);  // 0-based list position
+            const float gx_ = rl(ea.x, bit), gy_ = rl(ea.y, bit);
+            const float cA = rl(ea.z, bit), cB = rl(ea.w, bit), cC = rl(eb.x, bit), op = rl(eb.y, bit);
+            const float dx = gx_ - pxf, dy = gy_ - pyf;
+            const float power = -0.5f * (cA * dx * dx + cC * dy * dy) - cB * dx * dy;
+            const float G = __expf(power);
+            const float alpha = fminf(0.99f, op * G);
+            const bool active = contributor < last && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+            if (__ballot(active) == 0ull) continue;  // wave-uniform: nothing to reduce
             float g_x = 0.f, g_y = 0.f, g_A = 0.f, g_B = 0.f, g_C = 0.f, g_op = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f;
-            bool active = false;
-            if (contributor < last) {
-                const float4 a = sA[j];
-                const float4 bb = sB[j];
-                const float dx = a.x - pxf, dy = a.y - pyf;
-                const float power = -0.5f * (a.z * dx * dx + bb.x * dy * dy) - a.w * dx * dy;
-                if (power <= 0.0f) {
-                    const float G = __expf(power);
-                    const float alpha = fminf(0.99f, bb.y * G);
-                    if (alpha >= 1.0f / 255.0f) {
-                        active = true;
-                        T = T / (1.0f - alpha);
-                        const float dchannel_dcolor = alpha * T;
-                        const float c0 = bb.z, c1 = bb.w, c2 = sC[j];
-                        acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
-                        acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
-                        acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2;
-                        lc0 = c0; lc1 = c1; lc2 = c2;
-                        float dL_dalpha = (c0 - acc0) * dp0 + (c1 - acc1) * dp1 + (c2 - acc2) * dp2;
-                        g_r = dchannel_dcolor * dp0;
-                        g_g = dchannel_dcolor * dp1;
-                        g_b = dchannel_dcolor * dp2;
-                        dL_dalpha *= T;
-                        last_alpha = alpha;
-                        dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
-                        const float dL_dG = bb.y * dL_dalpha;
-                        const float gdx = G * dx, gdy = G * dy;
-                        const float dG_ddelx = -gdx * a.z - gdy * a.w;
-                        const float dG_ddely = -gdy * bb.x - gdx * a.w;
-                        g_x = dL_dG * dG_ddelx;
-                        g_y = dL_dG * dG_ddely;
-                        g_A = -0.5f * gdx * dx * dL_dG;
-                        g_B = -gdx * dy * dL_dG;
-                        g_C = -0.5f * gdy * dy * dL_dG;
-                        g_op = G * dL_dalpha;
-                    }
-                }
+            if (active) {
+                // 1/(1-alpha): hardware reciprocal + one Newton step (<= 1 ulp), shared by both quotients
+                const float om = 1.0f - alpha;
+                float rcp = __builtin_amdgcn_rcpf(om);
+                rcp = __builtin_fmaf(__builtin_fmaf(-om, rcp, 1.0f), rcp, rcp);
+                T = T * rcp;
+                const float dchannel_dcolor = alpha * T;
+                const float c0 = rl(eb.z, bit), c1 = rl(eb.w, bit), c2 = rl(ec, bit);
+                acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
+                acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
+                acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2;
+                lc0 = c0; lc1 = c1; lc2 = c2;
+                float dL_dalpha = (c0 - acc0) * dp0 + (c1 - acc1) * dp1 + (c2 - acc2) * dp2;
+                g_r = dchannel_dcolor * dp0;
+                g_g = dchannel_dcolor * dp1;
+                g_b = dchannel_dcolor * dp2;
+                dL_dalpha *= T;
+                last_alpha = alpha;
+                dL_dalpha += (-T_final * rcp) * bg_dot;
+                const float dL_dG = op * dL_dalpha;
+                const float gdx = G * dx, gdy = G * dy;
+                const float dG_ddelx = -gdx * cA - gdy * cB;
+                const float dG_ddely = -gdy * cC - gdx * cB;
+                g_x = dL_dG * dG_ddelx;
+                g_y = dL_dG * dG_ddely;
+                g_A = -0.5f * gdx * dx * dL_dG;
+                g_B = -gdx * dy * dL_dG;
+                g_C = -0.5f * gdy * dy * dL_dG;
+                g_op = G * dL_dalpha;
             }
-            if (__ballot(active) == 0ull) continue;  // wave-uniform skip: nothing to reduce
-            g_x = wave_sum_lane63(g_x);
-            g_y = wave_sum_lane63(g_y);
-            g_A = wave_sum_lane63(g_A);
-            g_B = wave_sum_lane63(g_B);
-            g_C = wave_sum_lane63(g_C);
-            g_op = wave_sum_lane63(g_op);
-            g_r = wave_sum_lane63(g_r);
-            g_g = wave_sum_lane63(g_g);
-            g_b = wave_sum_lane63(g_b);
-            if (lane == 63) {
-                sAcc[wave][j][0] = make_float4(g_x, g_y, g_A, g_B);
-                sAcc[wave][j][1] = make_float4(g_C, g_op, g_r, g_g);
-                sAcc[wave][j][2] = make_float4(g_b, 0.f, 0.f, 0.f);
+            wave_sum9_lane63(g_x, g_y, g_A, g_B, g_C, g_op, g_r, g_g, g_b);
+            const uint32_t inst = (uint32_t)__builtin_amdgcn_readlane((int)einst, bit);
+            if (lane == 63 && inst < kp.cap) {
+                float4* o = part + ((size_t)inst * 4 + wave) * (GREC / 4);
+                o[0] = make_float4(g_x, g_y, g_A, g_B);
+                o[1] = make_float4(g_C, g_op, g_r, g_g);
+                o[2] = make_float4(g_b, 0.f, 0.f, 0.f);
+                valid[(size_t)inst * 4 + wave] = 1;
             }
-            }
-        }
-        __syncthreads();
-        // 4 waves -> one record per instance; thread (j, q) handles quarter-record q of entry j
-        for (int w = threadIdx.x; w < cnt * (GREC / 4); w += S360_BLOCK) {
-            const int j = w / (GREC / 4), q = w - j * (GREC / 4);
-            const float4 s0 = sAcc[0][j][q], s1 = sAcc[1][j][q], s2 = sAcc[2][j][q], s3 = sAcc[3][j][q];
-            float4 r;
-            r.x = ((s0.x + s1.x) + s2.x) + s3.x;
-            r.y = ((s0.y + s1.y) + s2.y) + s3.y;
-            r.z = ((s0.z + s1.z) + s2.z) + s3.z;
-            r.w = ((s0.w + s1.w) + s2.w) + s3.w;
-            const uint32_t inst = sInst[j];
-            if (inst < kp.cap) inst_grad[(size_t)inst * (GREC / 4) + q] = r;
         }
     }
+}
+
+// One thread per (view, Gaussian) pair: adds the strip partials of all its (tile) instances in a fixed
+// order (instance ascending, strip ascending) into one 48-byte raster-gradient record per pair.
+// Light on registers => full occupancy, so the dependent offsets -> flags -> partials loads overlap
+// across waves instead of serialising inside the fat per-Gaussian kernel.
+__global__ __launch_bounds__(S360_BLOCK) void k_gather_pairs(KParams kp, const uint32_t* __restrict__ tiles_touched,
+                                                            const uint32_t* __restrict__ offsets, const float4* __restrict__ part,
+                                                            const uint32_t* __restrict__ valid_words, float4* __restrict__ pairgrad) {
+    const size_t p = (size_t)blockIdx.x * S360_BLOCK + threadIdx.x;
+    if (p >= (size_t)kp.V * kp.P) return;
+    if (tiles_touched[p] == 0) return;
+    const uint32_t i0 = p == 0 ? 0u : offsets[p - 1];
+    const uint32_t i1 = min(offsets[p], kp.cap);
+    float gx_ = 0.f, gy_ = 0.f, gA = 0.f, gB = 0.f, gC = 0.f, gop = 0.f, gr = 0.f, gg = 0.f, gb = 0.f;
+    for (uint32_t i = i0; i < i1; ++i) {
+        const uint32_t vw4 = valid_words[i];  // byte s != 0: strip s wrote a partial
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) {
+            if (!((vw4 >> (8 * sidx)) & 0xFFu)) continue;
+            const float4* r = part + ((size_t)i * 4 + sidx) * 3;
+            const float4 r0 = r[0], r1 = r[1], r2 = r[2];
+            gx_ += r0.x; gy_ += r0.y; gA += r0.z; gB += r0.w;
+            gC += r1.x; gop += r1.y; gr += r1.z; gg += r1.w;
+            gb += r2.x;
+        }
+    }
+    pairgrad[p * 3] = make_float4(gx_, gy_, gA, gB);
+    pairgrad[p * 3 + 1] = make_float4(gC, gop, gr, gg);
+    pairgrad[p * 3 + 2] = make_float4(gb, 0.f, 0.f, 0.f);
 }
 
 template <bool USE_SH>
 __global__ __launch_bounds__(S360_BLOCK) void k_preprocess_bwd(
     KParams kp, const S360View* __restrict__ views, const float* __restrict__ means, const float* __restrict__ cov6,
     const float* __restrict__ shs, const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ offsets,
-    const uint8_t* __restrict__ clamped, const float4* __restrict__ inst_grad, float* __restrict__ d_means3D,
+    const uint8_t* __restrict__ clamped, const float4* __restrict__ pairgrad, float* __restrict__ d_means3D,
     float* __restrict__ d_means2D, float* __restrict__ d_cov6, float* __restrict__ d_opac, float* __restrict__ d_shs,
     float* __restrict__ d_colors) {
     extern __shared__ __attribute__((aligned(16))) float lds_sh[];  // [256*M*3] SH slab, then [256*V*3] dRGB
@@ -255,15 +278,9 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess_bwd(
             if (tiles_touched[p] != 0) {
                 any_visible = true;
                 if (first_visible < 0) first_visible = v;
-                const uint32_t i0 = p == 0 ? 0u : offsets[p - 1];
-                const uint32_t i1 = min(offsets[p], kp.cap);
-                float gA = 0.f, gB = 0.f, gC = 0.f, gop = 0.f, gr = 0.f, gg = 0.f, gb = 0.f;
-                for (uint32_t i = i0; i < i1; ++i) {
-                    const float4 r0 = inst_grad[(size_t)i * 3], r1 = inst_grad[(size_t)i * 3 + 1], r2 = inst_grad[(size_t)i * 3 + 2];
-                    gx_ += r0.x; gy_ += r0.y; gA += r0.z; gB += r0.w;
-                    gC += r1.x; gop += r1.y; gr += r1.z; gg += r1.w;
-                    gb += r2.x;
-                }
+                const float4 r0 = pairgrad[p * 3], r1 = pairgrad[p * 3 + 1], r2 = pairgrad[p * 3 + 2];
+                gx_ = r0.x; gy_ = r0.y;
+                const float gA = r0.z, gB = r0.w, gC = r1.x, gop = r1.y, gr = r1.z, gg = r1.w, gb = r2.x;
                 dop += gop;
                 const S360View& vw = views[v];
                 const float* V = vw.viewmatrix;
@@ -496,19 +513,31 @@ extern "C" int s360_backward(const S360Params* prm, const S360View* views, const
     const float* final_T = (const float*)(ws + L.final_T);
     const uint32_t* n_contrib = (const uint32_t*)(ws + L.n_contrib);
     const uint32_t* tile_max_contrib = (const uint32_t*)(ws + L.tile_max_contrib);
-    float4* inst_grad = (float4*)bwd_workspace;
+    // backward scratch: [cap] x 4 strip partial records of 48 B, then [cap] x 4 validity bytes
+    float4* part = (float4*)bwd_workspace;
+    uint32_t* valid_words = (uint32_t*)((char*)bwd_workspace + (size_t)kp.cap * 4 * GREC * 4);
 
     {
         ProfScope ps(PS_ZERO_INST, st);
-        hipLaunchKernelGGL(k_zero_inst, dim3(2048), dim3(S360_BLOCK), 0, st, inst_grad, header, kp.cap);
+        hipLaunchKernelGGL(k_zero_valid, dim3(1024), dim3(S360_BLOCK), 0, st, valid_words, header, kp.cap);
     }
+    uint32_t* order = valid_words + kp.cap;  // [nt] after the validity words
+    const bool use_order = (size_t)nt <= 8192 && !getenv("S360_NO_ORDER");
     {
     ProfScope ps(PS_RENDER_BWD, st);
-    hipLaunchKernelGGL(k_render_bwd, dim3(nt), dim3(S360_BLOCK), 0, st, kp, views, tile_start, list, offsets, recA, recB,
-                       recC, final_T, n_contrib, tile_max_contrib, dL_dimages, inst_grad);
+    if (use_order)
+        hipLaunchKernelGGL(k_order_tiles, dim3(1), dim3(1024), 8192 * 8, st, tile_max_contrib, order, nt);
+    hipLaunchKernelGGL(k_render_bwd, dim3(nt), dim3(S360_BLOCK), getenv("S360_RBWD_LDS") ? (size_t)atol(getenv("S360_RBWD_LDS")) : 0, st, kp, views, tile_start, list, offsets, recA, recB,
+                       recC, final_T, n_contrib, dL_dimages, part, (uint8_t*)valid_words, use_order ? order : (const uint32_t*)nullptr);
     }
     S360_CHECK_LAUNCH();
     ProfScope ps(PS_PREPROCESS_BWD, st);
+    float4* pairgrad = (float4*)((char*)(order + nt) + 256 - ((uintptr_t)(order + nt) & 255));
+    {
+        const size_t np = (size_t)kp.V * kp.P;
+        hipLaunchKernelGGL(k_gather_pairs, dim3((unsigned)((np + S360_BLOCK - 1) / S360_BLOCK)), dim3(S360_BLOCK), 0, st, kp,
+                           tiles_touched, offsets, part, valid_words, pairgrad);
+    }
     const int nblk = (kp.P + S360_BLOCK - 1) / S360_BLOCK;
     if (shs) {
         size_t lds = d_shs ? (size_t)S360_BLOCK * kp.M * 3 * 4 : 0;
@@ -523,11 +552,11 @@ extern "C" int s360_backward(const S360Params* prm, const S360View* views, const
             }
         }
         hipLaunchKernelGGL(k_preprocess_bwd<true>, dim3(nblk), dim3(S360_BLOCK), lds, st, kp, views, means3D, cov6, shs,
-                           tiles_touched, offsets, clamped, inst_grad, d_means3D, d_means2D, d_cov6, d_opacities, d_shs,
+                           tiles_touched, offsets, clamped, pairgrad, d_means3D, d_means2D, d_cov6, d_opacities, d_shs,
                            d_colors);
     } else {
         hipLaunchKernelGGL(k_preprocess_bwd<false>, dim3(nblk), dim3(S360_BLOCK), 0, st, kp, views, means3D, cov6, shs,
-                           tiles_touched, offsets, clamped, inst_grad, d_means3D, d_means2D, d_cov6, d_opacities, d_shs,
+                           tiles_touched, offsets, clamped, pairgrad, d_means3D, d_means2D, d_cov6, d_opacities, d_shs,
                            d_colors);
     }
     S360_CHECK_LAUNCH();

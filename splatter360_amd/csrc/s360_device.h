@@ -222,6 +222,36 @@ __device__ __forceinline__ float rl(float v, int l) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 
+// Nine independent wave64 sums in one hand-scheduled block: 9 x 6 v_add_f32 with DPP source
+// modifiers (hipcc lowers update_dpp + add to v_mov_dpp + v_pk_add + moves, ~2.2x the instructions).
+// The nine chains are interleaved step by step, so between two dependent DPP ops on one register
+// there are always eight other VALU ops (the VALU-write -> DPP-read hazard needs two wait states);
+// the leading s_nop covers the producers of the inputs.  Totals end up in lane 63.
+__device__ __forceinline__ void wave_sum9_lane63(float& a, float& b, float& c, float& d, float& e, float& f,
+                                                 float& g, float& h, float& i) {
+#define S360_DPP_STEP(ctrl)                              \
+    "v_add_f32_dpp %0, %0, %0 " ctrl "\n"                \
+    "v_add_f32_dpp %1, %1, %1 " ctrl "\n"                \
+    "v_add_f32_dpp %2, %2, %2 " ctrl "\n"                \
+    "v_add_f32_dpp %3, %3, %3 " ctrl "\n"                \
+    "v_add_f32_dpp %4, %4, %4 " ctrl "\n"                \
+    "v_add_f32_dpp %5, %5, %5 " ctrl "\n"                \
+    "v_add_f32_dpp %6, %6, %6 " ctrl "\n"                \
+    "v_add_f32_dpp %7, %7, %7 " ctrl "\n"                \
+    "v_add_f32_dpp %8, %8, %8 " ctrl "\n"
+    asm volatile(
+        "s_nop 1\n"
+        S360_DPP_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+        S360_DPP_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+        S360_DPP_STEP("row_half_mirror row_mask:0xf bank_mask:0xf")
+        S360_DPP_STEP("row_mirror row_mask:0xf bank_mask:0xf")
+        S360_DPP_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+        S360_DPP_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+        "s_nop 1\n"
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(i));
+#undef S360_DPP_STEP
+}
+
 __device__ __forceinline__ float readlane63(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }

@@ -14,6 +14,8 @@
 #include "s360_device.h"
 #include "s360_prof.h"
 
+#include <cstdlib>
+
 namespace s360 {
 
 // ------------------------------------------------------------------------------ preprocess
@@ -278,6 +280,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_tile_scan(const uint32_t* __rest
         header[0] = carry;                    // num_instances ("num_rendered")
         header[1] = carry > cap ? 1u : 0u;    // overflow flag
         header[2] = lds_max;                  // longest tile list
+        for (int i = 8; i < 16; ++i) header[i] = 0;  // debug counters
     }
 }
 
@@ -476,30 +479,68 @@ __global__ __launch_bounds__(S360_BLOCK) void k_render(KParams kp, const S360Vie
 
         const bool hit = ev && !(ea.x + er < x0 || ea.x - er > x0 + 15.0f || ea.y + er < ys0 || ea.y - er > ys0 + 3.0f);
         unsigned long long m = __ballot(hit);
+#ifdef S360_DBG_COUNT
+        {
+            const unsigned long long qe = __ballot(ev);
+            if (lane == 0) atomicAdd(&dbg[3], (uint32_t)__popcll(qe));  // entries walked
+        }
+#endif
         if (m == 0ull) continue;
         const uint32_t rel = b - start;  // list position of this chunk's lane 0
         const unsigned long long act = __ballot(!done);
         if (__popcll(act) > SPARSE_PIXELS) {
+            // two list entries per iteration: their alpha evaluations are independent instruction
+            // chains (ILP for the in-order wave); the T / colour updates stay strictly sequential
             while (m) {
-                const int bit = __builtin_ctzll(m);
+                const int b0 = __builtin_ctzll(m);
                 m &= m - 1;
-                const float gx_ = rl(ea.x, bit), gy_ = rl(ea.y, bit);
-                const float cA = rl(ea.z, bit), cB = rl(ea.w, bit), cC = rl(eb.x, bit), op = rl(eb.y, bit);
-                const float dx = gx_ - pxf, dy = gy_ - pyf;
-                const float power = -0.5f * (cA * dx * dx + cC * dy * dy) - cB * dx * dy;
-                const float alpha = fminf(0.99f, op * __expf(power));
-                const bool valid = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-                if (__ballot(valid) == 0ull) continue;  // wave-uniform
-                const float test_T = T * (1.0f - alpha);
-                const bool stop = valid && test_T < 0.0001f;
-                const bool contrib = valid && !stop;
-                done = done || stop;
-                const float w = contrib ? alpha * T : 0.0f;
-                C0 += rl(eb.z, bit) * w;
-                C1 += rl(eb.w, bit) * w;
-                C2 += rl(ec, bit) * w;
-                T = contrib ? test_T : T;
-                last = contrib ? rel + (uint32_t)bit + 1u : last;
+                const bool two = m != 0ull;
+                const int b1 = two ? __builtin_ctzll(m) : b0;
+                m &= m - 1;  // no-op when m == 0
+                const float dx0 = rl(ea.x, b0) - pxf, dy0 = rl(ea.y, b0) - pyf;
+                const float dx1 = rl(ea.x, b1) - pxf, dy1 = rl(ea.y, b1) - pyf;
+                const float pw0 = -0.5f * (rl(ea.z, b0) * dx0 * dx0 + rl(eb.x, b0) * dy0 * dy0) - rl(ea.w, b0) * dx0 * dy0;
+                const float pw1 = -0.5f * (rl(ea.z, b1) * dx1 * dx1 + rl(eb.x, b1) * dy1 * dy1) - rl(ea.w, b1) * dx1 * dy1;
+                const float al0 = fminf(0.99f, rl(eb.y, b0) * __expf(pw0));
+                const float al1 = fminf(0.99f, rl(eb.y, b1) * __expf(pw1));
+                const bool v0 = !done && !(pw0 > 0.0f) && !(al0 < 1.0f / 255.0f);
+                const bool v1 = two && !done && !(pw1 > 0.0f) && !(al1 < 1.0f / 255.0f);
+#ifdef S360_DBG_COUNT
+                {
+                    const unsigned long long q0 = __ballot(v0), q1 = __ballot(v1);
+                    if (lane == 0) {
+                        atomicAdd(&dbg[0], two ? 2u : 1u);                          // entries past the cull
+                        atomicAdd(&dbg[1], (q0 ? 1u : 0u) + (q1 ? 1u : 0u));        // entries with >= 1 valid lane
+                        atomicAdd(&dbg[2], (uint32_t)(__popcll(q0) + __popcll(q1)));  // valid lanes
+                    }
+                }
+#endif
+                if (__ballot(v0 || v1) == 0ull) continue;  // wave-uniform
+                {
+                    const float test_T = T * (1.0f - al0);
+                    const bool stop = v0 && test_T < 0.0001f;
+                    const bool contrib = v0 && !stop;
+                    done = done || stop;
+                    const float w = contrib ? al0 * T : 0.0f;
+                    C0 += rl(eb.z, b0) * w;
+                    C1 += rl(eb.w, b0) * w;
+                    C2 += rl(ec, b0) * w;
+                    T = contrib ? test_T : T;
+                    last = contrib ? rel + (uint32_t)b0 + 1u : last;
+                }
+                {
+                    const bool v1b = v1 && !done;
+                    const float test_T = T * (1.0f - al1);
+                    const bool stop = v1b && test_T < 0.0001f;
+                    const bool contrib = v1b && !stop;
+                    done = done || stop;
+                    const float w = contrib ? al1 * T : 0.0f;
+                    C0 += rl(eb.z, b1) * w;
+                    C1 += rl(eb.w, b1) * w;
+                    C2 += rl(ec, b1) * w;
+                    T = contrib ? test_T : T;
+                    last = contrib ? rel + (uint32_t)b1 + 1u : last;
+                }
             }
         } else {
             unsigned long long am = act;
@@ -558,6 +599,13 @@ using namespace s360;
 
 static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
+// Experiment knob: reserving (unused) dynamic LDS caps the number of resident workgroups per CU so
+// that the tail of a launch is balanced dynamically by the dispatcher.
+static size_t occupancy_cap_lds(const char* env, size_t dflt) {
+    const char* e = getenv(env);
+    return e ? (size_t)atol(e) : dflt;
+}
+
 // Kernels that ask for more than 64 KiB of dynamic LDS need the attribute once per device.
 static void ensure_func_attributes() {
     static bool done[64] = {};
@@ -598,8 +646,9 @@ extern "C" int s360_layout(const S360Params* prm, S360Layout* out) {
     out->n_contrib = take(npix * 4);
     out->tile_max_contrib = take(nt * 4);
     out->total_bytes = o;
-    // backward scratch: per-instance raster gradients (12 floats per instance)
-    out->backward_bytes = align_up(cap * 12 * 4) + 256;
+    // backward scratch: 4 strip-partial raster-gradient records (12 floats) + 4 validity bytes per instance
+    // ... + tile order [V*T] + one gathered 48-byte record per (view, Gaussian) pair
+    out->backward_bytes = align_up(cap * 4 * 12 * 4) + align_up(cap * 4) + align_up(nt * 4) + 512 + align_up(np * 48) + 256;
     return S360_OK;
 }
 
@@ -702,8 +751,8 @@ extern "C" int s360_forward(const S360Params* prm, const S360View* views, const 
     }
     {
         ProfScope ps(PS_RENDER, st);
-        hipLaunchKernelGGL(k_render, dim3(nt), dim3(S360_BLOCK), 0, st, kp, views, tile_start, list, recA, recB, recC, images,
-                           final_T, n_contrib, tile_max_contrib, (uint32_t*)keys);
+        hipLaunchKernelGGL(k_render, dim3(nt), dim3(S360_BLOCK), occupancy_cap_lds("S360_RENDER_LDS", 0), st, kp, views, tile_start, list, recA, recB, recC, images,
+                           final_T, n_contrib, tile_max_contrib, header + 8);
     }
     S360_CHECK_LAUNCH();
     return S360_OK;

@@ -56,7 +56,7 @@ def pack_views(viewmatrix: Tensor, projmatrix: Tensor, campos: Tensor, tanfovx, 
 
 def default_capacity(p: int, v: int) -> int:
     """Initial capacity (instances = (Gaussian, tile) pairs) of the binning buffers."""
-    return int(min(2**32 - 1, max(1 << 16, 4 * p * v + (1 << 18))))
+    return int(min(2**32 - 1, max(1 << 16, (3 * p * v) // 2 + (1 << 18))))
 
 
 class RasterState:

@@ -32,7 +32,7 @@ def test_layout_is_monotone_and_aligned():
     lay = _lib.layout(prm)
     offs = [getattr(lay, n) for n, _ in _lib.S360Layout._fields_ if n not in ("total_bytes", "backward_bytes")]
     assert offs == sorted(offs) and all(o % 256 == 0 for o in offs)
-    assert lay.total_bytes >= offs[-1] + 6 * 16 * 4 and lay.backward_bytes >= 5000 * 48
+    assert lay.total_bytes >= offs[-1] + 6 * 16 * 4 and lay.backward_bytes >= 5000 * 4 * 48
     assert C.sizeof(_lib.S360Params) == 32
 
 
