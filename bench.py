@@ -103,12 +103,14 @@ def main():
     bg = torch.zeros(3, device=dev)
     gt = torch.full((6, 3, face_w, face_w), 0.5, device=dev)
     c2e = stitch.Cube2Equirec(face_w, pano_h, pano_w).to(dev)
+    cams = decoder.CameraPrefetcher(dev)
     out = {}
 
     def step():
         for p in params:
             p.grad = None
-        faces = decoder.render_views_fused(ext, K, near, far, (face_w, face_w), bg, *params, check="lazy")
+        views = cams.pack(ext, K, near, far, bg)  # camera glue of this step, overlapped on a side stream
+        faces = decoder.render_views_fused(ext, K, near, far, (face_w, face_w), bg, *params, check="lazy", views=views)
         out["erp"] = c2e.stitch_rendered(faces.detach())
         if a.mode == "fwdbwd":
             loss = ((faces - gt) ** 2).mean()

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define S360_ABI_VERSION 2
+#define S360_ABI_VERSION 3
 #define S360_MAX_VIEWS 8
 #define S360_TILE 16
 
@@ -90,8 +90,9 @@ typedef struct S360Layout {
     size_t scan_scratch;        /* uint32[...] */
     size_t rec_a;               /* float4[V*P]  x, y, conic.a, conic.b */
     size_t rec_b;               /* float4[V*P]  conic.c, opacity, r, g */
-    size_t rec_c;               /* float4[V*P]  b, depth, radius (int32 bits), conservative cull radius */
+    size_t rec_c;               /* float4[V*P]  b, radius (int32 bits), conservative cull half-extents wx, wy */
     size_t clamped;             /* uint8[V*P]   bit c set: colour channel c was clamped at 0 */
+    size_t depths;              /* float[V*P]   view-space z of visible pairs (sort key) */
     size_t tile_count;          /* uint32[V*T] */
     size_t tile_start;          /* uint32[V*T+1] exclusive scan (upstream ranges: [start[t], start[t+1])) */
     size_t tile_cursor;         /* uint32[V*T] */

@@ -22,7 +22,7 @@ S360_MAX_VIEWS = 8
 FLAG_SHARED_CAMPOS = 1
 FLAG_COV9 = 2
 FLAG_SH_CHANNEL_MAJOR = 4
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class S360Params(C.Structure):
@@ -34,7 +34,7 @@ class S360Params(C.Structure):
 class S360Layout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in (
         "total_bytes", "header", "tiles_touched", "offsets", "scan_scratch", "rec_a", "rec_b", "rec_c",
-        "clamped", "tile_count", "tile_start", "tile_cursor", "keys", "list", "final_T", "n_contrib",
+        "clamped", "depths", "tile_count", "tile_start", "tile_cursor", "keys", "list", "final_T", "n_contrib",
         "tile_max_contrib", "backward_bytes")]
 
 

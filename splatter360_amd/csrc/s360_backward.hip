@@ -14,6 +14,7 @@
 #include "s360_device.h"
 #include "s360_prof.h"
 
+#include <cstdio>
 #include <cstdlib>
 
 namespace s360 {
@@ -108,8 +109,8 @@ __global__ __launch_bounds__(S360_BLOCK) void k_render_bwd(
     }
     for (int64_t hi = hi0; hi >= 0; hi -= 64) {
         const float4 ea = na, eb = nb;
-        const float ec = nc.x, er = nc.w;
-        const int erad = __float_as_int(nc.z);
+        const float ec = nc.x, ewx = nc.z, ewy = nc.w;
+        const int erad = __float_as_int(nc.y);
         const uint32_t ebase = nbase;
         const bool ev = hi - lane >= 0;
         p_n1 = p_n2;
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_render_bwd(
         }
         if (hi - 128 - lane >= 0) p_n2 = list[start + (uint32_t)(hi - 128 - lane)];
 
-        const bool hit = ev && !(ea.x + er < x0 || ea.x - er > x0 + 15.0f || ea.y + er < ys0 || ea.y - er > ys0 + 3.0f);
+        const bool hit = ev && !(ea.x + ewx < x0 || ea.x - ewx > x0 + 15.0f || ea.y + ewy < ys0 || ea.y - ewy > ys0 + 3.0f);
         unsigned long long m = __ballot(hit);
         if (m == 0ull) continue;
         // slot of this lane's entry: position of tile (tx,ty) inside the splat's tile rectangle,
@@ -473,9 +474,13 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess_bwd(
 
 using namespace s360;
 
-#define S360_CHECK_LAUNCH()                                        \
-    do {                                                           \
-        if (hipGetLastError() != hipSuccess) return S360_E_LAUNCH; \
+#define S360_CHECK_LAUNCH()                                                                          \
+    do {                                                                                             \
+        hipError_t e_ = hipGetLastError();                                                           \
+        if (e_ != hipSuccess) {                                                                      \
+            if (getenv("S360_DEBUG")) fprintf(stderr, "s360: %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+            return S360_E_LAUNCH;                                                                    \
+        }                                                                                            \
     } while (0)
 
 extern "C" int s360_backward(const S360Params* prm, const S360View* views, const float* means3D, const float* cov6,

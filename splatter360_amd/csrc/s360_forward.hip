@@ -14,6 +14,7 @@
 #include "s360_device.h"
 #include "s360_prof.h"
 
+#include <cstdio>
 #include <cstdlib>
 
 namespace s360 {
@@ -25,7 +26,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess(
     const float* __restrict__ cov6, const float* __restrict__ opac, const float* __restrict__ shs,
     const float* __restrict__ colors, int32_t* __restrict__ radii, uint32_t* __restrict__ tiles_touched,
     float4* __restrict__ recA, float4* __restrict__ recB, float4* __restrict__ recC,
-    uint8_t* __restrict__ clamped, uint32_t* __restrict__ tile_count, int lds_hist) {
+    uint8_t* __restrict__ clamped, float* __restrict__ depths, uint32_t* __restrict__ tile_count, int lds_hist) {
     // dynamic LDS: tile histogram V*T uint32 (lds_hist).  SH coefficients are NOT staged: every lane
     // streams its own Gaussian's 300-byte slab with 16-byte loads (all bytes of every cache line are
     // consumed by the same lane within a few instructions, so HBM traffic stays 1x) — this keeps the
@@ -151,9 +152,14 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess(
                     recB[p] = make_float4(conC, op, rgb[0], rgb[1]);
                     // conservative cull radius: alpha = o*exp(power) <= o*exp(-|d|^2 / (2 lambda_max)), so
                     // outside |d| > sqrt(2 lambda_max ln(255 o)) the 1/255 test always rejects.
-                    const float l255 = __logf(255.0f * op);
-                    const float rcull = (255.0f * op > 1.0f) ? sqrtf(2.0f * fmaxf(lam1, lam2) * l255) * 1.001f + 0.01f : -1.0f;
-                    recC[p] = make_float4(rgb[2], pvz, __int_as_float(rad), rcull);
+                    // alpha = o*exp(-d^T Q d / 2) >= 1/255  <=>  d^T Q d <= 2 ln(255 o): an ellipse whose exact
+                    // axis-aligned half extents are sqrt(2 ln(255 o) * cov_xx), sqrt(2 ln(255 o) * cov_yy).
+                    const float tau2 = 2.0f * __logf(255.0f * op);
+                    const bool can = 255.0f * op > 1.0f;
+                    const float wx = can ? sqrtf(tau2 * ge.a) * 1.001f + 0.01f : -1.0f;
+                    const float wy = can ? sqrtf(tau2 * ge.c) * 1.001f + 0.01f : -1.0f;
+                    recC[p] = make_float4(rgb[2], __int_as_float(rad), wx, wy);
+                    depths[p] = pvz;
                     clamped[p] = (uint8_t)clampbits;
                     // block-local histogram in LDS; one global atomic per (block, touched tile) below
                     uint32_t* tc = (lds_hist ? hist : tile_count) + (size_t)v * kp.T;
@@ -291,7 +297,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_tile_scan(const uint32_t* __rest
 template <bool LDS_BIN>
 __global__ __launch_bounds__(S360_BLOCK) void k_emit(KParams kp, const uint32_t* __restrict__ tiles_touched,
                                                     const float4* __restrict__ recA, const float4* __restrict__ recC,
-                                                    const uint32_t* __restrict__ tile_start,
+                                                    const float* __restrict__ depths, const uint32_t* __restrict__ tile_start,
                                                     uint32_t* __restrict__ tile_cursor, uint64_t* __restrict__ keys) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_bin[];  // [T] counts/cursors, [T] bases
     const int v = blockIdx.y;
@@ -310,8 +316,8 @@ __global__ __launch_bounds__(S360_BLOCK) void k_emit(KParams kp, const uint32_t*
     if (act) {
         const float4 rc = recC[p];
         const float4 ra = recA[p];
-        tile_rect(ra.x, ra.y, __float_as_int(rc.z), kp.gx, kp.gy, minx, miny, maxx, maxy);
-        key = ((uint64_t)__float_as_uint(rc.y) << 32) | (uint64_t)(uint32_t)p;
+        tile_rect(ra.x, ra.y, __float_as_int(rc.y), kp.gx, kp.gy, minx, miny, maxx, maxy);
+        key = ((uint64_t)__float_as_uint(depths[p]) << 32) | (uint64_t)(uint32_t)p;
     }
     if (LDS_BIN) {
         for (int y = miny; y < maxy; ++y)
@@ -381,6 +387,120 @@ __global__ __launch_bounds__(THREADS) void k_sort_tiles(const uint32_t* __restri
 #ifdef S360_DBG_TIMING
     if (threadIdx.x == 0) dbg[blockIdx.x] = (uint32_t)(wall_clock64() - t_begin);
 #endif
+}
+
+// LDS radix sort of one tile's bucket: LSD, 4-bit digits over the 32 depth bits (passes whose digit is
+// constant over the tile are skipped), E contiguous keys per thread so every pass is stable.  ~6x less
+// LDS traffic than the bitonic network for the common 1-4 K lists.  The low 32 bits (pair index) only
+// matter for equal depths; if the tile contains any such tie the (rare) slow path re-sorts the full
+// 64-bit keys with the bitonic network, so the result is always the unique ascending key order.
+template <int THREADS, int E>
+__global__ __launch_bounds__(THREADS) void k_sort_tiles_radix(const uint32_t* __restrict__ tile_start, uint64_t* __restrict__ keys,
+                                                             uint32_t* __restrict__ list, uint32_t lo, uint32_t cap) {
+    constexpr int CAP = THREADS * E;
+    constexpr int WAVES = THREADS / 64;
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds_r[];  // [CAP] A, [CAP] B, then uint16 cnt[16*THREADS], scratch
+    uint64_t* bufA = lds_r;
+    uint64_t* bufB = lds_r + CAP;
+    uint16_t* cnt = reinterpret_cast<uint16_t*>(lds_r + 2 * CAP);
+    uint32_t* wsum = reinterpret_cast<uint32_t*>(cnt + 16 * THREADS);  // [WAVES + 2]
+    const uint32_t s = min(tile_start[blockIdx.x], cap), e = min(tile_start[blockIdx.x + 1], cap);
+    const uint32_t n = e - s;
+    if (n <= lo || n > (uint32_t)CAP) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // load (padding = all-ones keys) and find which depth bits vary inside the tile
+    uint32_t diff = 0;
+    const uint32_t ref_hi = (uint32_t)(keys[s] >> 32);
+    for (uint32_t i = tid; i < (uint32_t)CAP; i += THREADS) {
+        const uint64_t k = i < n ? keys[s + i] : ~0ull;
+        bufA[i] = k;
+        if (i < n) diff |= (uint32_t)(k >> 32) ^ ref_hi;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) diff |= (uint32_t)__shfl_xor((int)diff, o);
+    if (lane == 0) wsum[wave] = diff;
+    __syncthreads();
+    diff = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) diff |= wsum[w];
+    __syncthreads();
+
+    uint64_t* src = bufA;
+    uint64_t* dst = bufB;
+    for (int shift = 32; shift < 64; shift += 4) {
+        if (((diff >> (shift - 32)) & 15u) == 0u) continue;  // digit constant over the tile
+        uint64_t k[E];
+        uint64_t packed = 0;  // 16 x 4-bit counters (E <= 15)
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+            k[q] = src[tid * E + q];
+            packed += 1ull << (4 * (int)((k[q] >> shift) & 15ull));
+        }
+#pragma unroll
+        for (int b = 0; b < 16; ++b) cnt[b * THREADS + tid] = (uint16_t)((packed >> (4 * b)) & 15ull);
+        __syncthreads();
+        // exclusive scan of the 16*THREADS counters (bin-major): thread t owns entries [16t, 16t+16)
+        uint32_t v[16];
+        uint32_t tot = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            v[q] = cnt[tid * 16 + q];
+            tot += v[q];
+        }
+        uint32_t inc = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t2 = (uint32_t)__shfl_up((int)inc, o);
+            if (lane >= o) inc += t2;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t run = inc - tot;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w)
+            if (w < wave) run += wsum[w];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            cnt[tid * 16 + q] = (uint16_t)run;
+            run += v[q];
+        }
+        __syncthreads();
+        // stable scatter: a thread's keys go out in order, each to the next slot of its (digit, thread) counter
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+            const int d = (int)((k[q] >> shift) & 15ull);
+            const uint16_t pos = cnt[d * THREADS + tid];
+            cnt[d * THREADS + tid] = (uint16_t)(pos + 1);
+            dst[pos] = k[q];
+        }
+        __syncthreads();
+        uint64_t* tmp = src;
+        src = dst;
+        dst = tmp;
+    }
+    // equal depths (rare): fall back to the full 64-bit bitonic network on the padded buffer
+    int tie = 0;
+    for (uint32_t i = tid + 1; i < n; i += THREADS) tie |= (uint32_t)(src[i] >> 32) == (uint32_t)(src[i - 1] >> 32);
+    if (__syncthreads_or(tie)) {
+        for (uint32_t kk = 2; kk <= (uint32_t)CAP; kk <<= 1)
+            for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+                for (uint32_t t = tid; t < (uint32_t)(CAP >> 1); t += THREADS) {
+                    const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+                    const uint64_t a = src[i], c = src[l];
+                    if ((a > c) == ((i & kk) == 0)) {
+                        src[i] = c;
+                        src[l] = a;
+                    }
+                }
+                __syncthreads();
+            }
+    }
+    for (uint32_t i = tid; i < n; i += THREADS) {
+        const uint64_t kq = src[i];
+        keys[s + i] = kq;
+        list[s + i] = (uint32_t)kq;
+    }
 }
 
 // Fallback for tile lists that exceed the LDS capacity: the same bitonic network run by one
@@ -466,7 +586,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_render(KParams kp, const S360Vie
     for (uint32_t b = start; b < end; b += 64) {
         if (__ballot(!done) == 0ull) break;
         const float4 ea = na, eb = nb;
-        const float ec = nc.x, er = nc.w;
+        const float ec = nc.x, ewx = nc.z, ewy = nc.w;
         const bool ev = b + lane < end;
         // issue the next chunk's loads before touching this one
         p_n1 = p_n2;
@@ -477,7 +597,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_render(KParams kp, const S360Vie
         }
         if (b + 128 + lane < end) p_n2 = list[b + 128 + lane];
 
-        const bool hit = ev && !(ea.x + er < x0 || ea.x - er > x0 + 15.0f || ea.y + er < ys0 || ea.y - er > ys0 + 3.0f);
+        const bool hit = ev && !(ea.x + ewx < x0 || ea.x - ewx > x0 + 15.0f || ea.y + ewy < ys0 || ea.y - ewy > ys0 + 3.0f);
         unsigned long long m = __ballot(hit);
 #ifdef S360_DBG_COUNT
         {
@@ -606,12 +726,35 @@ static size_t occupancy_cap_lds(const char* env, size_t dflt) {
     return e ? (size_t)atol(e) : dflt;
 }
 
+// One non-blocking side stream (+ fork/join events) per device, created on first use.
+struct SideStream {
+    hipStream_t stream;
+    hipEvent_t fork, join;
+};
+static SideStream* side_stream() {
+    static SideStream ss[64];
+    static int state[64] = {};  // 0 = not created, 1 = ready, -1 = unavailable
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || getenv("S360_NO_SIDE_STREAM")) return nullptr;
+    if (state[dev] == 0) {
+        const bool ok = hipStreamCreateWithFlags(&ss[dev].stream, hipStreamNonBlocking) == hipSuccess &&
+                        hipEventCreateWithFlags(&ss[dev].fork, hipEventDisableTiming) == hipSuccess &&
+                        hipEventCreateWithFlags(&ss[dev].join, hipEventDisableTiming) == hipSuccess;
+        state[dev] = ok ? 1 : -1;
+        (void)hipGetLastError();
+    }
+    return state[dev] == 1 ? &ss[dev] : nullptr;
+}
+
 // Kernels that ask for more than 64 KiB of dynamic LDS need the attribute once per device.
 static void ensure_func_attributes() {
     static bool done[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || done[dev]) return;
-    (void)hipFuncSetAttribute((const void*)k_sort_tiles<16384, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e1 = hipFuncSetAttribute((const void*)k_sort_tiles<16384, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e2 = hipFuncSetAttribute((const void*)k_sort_tiles_radix<512, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (getenv("S360_DEBUG")) fprintf(stderr, "s360: set attr %s / %s\n", hipGetErrorString(e1), hipGetErrorString(e2));
+    (void)hipGetLastError();
     done[dev] = true;
 }
 
@@ -637,6 +780,7 @@ extern "C" int s360_layout(const S360Params* prm, S360Layout* out) {
     out->rec_b = take(np * 16);
     out->rec_c = take(np * 16);
     out->clamped = take(np);
+    out->depths = take(np * 4);
     out->tile_count = take(nt * 4);
     out->tile_start = take((nt + 1) * 4);
     out->tile_cursor = take(nt * 4);
@@ -652,9 +796,13 @@ extern "C" int s360_layout(const S360Params* prm, S360Layout* out) {
     return S360_OK;
 }
 
-#define S360_CHECK_LAUNCH()                                  \
-    do {                                                     \
-        if (hipGetLastError() != hipSuccess) return S360_E_LAUNCH; \
+#define S360_CHECK_LAUNCH()                                                                          \
+    do {                                                                                             \
+        hipError_t e_ = hipGetLastError();                                                           \
+        if (e_ != hipSuccess) {                                                                      \
+            if (getenv("S360_DEBUG")) fprintf(stderr, "s360: %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+            return S360_E_LAUNCH;                                                                    \
+        }                                                                                            \
     } while (0)
 
 extern "C" int s360_forward(const S360Params* prm, const S360View* views, const float* means3D, const float* cov6,
@@ -689,6 +837,7 @@ extern "C" int s360_forward(const S360Params* prm, const S360View* views, const 
     float4* recB = (float4*)(ws + L.rec_b);
     float4* recC = (float4*)(ws + L.rec_c);
     uint8_t* clamped = (uint8_t*)(ws + L.clamped);
+    float* depths = (float*)(ws + L.depths);
     uint32_t* tile_count = (uint32_t*)(ws + L.tile_count);
     uint32_t* tile_start = (uint32_t*)(ws + L.tile_start);
     uint32_t* tile_cursor = (uint32_t*)(ws + L.tile_cursor);
@@ -708,12 +857,12 @@ extern "C" int s360_forward(const S360Params* prm, const S360View* views, const 
         if (shs) {
             const size_t lds = lds_hist ? hist_bytes : 0;
             hipLaunchKernelGGL(k_preprocess<true>, dim3(nblk), dim3(S360_BLOCK), lds, st, kp, views, means3D, cov6,
-                               opacities, shs, colors_precomp, radii, tiles_touched, recA, recB, recC, clamped, tile_count,
+                               opacities, shs, colors_precomp, radii, tiles_touched, recA, recB, recC, clamped, depths, tile_count,
                                lds_hist);
         } else {
             hipLaunchKernelGGL(k_preprocess<false>, dim3(nblk), dim3(S360_BLOCK), lds_hist ? hist_bytes : 0, st, kp, views,
                                means3D, cov6, opacities, shs, colors_precomp, radii, tiles_touched, recA, recB, recC, clamped,
-                               tile_count, lds_hist);
+                               depths, tile_count, lds_hist);
         }
         }
         S360_CHECK_LAUNCH();
@@ -735,17 +884,29 @@ extern "C" int s360_forward(const S360Params* prm, const S360View* views, const 
         ProfScope ps(PS_EMIT, st);
         if ((size_t)kp.T * 8 <= 64 * 1024)
             hipLaunchKernelGGL(k_emit<true>, egrid, dim3(S360_BLOCK), (size_t)kp.T * 8, st, kp, tiles_touched, recA, recC,
-                               tile_start, tile_cursor, keys);
+                               depths, tile_start, tile_cursor, keys);
         else
-            hipLaunchKernelGGL(k_emit<false>, egrid, dim3(S360_BLOCK), 0, st, kp, tiles_touched, recA, recC, tile_start,
+            hipLaunchKernelGGL(k_emit<false>, egrid, dim3(S360_BLOCK), 0, st, kp, tiles_touched, recA, recC, depths, tile_start,
                                tile_cursor, keys);
         }
         S360_CHECK_LAUNCH();
         ProfScope ps(PS_SORT, st);
         ensure_func_attributes();
+        // The few very long lists (polar tiles, > 4096 entries) take ~150 us each but occupy < 100 CUs:
+        // fork them onto a side stream so they overlap with the ~1.5 K short lists on the main stream.
+        SideStream* ss = side_stream();
+        if (ss) {
+            (void)hipEventRecord(ss->fork, st);
+            (void)hipStreamWaitEvent(ss->stream, ss->fork, 0);
+            hipLaunchKernelGGL((k_sort_tiles<16384, 1024>), dim3(nt), dim3(1024), 16384 * 8, ss->stream, tile_start, keys, list, 4096u, kp.cap, tile_cursor);
+            (void)hipEventRecord(ss->join, ss->stream);
+        }
         hipLaunchKernelGGL((k_sort_tiles<1024, 256>), dim3(nt), dim3(256), 1024 * 8, st, tile_start, keys, list, 0u, kp.cap, tile_cursor);
         hipLaunchKernelGGL((k_sort_tiles<4096, 512>), dim3(nt), dim3(512), 4096 * 8, st, tile_start, keys, list, 1024u, kp.cap, tile_cursor);
-        hipLaunchKernelGGL((k_sort_tiles<16384, 1024>), dim3(nt), dim3(1024), 16384 * 8, st, tile_start, keys, list, 4096u, kp.cap, tile_cursor);
+        if (ss)
+            (void)hipStreamWaitEvent(st, ss->join, 0);
+        else
+            hipLaunchKernelGGL((k_sort_tiles<16384, 1024>), dim3(nt), dim3(1024), 16384 * 8, st, tile_start, keys, list, 4096u, kp.cap, tile_cursor);
         hipLaunchKernelGGL(k_sort_tiles_global, dim3(nt), dim3(S360_BLOCK), 0, st, tile_start, keys, list, 16384u, kp.cap);
         S360_CHECK_LAUNCH();
     }

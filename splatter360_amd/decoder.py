@@ -131,12 +131,13 @@ def pack_camera_views(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far:
 def render_views_fused(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, image_shape: tuple,
                        background: Tensor, gaussian_means: Tensor, gaussian_covariances: Tensor,
                        gaussian_sh_coefficients: Tensor, gaussian_opacities: Tensor, *, shared_campos: bool = True,
-                       max_instances: Optional[int] = None, check: str = "sync") -> Tensor:
+                       max_instances: Optional[int] = None, check: str = "sync", views: Optional[Tensor] = None) -> Tensor:
     """V <= 8 views of ONE cloud in one fused rasteriser call: means[G,3], covariances[G,3,3],
     harmonics[G,3,d_sh] (the reference's Gaussians layout, src/model/types.py:7-12, read in place),
     opacities[G] -> [V,3,h,w].  With the six face cameras of a panorama (shared_campos=True: one camera
     centre) this is bit-for-bit the result of six reference-style render_cuda calls."""
-    views = pack_camera_views(extrinsics, intrinsics, near, far, background)
+    if views is None:  # callers may pass pre-packed views (e.g. prepared on a side stream, see CameraPrefetcher)
+        views = pack_camera_views(extrinsics, intrinsics, near, far, background)
     n = gaussian_sh_coefficients.shape[-1]
     h, w = image_shape
     images, _ = rasterizer.rasterize_views(
@@ -144,6 +145,30 @@ def render_views_fused(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far
         image_height=h, image_width=w, sh_degree=isqrt(n) - 1, shared_campos=shared_campos, want_radii=False,
         max_instances=max_instances, check=check, cov9=True, sh_channel_major=True)
     return images
+
+
+class CameraPrefetcher:
+    """Packs the V camera records of the NEXT rasteriser call on a side stream.  The ~60 tiny torch
+    kernels of the camera glue (inverse, fov, projection, matmul: O(V) work, independent of the cloud)
+    then overlap with the previous call's heavy kernels instead of serialising in front of them; the
+    main stream only waits on an event.  Results are identical to pack_camera_views."""
+
+    def __init__(self, device):
+        self.stream = torch.cuda.Stream(device=device)
+        self.event = torch.cuda.Event()
+
+    def pack(self, extrinsics, intrinsics, near, far, background, inputs_ready: bool = True) -> Tensor:
+        """inputs_ready=True: the camera tensors come from the data loader / an earlier step and are
+        already materialised (the normal case: poses do not depend on the model).  Pass False when they
+        were just produced on the current stream; the side stream then waits for it (no overlap)."""
+        if not inputs_ready:
+            self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            views = pack_camera_views(extrinsics, intrinsics, near, far, background)
+            self.event.record(self.stream)
+        torch.cuda.current_stream().wait_event(self.event)
+        views.record_stream(torch.cuda.current_stream())
+        return views
 
 
 def render_cube_faces(pano_c2w: Tensor, near: Tensor, far: Tensor, face_w: int, background: Tensor,

@@ -87,6 +87,7 @@ class RasterState:
             rec_b=self._arr(l.rec_b, npair * 4, torch.float32).view(p.V, p.P, 4),
             rec_c=self._arr(l.rec_c, npair * 4, torch.float32).view(p.V, p.P, 4),
             clamped=self._arr(l.clamped, npair, torch.uint8).view(p.V, p.P),
+            depths=self._arr(l.depths, npair, torch.float32).view(p.V, p.P),
             tile_count=self._arr(l.tile_count, nt, torch.int32),
             tile_start=self._arr(l.tile_start, nt + 1, torch.int32),
             keys=self._arr(l.keys, cap, torch.int64),

@@ -48,7 +48,8 @@ def check_forward(h, f, P, H, W):
     np.testing.assert_array_equal(st["offsets"][0].astype(np.uint32), f["offsets"])
     vis = f["radii"] > 0
     np.testing.assert_array_equal(st["rec_a"][0][vis][:, :2], f["xy"][vis])          # pixel centres: bit-exact
-    np.testing.assert_array_equal(st["rec_c"][0][vis][:, 1], f["depth"][vis])         # depths: bit-exact
+    np.testing.assert_array_equal(st["depths"][0][vis], f["depth"][vis])               # depths: bit-exact
+    np.testing.assert_array_equal(st["rec_c"][0][vis][:, 1].view(np.int32), f["radii"][vis])
     np.testing.assert_array_equal(st["rec_a"][0][vis][:, 2:], f["conic_opacity"][vis][:, :2])
     np.testing.assert_array_equal(st["rec_b"][0][vis][:, 0], f["conic_opacity"][vis][:, 2])
     L = f["num_rendered"]
