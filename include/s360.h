@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define S360_ABI_VERSION 3
+#define S360_ABI_VERSION 4
 #define S360_MAX_VIEWS 8
 #define S360_TILE 16
 
@@ -88,9 +88,10 @@ typedef struct S360Layout {
     size_t tiles_touched;       /* uint32[V*P] */
     size_t offsets;             /* uint32[V*P]  inclusive scan of tiles_touched (upstream point_offsets) */
     size_t scan_scratch;        /* uint32[...] */
-    size_t rec_a;               /* float4[V*P]  x, y, conic.a, conic.b */
-    size_t rec_b;               /* float4[V*P]  conic.c, opacity, r, g */
-    size_t rec_c;               /* float4[V*P]  b, radius (int32 bits), conservative cull half-extents wx, wy */
+    /* one 48-byte record per pair, stride 48 B: rec_b / rec_c = rec_a + 16 / + 32 (one cache line per gather) */
+    size_t rec_a;               /* float4  x, y, conic.a, conic.b */
+    size_t rec_b;               /* float4  conic.c, opacity, r, g */
+    size_t rec_c;               /* float4  b, radius (int32 bits), conservative cull half-extents wx, wy */
     size_t clamped;             /* uint8[V*P]   bit c set: colour channel c was clamped at 0 */
     size_t depths;              /* float[V*P]   view-space z of visible pairs (sort key) */
     size_t tile_count;          /* uint32[V*T] */
@@ -101,6 +102,7 @@ typedef struct S360Layout {
     size_t final_T;             /* float[V*H*W] */
     size_t n_contrib;           /* uint32[V*H*W] */
     size_t tile_max_contrib;    /* uint32[V*T] */
+    size_t strip_last;          /* uint32[V*T*4] max n_contrib of each 16x4 strip */
     size_t backward_bytes;      /* size of the separate backward scratch workspace */
 } S360Layout;
 

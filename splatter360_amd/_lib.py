@@ -22,7 +22,7 @@ S360_MAX_VIEWS = 8
 FLAG_SHARED_CAMPOS = 1
 FLAG_COV9 = 2
 FLAG_SH_CHANNEL_MAJOR = 4
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class S360Params(C.Structure):
@@ -35,7 +35,7 @@ class S360Layout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in (
         "total_bytes", "header", "tiles_touched", "offsets", "scan_scratch", "rec_a", "rec_b", "rec_c",
         "clamped", "depths", "tile_count", "tile_start", "tile_cursor", "keys", "list", "final_T", "n_contrib",
-        "tile_max_contrib", "backward_bytes")]
+        "tile_max_contrib", "strip_last", "backward_bytes")]
 
 
 EXPORTS = ("s360_abi_version", "s360_error_string", "s360_layout", "s360_forward", "s360_backward",

@@ -28,29 +28,37 @@ __global__ __launch_bounds__(S360_BLOCK) void k_zero_valid(uint32_t* __restrict_
     for (size_t i = (size_t)blockIdx.x * S360_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * S360_BLOCK) valid_words[i] = 0u;
 }
 
-// Single workgroup: order[] = tile ids sorted by descending work estimate (LDS bitonic on
-// (weight << 32 | tile)).  Workgroups are dispatched in index order, round-robin over the CUs, so
-// dealing the tiles heavy-first gives every CU a similar mix (LPT-style static balancing).
-__global__ __launch_bounds__(1024) void k_order_tiles(const uint32_t* __restrict__ weight, uint32_t* __restrict__ order, int nt) {
-    extern __shared__ __attribute__((aligned(16))) uint64_t lds_o[];
-    uint32_t npad = 1;
-    while (npad < (uint32_t)nt) npad <<= 1;
-    for (uint32_t i = threadIdx.x; i < npad; i += 1024)
-        lds_o[i] = i < (uint32_t)nt ? (((uint64_t)(~weight[i]) << 32) | i) : ~0ull;  // ~weight: descending
+// Single workgroup: order[] = work-unit ids (tile*4 + strip) in descending order of their work estimate
+// (64-bucket counting sort on weight / max weight).  Units are dispatched in index order round-robin over
+// the CUs / SIMDs, so dealing them heavy-first gives every SIMD a similar mix (LPT-style balancing of
+// the sequential per-strip chains, which cannot be split).
+__global__ __launch_bounds__(1024) void k_order_units(const uint32_t* __restrict__ weight, uint32_t* __restrict__ order, int n) {
+    __shared__ uint32_t s_max;
+    __shared__ uint32_t s_cnt[64];
+    __shared__ uint32_t s_base[64];
+    if (threadIdx.x == 0) s_max = 1;
+    if (threadIdx.x < 64) s_cnt[threadIdx.x] = 0;
     __syncthreads();
-    for (uint32_t k = 2; k <= npad; k <<= 1)
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t t = threadIdx.x; t < (npad >> 1); t += 1024) {
-                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
-                const uint64_t a = lds_o[i], c = lds_o[l];
-                if ((a > c) == ((i & k) == 0)) {
-                    lds_o[i] = c;
-                    lds_o[l] = a;
-                }
-            }
-            __syncthreads();
+    uint32_t mx = 0;
+    for (int i = threadIdx.x; i < n; i += 1024) mx = max(mx, weight[i]);
+    mx = wave_max_u32(mx);
+    if ((threadIdx.x & 63) == 0) atomicMax(&s_max, mx);
+    __syncthreads();
+    const uint32_t wmax = s_max;
+    for (int i = threadIdx.x; i < n; i += 1024) atomicAdd(&s_cnt[63 - (uint32_t)(((uint64_t)weight[i] * 63) / wmax)], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int b = 0; b < 64; ++b) {
+            s_base[b] = run;
+            run += s_cnt[b];
         }
-    for (uint32_t i = threadIdx.x; i < (uint32_t)nt; i += 1024) order[i] = (uint32_t)lds_o[i];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const uint32_t b = 63 - (uint32_t)(((uint64_t)weight[i] * 63) / wmax);
+        order[atomicAdd(&s_base[b], 1u)] = (uint32_t)i;
+    }
 }
 
 // Wave-autonomous like the forward composite: wave w replays strip w of the tile back to front from
@@ -58,20 +66,20 @@ __global__ __launch_bounds__(1024) void k_order_tiles(const uint32_t* __restrict
 // Per surviving entry the 9 raster gradients are reduced over the strip's 64 pixels with DPP adds and
 // lane 63 stores ONE partial record for (instance, strip); k_preprocess_bwd adds the (up to four)
 // strip partials of every instance in a fixed order.  No LDS, no barriers, no float atomics.
-__global__ __launch_bounds__(S360_BLOCK) void k_render_bwd(
+__global__ __launch_bounds__(64) void k_render_bwd(
     KParams kp, const S360View* __restrict__ views, const uint32_t* __restrict__ tile_start,
     const uint32_t* __restrict__ list, const uint32_t* __restrict__ offsets, const float4* __restrict__ recA,
     const float4* __restrict__ recB, const float4* __restrict__ recC, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dimages, float4* __restrict__ part,
     uint8_t* __restrict__ valid, const uint32_t* __restrict__ order) {
-    const int t = order ? (int)order[blockIdx.x] : (int)blockIdx.x;
+    const uint32_t unit = order ? order[blockIdx.x] : blockIdx.x;  // tile*4 + strip
+    const int t = (int)(unit >> 2), wave = (int)(unit & 3u), lane = threadIdx.x;
     const int v = t / kp.T, rem = t - v * kp.T;
     const int ty = rem / kp.gx, tx = rem - ty * kp.gx;
-    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int lx = lane & 15, ly = wave * 4 + (lane >> 4);
     const int px = tx * 16 + lx, py = ty * 16 + ly;
     const bool inside = px < kp.W && py < kp.H;
     const float pxf = (float)px, pyf = (float)py;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float x0 = (float)(tx * 16), ys0 = (float)(ty * 16 + wave * 4);
 
     const uint32_t start = min(tile_start[t], kp.cap);
@@ -102,9 +110,9 @@ __global__ __launch_bounds__(S360_BLOCK) void k_render_bwd(
     float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na, nc = na;
     uint32_t nbase = 0;
     if (hi0 - lane >= 0) {
-        na = recA[p_n1];
-        nb = recB[p_n1];
-        nc = recC[p_n1];
+        na = recA[3 * (size_t)(p_n1)];
+        nb = recA[3 * (size_t)(p_n1) + 1];
+        nc = recA[3 * (size_t)(p_n1) + 2];
         nbase = p_n1 == 0 ? 0u : offsets[p_n1 - 1];
     }
     for (int64_t hi = hi0; hi >= 0; hi -= 64) {
@@ -115,9 +123,9 @@ __global__ __launch_bounds__(S360_BLOCK) void k_render_bwd(
         const bool ev = hi - lane >= 0;
         p_n1 = p_n2;
         if (hi - 64 - lane >= 0) {
-            na = recA[p_n1];
-            nb = recB[p_n1];
-            nc = recC[p_n1];
+            na = recA[3 * (size_t)(p_n1)];
+            nb = recA[3 * (size_t)(p_n1) + 1];
+            nc = recA[3 * (size_t)(p_n1) + 2];
             nbase = p_n1 == 0 ? 0u : offsets[p_n1 - 1];
         }
         if (hi - 128 - lane >= 0) p_n2 = list[start + (uint32_t)(hi - 128 - lane)];
@@ -517,7 +525,6 @@ extern "C" int s360_backward(const S360Params* prm, const S360View* views, const
     const uint32_t* list = (const uint32_t*)(ws + L.list);
     const float* final_T = (const float*)(ws + L.final_T);
     const uint32_t* n_contrib = (const uint32_t*)(ws + L.n_contrib);
-    const uint32_t* tile_max_contrib = (const uint32_t*)(ws + L.tile_max_contrib);
     // backward scratch: [cap] x 4 strip partial records of 48 B, then [cap] x 4 validity bytes
     float4* part = (float4*)bwd_workspace;
     uint32_t* valid_words = (uint32_t*)((char*)bwd_workspace + (size_t)kp.cap * 4 * GREC * 4);
@@ -526,18 +533,18 @@ extern "C" int s360_backward(const S360Params* prm, const S360View* views, const
         ProfScope ps(PS_ZERO_INST, st);
         hipLaunchKernelGGL(k_zero_valid, dim3(1024), dim3(S360_BLOCK), 0, st, valid_words, header, kp.cap);
     }
-    uint32_t* order = valid_words + kp.cap;  // [nt] after the validity words
-    const bool use_order = (size_t)nt <= 8192 && !getenv("S360_NO_ORDER");
+    uint32_t* order = valid_words + kp.cap;  // [nt*4] after the validity words
+    const uint32_t* strip_last = (const uint32_t*)(ws + L.strip_last);
+    const bool use_order = !getenv("S360_NO_ORDER");
     {
     ProfScope ps(PS_RENDER_BWD, st);
-    if (use_order)
-        hipLaunchKernelGGL(k_order_tiles, dim3(1), dim3(1024), 8192 * 8, st, tile_max_contrib, order, nt);
-    hipLaunchKernelGGL(k_render_bwd, dim3(nt), dim3(S360_BLOCK), getenv("S360_RBWD_LDS") ? (size_t)atol(getenv("S360_RBWD_LDS")) : 0, st, kp, views, tile_start, list, offsets, recA, recB,
+    if (use_order) hipLaunchKernelGGL(k_order_units, dim3(1), dim3(1024), 0, st, strip_last, order, nt * 4);
+    hipLaunchKernelGGL(k_render_bwd, dim3(nt * 4), dim3(64), 0, st, kp, views, tile_start, list, offsets, recA, recB,
                        recC, final_T, n_contrib, dL_dimages, part, (uint8_t*)valid_words, use_order ? order : (const uint32_t*)nullptr);
     }
     S360_CHECK_LAUNCH();
     ProfScope ps(PS_PREPROCESS_BWD, st);
-    float4* pairgrad = (float4*)((char*)(order + nt) + 256 - ((uintptr_t)(order + nt) & 255));
+    float4* pairgrad = (float4*)((char*)(order + nt * 4) + 256 - ((uintptr_t)(order + nt * 4) & 255));
     {
         const size_t np = (size_t)kp.V * kp.P;
         hipLaunchKernelGGL(k_gather_pairs, dim3((unsigned)((np + S360_BLOCK - 1) / S360_BLOCK)), dim3(S360_BLOCK), 0, st, kp,

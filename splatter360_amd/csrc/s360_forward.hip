@@ -148,8 +148,8 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess(
                     }
                     radius = rad;
                     touched = (uint32_t)area;
-                    recA[p] = make_float4(px, py, conA, conB);
-                    recB[p] = make_float4(conC, op, rgb[0], rgb[1]);
+                    recA[3 * (size_t)(p)] = make_float4(px, py, conA, conB);
+                    recA[3 * (size_t)(p) + 1] = make_float4(conC, op, rgb[0], rgb[1]);
                     // conservative cull radius: alpha = o*exp(power) <= o*exp(-|d|^2 / (2 lambda_max)), so
                     // outside |d| > sqrt(2 lambda_max ln(255 o)) the 1/255 test always rejects.
                     // alpha = o*exp(-d^T Q d / 2) >= 1/255  <=>  d^T Q d <= 2 ln(255 o): an ellipse whose exact
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess(
                     const bool can = 255.0f * op > 1.0f;
                     const float wx = can ? sqrtf(tau2 * ge.a) * 1.001f + 0.01f : -1.0f;
                     const float wy = can ? sqrtf(tau2 * ge.c) * 1.001f + 0.01f : -1.0f;
-                    recC[p] = make_float4(rgb[2], __int_as_float(rad), wx, wy);
+                    recA[3 * (size_t)(p) + 2] = make_float4(rgb[2], __int_as_float(rad), wx, wy);
                     depths[p] = pvz;
                     clamped[p] = (uint8_t)clampbits;
                     // block-local histogram in LDS; one global atomic per (block, touched tile) below
@@ -314,8 +314,8 @@ __global__ __launch_bounds__(S360_BLOCK) void k_emit(KParams kp, const uint32_t*
     int minx = 0, miny = 0, maxx = 0, maxy = 0;
     uint64_t key = 0;
     if (act) {
-        const float4 rc = recC[p];
-        const float4 ra = recA[p];
+        const float4 rc = recA[3 * (size_t)(p) + 2];
+        const float4 ra = recA[3 * (size_t)(p)];
         tile_rect(ra.x, ra.y, __float_as_int(rc.y), kp.gx, kp.gy, minx, miny, maxx, maxy);
         key = ((uint64_t)__float_as_uint(depths[p]) << 32) | (uint64_t)(uint32_t)p;
     }
@@ -554,7 +554,8 @@ __global__ __launch_bounds__(S360_BLOCK) void k_render(KParams kp, const S360Vie
                                                       const float4* __restrict__ recA, const float4* __restrict__ recB,
                                                       const float4* __restrict__ recC, float* __restrict__ images,
                                                       float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                                                      uint32_t* __restrict__ tile_max_contrib, uint32_t* __restrict__ dbg) {
+                                                      uint32_t* __restrict__ tile_max_contrib, uint32_t* __restrict__ strip_last,
+                                                      uint32_t* __restrict__ dbg) {
 #ifdef S360_DBG_TIMING
     const long long t_begin = wall_clock64();
 #endif
@@ -579,9 +580,9 @@ __global__ __launch_bounds__(S360_BLOCK) void k_render(KParams kp, const S360Vie
     if (start + 64 + lane < end) p_n2 = list[start + 64 + lane];
     float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na, nc = na;
     if (start + lane < end) {
-        na = recA[p_n1];
-        nb = recB[p_n1];
-        nc = recC[p_n1];
+        na = recA[3 * (size_t)(p_n1)];
+        nb = recA[3 * (size_t)(p_n1) + 1];
+        nc = recA[3 * (size_t)(p_n1) + 2];
     }
     for (uint32_t b = start; b < end; b += 64) {
         if (__ballot(!done) == 0ull) break;
@@ -591,9 +592,9 @@ __global__ __launch_bounds__(S360_BLOCK) void k_render(KParams kp, const S360Vie
         // issue the next chunk's loads before touching this one
         p_n1 = p_n2;
         if (b + 64 + lane < end) {
-            na = recA[p_n1];
-            nb = recB[p_n1];
-            nc = recC[p_n1];
+            na = recA[3 * (size_t)(p_n1)];
+            nb = recA[3 * (size_t)(p_n1) + 1];
+            nc = recA[3 * (size_t)(p_n1) + 2];
         }
         if (b + 128 + lane < end) p_n2 = list[b + 128 + lane];
 
@@ -704,7 +705,10 @@ __global__ __launch_bounds__(S360_BLOCK) void k_render(KParams kp, const S360Vie
         n_contrib[(size_t)v * hw + pix] = last;
     }
     const uint32_t wm = wave_max_u32(inside ? last : 0u);
-    if (lane == 0 && wm) atomicMax(&tile_max_contrib[t], wm);  // zeroed by k_tile_scan
+    if (lane == 0) {
+        strip_last[4 * t + wave] = wm;  // per-strip replay length: the backward's work estimate
+        if (wm) atomicMax(&tile_max_contrib[t], wm);  // zeroed by k_tile_scan
+    }
 #ifdef S360_DBG_TIMING
     if (lane == 0) {
         dbg[4 * t + wave] = (uint32_t)(wall_clock64() - t_begin);
@@ -776,9 +780,9 @@ extern "C" int s360_layout(const S360Params* prm, S360Layout* out) {
     out->tiles_touched = take(np * 4);
     out->offsets = take(np * 4);
     out->scan_scratch = take((np / SCAN_TILE + 2) * 4);
-    out->rec_a = take(np * 16);
-    out->rec_b = take(np * 16);
-    out->rec_c = take(np * 16);
+    out->rec_a = take(np * 48);  // one 48-byte record per pair: rec_b / rec_c are the 2nd / 3rd float4 of it
+    out->rec_b = out->rec_a + 16;
+    out->rec_c = out->rec_a + 32;
     out->clamped = take(np);
     out->depths = take(np * 4);
     out->tile_count = take(nt * 4);
@@ -789,10 +793,11 @@ extern "C" int s360_layout(const S360Params* prm, S360Layout* out) {
     out->final_T = take(npix * 4);
     out->n_contrib = take(npix * 4);
     out->tile_max_contrib = take(nt * 4);
+    out->strip_last = take(nt * 4 * 4);
     out->total_bytes = o;
     // backward scratch: 4 strip-partial raster-gradient records (12 floats) + 4 validity bytes per instance
     // ... + tile order [V*T] + one gathered 48-byte record per (view, Gaussian) pair
-    out->backward_bytes = align_up(cap * 4 * 12 * 4) + align_up(cap * 4) + align_up(nt * 4) + 512 + align_up(np * 48) + 256;
+    out->backward_bytes = align_up(cap * 4 * 12 * 4) + align_up(cap * 4) + align_up(nt * 4 * 4) + 512 + align_up(np * 48) + 256;
     return S360_OK;
 }
 
@@ -846,6 +851,7 @@ extern "C" int s360_forward(const S360Params* prm, const S360View* views, const 
     float* final_T = (float*)(ws + L.final_T);
     uint32_t* n_contrib = (uint32_t*)(ws + L.n_contrib);
     uint32_t* tile_max_contrib = (uint32_t*)(ws + L.tile_max_contrib);
+    uint32_t* strip_last = (uint32_t*)(ws + L.strip_last);
 
     if (hipMemsetAsync(tile_count, 0, (size_t)nt * 4, st) != hipSuccess) return S360_E_LAUNCH;
     if (kp.P > 0) {
@@ -913,7 +919,7 @@ extern "C" int s360_forward(const S360Params* prm, const S360View* views, const 
     {
         ProfScope ps(PS_RENDER, st);
         hipLaunchKernelGGL(k_render, dim3(nt), dim3(S360_BLOCK), occupancy_cap_lds("S360_RENDER_LDS", 0), st, kp, views, tile_start, list, recA, recB, recC, images,
-                           final_T, n_contrib, tile_max_contrib, header + 8);
+                           final_T, n_contrib, tile_max_contrib, strip_last, header + 8);
     }
     S360_CHECK_LAUNCH();
     return S360_OK;

@@ -83,9 +83,9 @@ class RasterState:
             header=self.header(),
             tiles_touched=self._arr(l.tiles_touched, npair, torch.int32).view(p.V, p.P),
             offsets=self._arr(l.offsets, npair, torch.int32).view(p.V, p.P),
-            rec_a=self._arr(l.rec_a, npair * 4, torch.float32).view(p.V, p.P, 4),
-            rec_b=self._arr(l.rec_b, npair * 4, torch.float32).view(p.V, p.P, 4),
-            rec_c=self._arr(l.rec_c, npair * 4, torch.float32).view(p.V, p.P, 4),
+            rec_a=self._arr(l.rec_a, npair * 12, torch.float32).view(p.V, p.P, 12)[..., 0:4],
+            rec_b=self._arr(l.rec_a, npair * 12, torch.float32).view(p.V, p.P, 12)[..., 4:8],
+            rec_c=self._arr(l.rec_a, npair * 12, torch.float32).view(p.V, p.P, 12)[..., 8:12],
             clamped=self._arr(l.clamped, npair, torch.uint8).view(p.V, p.P),
             depths=self._arr(l.depths, npair, torch.float32).view(p.V, p.P),
             tile_count=self._arr(l.tile_count, nt, torch.int32),

@@ -31,7 +31,8 @@ def test_layout_is_monotone_and_aligned():
     prm = _lib.S360Params(P=1000, V=6, H=64, W=64, sh_degree=4, M=25, flags=1, max_instances=5000)
     lay = _lib.layout(prm)
     offs = [getattr(lay, n) for n, _ in _lib.S360Layout._fields_ if n not in ("total_bytes", "backward_bytes")]
-    assert offs == sorted(offs) and all(o % 256 == 0 for o in offs)
+    assert offs == sorted(offs) and all(o % 16 == 0 for o in offs)
+    assert (lay.rec_b, lay.rec_c) == (lay.rec_a + 16, lay.rec_a + 32)
     assert lay.total_bytes >= offs[-1] + 6 * 16 * 4 and lay.backward_bytes >= 5000 * 4 * 48
     assert C.sizeof(_lib.S360Params) == 32
 
