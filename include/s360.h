@@ -89,8 +89,8 @@ typedef struct S360Layout {
     size_t offsets;             /* uint32[V*P]  inclusive scan of tiles_touched (upstream point_offsets) */
     size_t scan_scratch;        /* uint32[...] */
     /* one 48-byte record per pair, stride 48 B: rec_b / rec_c = rec_a + 16 / + 32 (one cache line per gather) */
-    size_t rec_a;               /* float4  x, y, conic.a, conic.b */
-    size_t rec_b;               /* float4  conic.c, opacity, r, g */
+    size_t rec_a;               /* float4  x, y, -log2(e)/2 * conic.a, -log2(e) * conic.b */
+    size_t rec_b;               /* float4  -log2(e)/2 * conic.c, opacity, r, g */
     size_t rec_c;               /* float4  b, radius (int32 bits), conservative cull half-extents wx, wy */
     size_t clamped;             /* uint8[V*P]   bit c set: colour channel c was clamped at 0 */
     size_t depths;              /* float[V*P]   view-space z of visible pairs (sort key) */

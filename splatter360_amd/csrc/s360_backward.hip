@@ -66,7 +66,7 @@ __global__ __launch_bounds__(1024) void k_order_units(const uint32_t* __restrict
 // Per surviving entry the 9 raster gradients are reduced over the strip's 64 pixels with DPP adds and
 // lane 63 stores ONE partial record for (instance, strip); k_preprocess_bwd adds the (up to four)
 // strip partials of every instance in a fixed order.  No LDS, no barriers, no float atomics.
-__global__ __launch_bounds__(64) void k_render_bwd(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_render_bwd(
     KParams kp, const S360View* __restrict__ views, const uint32_t* __restrict__ tile_start,
     const uint32_t* __restrict__ list, const uint32_t* __restrict__ offsets, const float4* __restrict__ recA,
     const float4* __restrict__ recB, const float4* __restrict__ recC, const float* __restrict__ final_T,
@@ -145,8 +145,8 @@ __global__ __launch_bounds__(64) void k_render_bwd(
             const float gx_ = rl(ea.x, bit), gy_ = rl(ea.y, bit);
             const float cA = rl(ea.z, bit), cB = rl(ea.w, bit), cC = rl(eb.x, bit), op = rl(eb.y, bit);
             const float dx = gx_ - pxf, dy = gy_ - pyf;
-            const float power = -0.5f * (cA * dx * dx + cC * dy * dy) - cB * dx * dy;
-            const float G = __expf(power);
+            const float power = power2(cA, cB, cC, dx, dy);  // log2 G; cA, cB, cC are the pre-scaled conic
+            const float G = __builtin_amdgcn_exp2f(power);
             const float alpha = fminf(0.99f, op * G);
             const bool active = contributor < last && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
             if (__ballot(active) == 0ull) continue;  // wave-uniform: nothing to reduce
@@ -172,8 +172,9 @@ __global__ __launch_bounds__(64) void k_render_bwd(
                 dL_dalpha += (-T_final * rcp) * bg_dot;
                 const float dL_dG = op * dL_dalpha;
                 const float gdx = G * dx, gdy = G * dy;
-                const float dG_ddelx = -gdx * cA - gdy * cB;
-                const float dG_ddely = -gdy * cC - gdx * cB;
+                // dG/d(delta) = -G (a dx + b dy) = ln2 * G (2 a' dx + b' dy)   (a' = -log2e/2 a, b' = -log2e b)
+                const float dG_ddelx = 0.6931471805599453f * (2.0f * gdx * cA + gdy * cB);
+                const float dG_ddely = 0.6931471805599453f * (2.0f * gdy * cC + gdx * cB);
                 g_x = dL_dG * dG_ddelx;
                 g_y = dL_dG * dG_ddely;
                 g_A = -0.5f * gdx * dx * dL_dG;
@@ -539,7 +540,16 @@ extern "C" int s360_backward(const S360Params* prm, const S360View* views, const
     {
     ProfScope ps(PS_RENDER_BWD, st);
     if (use_order) hipLaunchKernelGGL(k_order_units, dim3(1), dim3(1024), 0, st, strip_last, order, nt * 4);
-    hipLaunchKernelGGL(k_render_bwd, dim3(nt * 4), dim3(64), 0, st, kp, views, tile_start, list, offsets, recA, recB,
+    // Even spread of the single-wave work units: when all units fit on the chip at once (<= 32 per CU)
+    // reserve just enough (unused) LDS per workgroup that every CU admits exactly ceil(units / 256) of
+    // them — otherwise the dispatcher packs the first CUs to their register limit and starves the rest.
+    size_t even_lds = 0;
+    {
+        const int per_cu = (nt * 4 + 255) / 256;
+        (void)per_cu;  // measured: forcing an even spread is slower (782 vs 748 us) -> knob only
+        if (getenv("S360_RBWD_LDS")) even_lds = (size_t)atol(getenv("S360_RBWD_LDS"));
+    }
+    hipLaunchKernelGGL(k_render_bwd, dim3(nt * 4), dim3(64), even_lds, st, kp, views, tile_start, list, offsets, recA, recB,
                        recC, final_T, n_contrib, dL_dimages, part, (uint8_t*)valid_words, use_order ? order : (const uint32_t*)nullptr);
     }
     S360_CHECK_LAUNCH();

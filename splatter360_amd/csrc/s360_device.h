@@ -189,6 +189,18 @@ __device__ __forceinline__ void geo_compute(const float* V, float tanfovx, float
     g.c += 0.3f;
 }
 
+// Composite exponent.  Records hold the conic pre-scaled (a' = -log2(e)/2 * a, b' = -log2(e) * b,
+// c' = -log2(e)/2 * c) so that  log2 G = a' dx^2 + b' dx dy + c' dy^2  is three FMAs + two multiplies
+// and G = v_exp_f32(.) with no extra multiply.  Forward and backward share this function, so both
+// take identical accept / reject decisions for every (pixel, splat) pair.
+__device__ constexpr float kLog2e = 1.4426950408889634f;
+__device__ constexpr float kConicDiag = -0.5f * 1.4426950408889634f;
+__device__ constexpr float kConicOff = -1.4426950408889634f;
+__device__ __forceinline__ float power2(float a, float b, float c, float dx, float dy) {
+    const float t = __builtin_fmaf(b, dy, a * dx);
+    return __builtin_fmaf(t, dx, (c * dy) * dy);
+}
+
 // Tile rectangle of a splat (same float expression everywhere it is needed: preprocess, emit and
 // the backward instance index all recompute it from the stored centre and integer radius).
 __device__ __forceinline__ void tile_rect(float px, float py, int radius, int gx, int gy, int& minx, int& miny,

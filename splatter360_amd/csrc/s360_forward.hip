@@ -148,8 +148,9 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess(
                     }
                     radius = rad;
                     touched = (uint32_t)area;
-                    recA[3 * (size_t)(p)] = make_float4(px, py, conA, conB);
-                    recA[3 * (size_t)(p) + 1] = make_float4(conC, op, rgb[0], rgb[1]);
+                    // conic stored pre-scaled for the composite: exponent in base 2, -1/2 folded in
+                    recA[3 * (size_t)(p)] = make_float4(px, py, conA * kConicDiag, conB * kConicOff);
+                    recA[3 * (size_t)(p) + 1] = make_float4(conC * kConicDiag, op, rgb[0], rgb[1]);
                     // conservative cull radius: alpha = o*exp(power) <= o*exp(-|d|^2 / (2 lambda_max)), so
                     // outside |d| > sqrt(2 lambda_max ln(255 o)) the 1/255 test always rejects.
                     // alpha = o*exp(-d^T Q d / 2) >= 1/255  <=>  d^T Q d <= 2 ln(255 o): an ellipse whose exact
@@ -549,7 +550,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_sort_tiles_global(const uint32_t
 // A wave retires as soon as its own 64 pixels are saturated (no tile-wide barrier to wait for).
 constexpr int SPARSE_PIXELS = 12;
 
-__global__ __launch_bounds__(S360_BLOCK) void k_render(KParams kp, const S360View* __restrict__ views,
+__global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_render(KParams kp, const S360View* __restrict__ views,
                                                       const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ list,
                                                       const float4* __restrict__ recA, const float4* __restrict__ recB,
                                                       const float4* __restrict__ recC, float* __restrict__ images,
@@ -620,10 +621,10 @@ __global__ __launch_bounds__(S360_BLOCK) void k_render(KParams kp, const S360Vie
                 m &= m - 1;  // no-op when m == 0
                 const float dx0 = rl(ea.x, b0) - pxf, dy0 = rl(ea.y, b0) - pyf;
                 const float dx1 = rl(ea.x, b1) - pxf, dy1 = rl(ea.y, b1) - pyf;
-                const float pw0 = -0.5f * (rl(ea.z, b0) * dx0 * dx0 + rl(eb.x, b0) * dy0 * dy0) - rl(ea.w, b0) * dx0 * dy0;
-                const float pw1 = -0.5f * (rl(ea.z, b1) * dx1 * dx1 + rl(eb.x, b1) * dy1 * dy1) - rl(ea.w, b1) * dx1 * dy1;
-                const float al0 = fminf(0.99f, rl(eb.y, b0) * __expf(pw0));
-                const float al1 = fminf(0.99f, rl(eb.y, b1) * __expf(pw1));
+                const float pw0 = power2(rl(ea.z, b0), rl(ea.w, b0), rl(eb.x, b0), dx0, dy0);
+                const float pw1 = power2(rl(ea.z, b1), rl(ea.w, b1), rl(eb.x, b1), dx1, dy1);
+                const float al0 = fminf(0.99f, rl(eb.y, b0) * __builtin_amdgcn_exp2f(pw0));
+                const float al1 = fminf(0.99f, rl(eb.y, b1) * __builtin_amdgcn_exp2f(pw1));
                 const bool v0 = !done && !(pw0 > 0.0f) && !(al0 < 1.0f / 255.0f);
                 const bool v1 = two && !done && !(pw1 > 0.0f) && !(al1 < 1.0f / 255.0f);
 #ifdef S360_DBG_COUNT
@@ -670,8 +671,8 @@ __global__ __launch_bounds__(S360_BLOCK) void k_render(KParams kp, const S360Vie
                 am &= am - 1;
                 const float ppx = rl(pxf, pl), ppy = rl(pyf, pl);
                 const float dx = ea.x - ppx, dy = ea.y - ppy;
-                const float power = -0.5f * (ea.z * dx * dx + eb.x * dy * dy) - ea.w * dx * dy;
-                const float alpha = fminf(0.99f, eb.y * __expf(power));
+                const float power = power2(ea.z, ea.w, eb.x, dx, dy);
+                const float alpha = fminf(0.99f, eb.y * __builtin_amdgcn_exp2f(power));
                 unsigned long long vm = __ballot(hit && !(power > 0.0f) && !(alpha < 1.0f / 255.0f));
                 const bool mine = lane == pl;
                 while (vm) {

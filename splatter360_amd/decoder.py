@@ -2,7 +2,7 @@
 decoder_splatting_cuda.py) on top of the HIP rasteriser, plus the fused six-face path.
 
 Drop-in layer (same names, argument meaning and error behaviour as the reference):
-    render_cuda, render_depth_cuda, get_projection_matrix, DecoderSplattingCUDA
+    render_cuda, render_depth_cuda, render_cuda_orthographic, get_projection_matrix, DecoderSplattingCUDA
 Fused layer (what the MI355X design adds — one rasteriser call per panorama instead of six
 Python-looped calls, shared per-Gaussian loads and SH evaluation, no host synchronisation):
     cube_cameras, pack_camera_views, render_views_fused, render_cube_faces
@@ -75,6 +75,56 @@ def rasterizer_boundary(extrinsics, intrinsics, near, far, gaussian_means, gauss
                           opacities=gaussian_opacities[i, ..., None], shs=shs[i] if use_sh else None,
                           colors_precomp=None if use_sh else shs[i, :, 0, :], sh_degree=degree))
     return vs, calls
+
+
+def orthographic_setup(extrinsics: Tensor, width: Tensor, height: Tensor, near: Tensor, far: Tensor,
+                       fov_degrees: float = 0.1):
+    """Camera half of render_cuda_orthographic (cuda_splatting.py:155-179): a fake orthographic view
+    made of a tiny field of view and a camera pulled back so that `width` spans the image."""
+    dev = extrinsics.device
+    b = extrinsics.shape[0]
+    fov_x = torch.tensor(fov_degrees, device=dev).deg2rad()
+    tan_fov_x = (0.5 * fov_x).tan()
+    distance_to_near = (0.5 * width) / tan_fov_x
+    tan_fov_y = 0.5 * height / distance_to_near
+    fov_y = (2 * tan_fov_y).atan()
+    near = near + distance_to_near
+    far = far + distance_to_near
+    move_back = torch.eye(4, dtype=torch.float32, device=dev)
+    move_back[2, 3] = -distance_to_near
+    extrinsics = extrinsics @ move_back
+    proj = cameras.get_projection_matrix(near, far, fov_x.expand(b), fov_y).transpose(1, 2)
+    view = cameras._inverse_nosync(extrinsics).transpose(1, 2)
+    return dict(extrinsics=extrinsics, fov_x=fov_x, fov_y=fov_y, near=near, far=far, tan_fov_x=tan_fov_x,
+                tan_fov_y=tan_fov_y, view_matrix=view.contiguous(), full_projection=(view @ proj).contiguous())
+
+
+def render_cuda_orthographic(extrinsics: Tensor, width: Tensor, height: Tensor, near: Tensor, far: Tensor,
+                             image_shape: tuple, background_color: Tensor, gaussian_means: Tensor,
+                             gaussian_covariances: Tensor, gaussian_sh_coefficients: Tensor, gaussian_opacities: Tensor,
+                             fov_degrees: float = 0.1, use_sh: bool = True, dump: Optional[dict] = None) -> Tensor:
+    """Same contract as the reference's render_cuda_orthographic (cuda_splatting.py:130-220; used by
+    src/visualization/validation_in_3d.py:68-81 and the figure scripts).  As in the reference the
+    pull-back distance is a single value, i.e. batch size 1 (move_back[2, 3] = -distance_to_near)."""
+    h, w = image_shape
+    assert use_sh or gaussian_sh_coefficients.shape[-1] == 1
+    n = gaussian_sh_coefficients.shape[-1]
+    degree = isqrt(n) - 1
+    shs = gaussian_sh_coefficients.transpose(2, 3).contiguous()
+    o = orthographic_setup(extrinsics, width, height, near, far, fov_degrees)
+    if dump is not None:
+        for k in ("extrinsics", "fov_x", "fov_y", "near", "far"):
+            dump[k] = o[k]
+    images = []
+    for i in range(extrinsics.shape[0]):
+        views = rasterizer.pack_views(o["view_matrix"][i], o["full_projection"][i], o["extrinsics"][i, :3, 3],
+                                      o["tan_fov_x"].reshape(1), o["tan_fov_y"].reshape(-1)[i:i + 1], background_color[i])
+        img, _ = rasterizer.rasterize_views(
+            gaussian_means[i], _triu_cov6(gaussian_covariances[i]), gaussian_opacities[i, ..., None],
+            shs[i] if use_sh else None, None if use_sh else shs[i, :, 0, :], views=views, image_height=h,
+            image_width=w, sh_degree=degree, shared_campos=True, want_radii=False)
+        images.append(img[0])
+    return torch.stack(images)
 
 
 def _depth_colors(extrinsics, means, near, far, mode):

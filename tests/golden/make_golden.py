@@ -161,6 +161,17 @@ def main():
                                               torch.tensor([np.pi / 2, 1.0]), torch.tensor([np.pi / 2, 0.7])).numpy()
     cap["getfov_K"] = torch.cat([K[:1], K2]).numpy()
     cap["getfov"] = proj.get_fov(torch.cat([K[:1], K2])).numpy()
+    # orthographic fake camera (render_cuda_orthographic, batch 1)
+    dgr.CALLS.clear()
+    dump = {}
+    cs.render_cuda_orthographic(ext[1][None], torch.tensor([3.0]), torch.tensor([2.0]), near, far, (48, 64), bg, means, covs,
+                                harm, opac, dump=dump)
+    st, kw = dgr.CALLS[0]
+    for k in ("viewmatrix", "projmatrix", "campos"):
+        cap[f"ortho_{k}"] = to_np(st[k])
+    cap["ortho_tanfovx"], cap["ortho_tanfovy"] = to_np(st["tanfovx"]), to_np(st["tanfovy"])
+    for k in ("extrinsics", "fov_x", "fov_y", "near", "far"):
+        cap[f"ortho_dump_{k}"] = to_np(dump[k])
     np.savez_compressed(OUT / "boundary_render_cuda.npz", **cap)
 
     # ---- (2) Cube2Equirec: sample grid + a stitched random cube, small and bench sizes ----

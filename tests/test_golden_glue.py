@@ -50,6 +50,18 @@ def test_non_scale_invariant_and_anisotropic_fov():
     np.testing.assert_array_equal(calls[0]["means3D"].numpy(), cap["ns_means3D"])
 
 
+def test_orthographic_camera_setup():
+    cap = np.load(G / "boundary_render_cuda.npz")
+    t = lambda k: torch.from_numpy(cap[k])
+    o = decoder.orthographic_setup(t("face_c2w")[1][None], torch.tensor([3.0]), torch.tensor([2.0]), t("near"), t("far"))
+    np.testing.assert_array_equal(o["view_matrix"][0].numpy(), cap["ortho_viewmatrix"])
+    np.testing.assert_array_equal(o["full_projection"][0].numpy(), cap["ortho_projmatrix"])
+    np.testing.assert_array_equal(o["extrinsics"][0, :3, 3].numpy(), cap["ortho_campos"])
+    assert float(o["tan_fov_x"]) == float(cap["ortho_tanfovx"]) and float(o["tan_fov_y"][0]) == float(np.ravel(cap["ortho_tanfovy"])[0])
+    for k in ("extrinsics", "fov_x", "fov_y", "near", "far"):
+        np.testing.assert_array_equal(o[k].numpy(), cap[f"ortho_dump_{k}"])
+
+
 def test_get_fov_and_projection_matrix():
     cap = np.load(G / "boundary_render_cuda.npz")
     np.testing.assert_array_equal(cameras.get_fov(torch.from_numpy(cap["getfov_K"])).numpy(), cap["getfov"])

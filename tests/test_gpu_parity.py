@@ -50,8 +50,11 @@ def check_forward(h, f, P, H, W):
     np.testing.assert_array_equal(st["rec_a"][0][vis][:, :2], f["xy"][vis])          # pixel centres: bit-exact
     np.testing.assert_array_equal(st["depths"][0][vis], f["depth"][vis])               # depths: bit-exact
     np.testing.assert_array_equal(st["rec_c"][0][vis][:, 1].view(np.int32), f["radii"][vis])
-    np.testing.assert_array_equal(st["rec_a"][0][vis][:, 2:], f["conic_opacity"][vis][:, :2])
-    np.testing.assert_array_equal(st["rec_b"][0][vis][:, 0], f["conic_opacity"][vis][:, 2])
+    # conic is stored pre-scaled by one float multiply: (-log2(e)/2) a, (-log2(e)) b, (-log2(e)/2) c — still bit-exact
+    kd, ko = np.float32(-0.5 * 1.4426950408889634), np.float32(-1.4426950408889634)
+    np.testing.assert_array_equal(st["rec_a"][0][vis][:, 2], f["conic_opacity"][vis][:, 0] * kd)
+    np.testing.assert_array_equal(st["rec_a"][0][vis][:, 3], f["conic_opacity"][vis][:, 1] * ko)
+    np.testing.assert_array_equal(st["rec_b"][0][vis][:, 0], f["conic_opacity"][vis][:, 2] * kd)
     L = f["num_rendered"]
     ts = st["tile_start"].astype(np.uint32)
     # upstream-equivalent sorted (key, value) list and tile ranges
