@@ -86,8 +86,7 @@ def main():
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+    dev = torch.device("cuda", torch.cuda.current_device())  # distributed.init() pinned cuda:LOCAL_RANK
     _lib.lib()
 
     pano_h, pano_w = a.pano_h, 2 * a.pano_h

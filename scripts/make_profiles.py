@@ -1,0 +1,31 @@
+"""Condense gpurun_out/r01/* (scripts/collect_profiles.sh) into the committed profiles/ directory."""
+import collections, csv, glob, json, shutil, subprocess, sys
+from pathlib import Path
+R = Path(__file__).resolve().parent.parent
+O = R / "gpurun_out" / "r01"
+P = R / "profiles"
+P.mkdir(exist_ok=True)
+rows = list(csv.DictReader(open(O / "stats" / "bench_kernel_stats.csv")))
+with open(P / "r01_bench_kernel_stats.csv", "w") as f:
+    w = csv.writer(f)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+    for r in rows[:45]:
+        w.writerow([r["Name"].split("(")[0][:90], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
+for n in ("bench_fwdbwd.json", "bench_fwd.json", "bench_under_rocprof.json"):
+    txt = (O / n).read_text().strip().splitlines()
+    (P / ("r01_" + n)).write_text(json.dumps(json.loads(txt[-1]), indent=1) + "\n")
+subprocess.run([sys.executable, str(R / "scripts" / "make_pmc_json.py"), str(P / "pmc_latest.json"),
+                str(O / "pmc_FETCH_SIZE" / "pmc_counter_collection.csv"), str(O / "pmc_WRITE_SIZE" / "pmc_counter_collection.csv")], check=True)
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(str(O / "pmc_*" / "pmc_counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        if "s360" in k:
+            acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+with open(P / "r01_pmc_counters.csv", "w") as f:
+    w = csv.writer(f)
+    w.writerow(["kernel", "counter", "mean_per_launch", "launches"])
+    for k in sorted(acc):
+        for c in sorted(acc[k]):
+            w.writerow([k, c, round(sum(acc[k][c]) / len(acc[k][c])), len(acc[k][c])])
+print("profiles/ updated")

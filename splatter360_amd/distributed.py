@@ -24,12 +24,18 @@ def env_world():
 
 
 def init(backend: Optional[str] = None) -> tuple:
-    """Initialise torch.distributed from MASTER_ADDR/MASTER_PORT when WORLD_SIZE > 1."""
+    """Initialise torch.distributed from MASTER_ADDR/MASTER_PORT when WORLD_SIZE > 1.  On a GPU
+    machine the process is pinned to cuda:LOCAL_RANK *before* the communicator is created (RCCL binds
+    to the current device).  S360_DIST_BACKEND / S360_FORCE_DEVICE override the backend / device index
+    (used to exercise the N>1 code path with gloo on a single-GPU box)."""
     rank, local_rank, world = env_world()
+    if torch.cuda.is_available():
+        dev_index = int(os.environ.get("S360_FORCE_DEVICE", local_rank))
+        torch.cuda.set_device(dev_index)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        backend = backend or os.environ.get("S360_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
@@ -72,4 +78,7 @@ def max_over_ranks(value: float, device) -> float:
 
 def barrier():
     if dist.is_available() and dist.is_initialized():
-        dist.barrier()
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
