@@ -504,8 +504,10 @@ __global__ __launch_bounds__(THREADS) void k_sort_tiles_radix(const uint32_t* __
     }
 }
 
-// Fallback for tile lists that exceed the LDS capacity: the same bitonic network run by one
-// workgroup directly on global memory (padding handled by index guards).  Rare and slow.
+// Fallback for tile lists that exceed the LDS capacity: one workgroup sorts directly in global memory with
+// the ascending-only form of the bitonic network (first sub-step of every stage compares mirrored
+// positions), which tolerates VIRTUAL +inf padding at indices >= n: an ascending compare-exchange never
+// moves a padding key inwards, so nothing outside [0, n) is ever read or written.  Rare and slow.
 __global__ __launch_bounds__(S360_BLOCK) void k_sort_tiles_global(const uint32_t* __restrict__ tile_start, uint64_t* __restrict__ keys,
                                                                  uint32_t* __restrict__ list, uint32_t lo, uint32_t cap) {
     const uint32_t s = min(tile_start[blockIdx.x], cap), e = min(tile_start[blockIdx.x + 1], cap);
@@ -515,16 +517,29 @@ __global__ __launch_bounds__(S360_BLOCK) void k_sort_tiles_global(const uint32_t
     while (npad < n) npad <<= 1;
     uint64_t* kk = keys + s;
     for (uint32_t k = 2; k <= npad; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+        const uint32_t half = k >> 1;
+        for (uint32_t t = threadIdx.x; t < (npad >> 1); t += S360_BLOCK) {
+            const uint32_t blk = t / half, off = t - blk * half;
+            const uint32_t i = blk * k + off, l = blk * k + (k - 1 - off);
+            if (l < n) {
+                const uint64_t a = kk[i], b = kk[l];
+                if (a > b) {
+                    kk[i] = b;
+                    kk[l] = a;
+                }
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        for (uint32_t j = k >> 2; j > 0; j >>= 1) {
             for (uint32_t t = threadIdx.x; t < (npad >> 1); t += S360_BLOCK) {
-                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const uint32_t l = i | j;
-                // virtual padding = +inf keys at indices >= n
-                const uint64_t a = i < n ? kk[i] : ~0ull, b = l < n ? kk[l] : ~0ull;
-                const bool up = (i & k) == 0;
-                if ((a > b) == up) {
-                    if (i < n) kk[i] = b;
-                    if (l < n) kk[l] = a;
+                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+                if (l < n) {
+                    const uint64_t a = kk[i], b = kk[l];
+                    if (a > b) {
+                        kk[i] = b;
+                        kk[l] = a;
+                    }
                 }
             }
             __threadfence_block();
@@ -815,7 +830,7 @@ extern "C" int s360_forward(const S360Params* prm, const S360View* views, const 
                             const float* opacities, const float* shs, const float* colors_precomp, float* images,
                             int32_t* radii, void* workspace, size_t workspace_bytes, void* stream_) {
     if (!prm || !views || !images || !workspace) return S360_E_BADARG;
-    if ((shs == nullptr) == (colors_precomp == nullptr)) return S360_E_BADARG;
+    if (prm->P > 0 && (shs == nullptr) == (colors_precomp == nullptr)) return S360_E_BADARG;
     if (prm->P > 0 && (!means3D || !cov6 || !opacities)) return S360_E_BADARG;
     if (shs && (prm->M < 1 || prm->sh_degree < 0 || prm->sh_degree > 4 ||
                 (prm->sh_degree + 1) * (prm->sh_degree + 1) > prm->M))

@@ -150,6 +150,8 @@ class _RasterizeViews(torch.autograd.Function):
             prm.P, prm.V, prm.H, prm.W = p, v, int(h), int(w)
             prm.sh_degree = int(sh_degree)
             prm.M = 0 if sh is None else int(sh.shape[2] if sh_channel_major else sh.shape[1])
+            if sh is not None and p == 0:
+                prm.M = max(prm.M, (int(sh_degree) + 1) ** 2)
             prm.flags = (_lib.FLAG_SHARED_CAMPOS if (shared_campos or v == 1) else 0) | (
                 _lib.FLAG_COV9 if cov9 else 0) | (_lib.FLAG_SH_CHANNEL_MAJOR if sh_channel_major else 0)
             prm.max_instances = int(max_instances) if max_instances else default_capacity(p, v)
