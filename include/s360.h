@@ -43,6 +43,8 @@ enum {
 
 /* flags */
 #define S360_FLAG_SHARED_CAMPOS 1u    /* all V views share campos (and scale): SH->RGB evaluated once per Gaussian */
+#define S360_FLAG_FORWARD_ONLY 8u     /* inference: skip the per-pair offsets scan (only s360_backward needs it);
+                                         s360_backward returns S360_E_BADARG on a workspace rendered with this flag */
 #define S360_FLAG_COV9 2u             /* covariances given (and their gradient returned) as [P,3,3] row-major, the
                                          reference's Gaussians.covariances layout (src/model/types.py:9); only the
                                          upper triangle is read / receives gradient, exactly like the

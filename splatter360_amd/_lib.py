@@ -22,6 +22,7 @@ S360_MAX_VIEWS = 8
 FLAG_SHARED_CAMPOS = 1
 FLAG_COV9 = 2
 FLAG_SH_CHANNEL_MAJOR = 4
+FLAG_FORWARD_ONLY = 8
 ABI_VERSION = 4
 
 

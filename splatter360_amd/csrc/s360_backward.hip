@@ -499,6 +499,7 @@ extern "C" int s360_backward(const S360Params* prm, const S360View* views, const
                              void* bwd_workspace, size_t bwd_workspace_bytes, void* stream_) {
     (void)opacities;
     if (!prm || !views || !workspace || !dL_dimages || !bwd_workspace) return S360_E_BADARG;
+    if (prm->flags & S360_FLAG_FORWARD_ONLY) return S360_E_BADARG;
     if (prm->P > 0 && (shs == nullptr) == (colors_precomp == nullptr)) return S360_E_BADARG;
     if (prm->P > 0 && (!means3D || !cov6 || !d_means3D || !d_cov6 || !d_opacities)) return S360_E_BADARG;
     S360Layout L;

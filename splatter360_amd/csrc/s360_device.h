@@ -134,6 +134,23 @@ __device__ __forceinline__ void load75(const float* __restrict__ p, float* c) {
     c[72] = p[72]; c[73] = p[73]; c[74] = p[74];
 }
 
+__device__ __forceinline__ void load15(const float* __restrict__ p, float* c) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const F4U v = *reinterpret_cast<const F4U*>(p + 4 * i);
+        c[4 * i] = v.x; c[4 * i + 1] = v.y; c[4 * i + 2] = v.z; c[4 * i + 3] = v.w;
+    }
+    c[12] = p[12]; c[13] = p[13]; c[14] = p[14];
+}
+__device__ __forceinline__ void load25(const float* __restrict__ p, float* c) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const F4U v = *reinterpret_cast<const F4U*>(p + 4 * i);
+        c[4 * i] = v.x; c[4 * i + 1] = v.y; c[4 * i + 2] = v.z; c[4 * i + 3] = v.w;
+    }
+    c[24] = p[24];
+}
+
 // Upper triangle (00,01,02,11,12,22) of Gaussian g's covariance from either layout.
 __device__ __forceinline__ void load_cov6(const float* __restrict__ cov, int g, bool cov9, float* c6) {
     if (cov9) {

@@ -20,7 +20,7 @@
 namespace s360 {
 
 // ------------------------------------------------------------------------------ preprocess
-template <bool USE_SH>
+template <bool USE_SH, bool CH_MAJOR>
 __global__ __launch_bounds__(S360_BLOCK) void k_preprocess(
     KParams kp, const S360View* __restrict__ views, const float* __restrict__ means,
     const float* __restrict__ cov6, const float* __restrict__ opac, const float* __restrict__ shs,
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess(
     float c60[6];
     load_cov6(cov6, g, (kp.flags & S360_FLAG_COV9) != 0, c60);
     const float op = opac[g];
-    const bool ch_major = (kp.flags & S360_FLAG_SH_CHANNEL_MAJOR) != 0;
+    constexpr bool ch_major = CH_MAJOR;
 
     const bool shared_cam = (kp.flags & S360_FLAG_SHARED_CAMPOS) != 0;
     float rgb[3] = {0.f, 0.f, 0.f};
@@ -106,22 +106,30 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess(
                         const float* sh = shs + (size_t)g * kp.M * 3;
                         float a0 = 0.f, a1 = 0.f, a2 = 0.f;
                         // sequential (unfused) accumulation: same rounding as the CPU oracle
-                        if (kp.M == 25 && kp.deg == 4) {
-                            float c[75];
-                            load75(sh, c);
-                            if (ch_major) {
+                        if (kp.M == 25 && kp.deg == 4 && ch_major) {
+                            // one colour channel (25 contiguous floats) at a time: 3x fewer live registers
+                            float acc[3];
+#pragma unroll 1
+                            for (int ch = 0; ch < 3; ++ch) {
+                                float c[25];
+                                load25(sh + 25 * ch, c);
+                                float a = 0.f;
 #pragma unroll
-                                for (int k = 0; k < 25; ++k) {
-                                    a0 += Y[k] * c[k];
-                                    a1 += Y[k] * c[25 + k];
-                                    a2 += Y[k] * c[50 + k];
-                                }
-                            } else {
+                                for (int k = 0; k < 25; ++k) a += Y[k] * c[k];
+                                acc[ch] = a;
+                            }
+                            a0 = acc[0]; a1 = acc[1]; a2 = acc[2];
+                        } else if (kp.M == 25 && kp.deg == 4) {
+                            // interleaved [k][rgb]: five chunks of 5 coefficients x 3 channels (15 floats)
+#pragma unroll 1
+                            for (int q = 0; q < 5; ++q) {
+                                float c[15];
+                                load15(sh + 15 * q, c);
 #pragma unroll
-                                for (int k = 0; k < 25; ++k) {
-                                    a0 += Y[k] * c[k * 3 + 0];
-                                    a1 += Y[k] * c[k * 3 + 1];
-                                    a2 += Y[k] * c[k * 3 + 2];
+                                for (int k = 0; k < 5; ++k) {
+                                    a0 += Y[5 * q + k] * c[k * 3 + 0];
+                                    a1 += Y[5 * q + k] * c[k * 3 + 1];
+                                    a2 += Y[5 * q + k] * c[k * 3 + 2];
                                 }
                             }
                         } else if (ch_major) {
@@ -878,21 +886,28 @@ extern "C" int s360_forward(const S360Params* prm, const S360View* views, const 
         const int lds_hist = hist_bytes <= 48 * 1024 ? 1 : 0;
         if (shs) {
             const size_t lds = lds_hist ? hist_bytes : 0;
-            hipLaunchKernelGGL(k_preprocess<true>, dim3(nblk), dim3(S360_BLOCK), lds, st, kp, views, means3D, cov6,
-                               opacities, shs, colors_precomp, radii, tiles_touched, recA, recB, recC, clamped, depths, tile_count,
-                               lds_hist);
+            if (kp.flags & S360_FLAG_SH_CHANNEL_MAJOR)
+                hipLaunchKernelGGL((k_preprocess<true, true>), dim3(nblk), dim3(S360_BLOCK), lds, st, kp, views, means3D, cov6,
+                                   opacities, shs, colors_precomp, radii, tiles_touched, recA, recB, recC, clamped, depths,
+                                   tile_count, lds_hist);
+            else
+                hipLaunchKernelGGL((k_preprocess<true, false>), dim3(nblk), dim3(S360_BLOCK), lds, st, kp, views, means3D, cov6,
+                                   opacities, shs, colors_precomp, radii, tiles_touched, recA, recB, recC, clamped, depths,
+                                   tile_count, lds_hist);
         } else {
-            hipLaunchKernelGGL(k_preprocess<false>, dim3(nblk), dim3(S360_BLOCK), lds_hist ? hist_bytes : 0, st, kp, views,
+            hipLaunchKernelGGL((k_preprocess<false, false>), dim3(nblk), dim3(S360_BLOCK), lds_hist ? hist_bytes : 0, st, kp, views,
                                means3D, cov6, opacities, shs, colors_precomp, radii, tiles_touched, recA, recB, recC, clamped,
                                depths, tile_count, lds_hist);
         }
         }
         S360_CHECK_LAUNCH();
+        if (!(kp.flags & S360_FLAG_FORWARD_ONLY)) {  // offsets only feed the backward's instance slots
         ProfScope ps(PS_SCAN, st);
         const int sblk = (int)((np + SCAN_TILE - 1) / SCAN_TILE);
         hipLaunchKernelGGL(k_scan_block_sums, dim3(sblk), dim3(S360_BLOCK), 0, st, tiles_touched, scratch, np);
         hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(S360_BLOCK), 0, st, scratch, sblk, (uint32_t*)nullptr);
         hipLaunchKernelGGL(k_scan_final, dim3(sblk), dim3(S360_BLOCK), 0, st, tiles_touched, scratch, offsets, np);
+        }
         S360_CHECK_LAUNCH();
     }
     {

@@ -133,7 +133,7 @@ class _RasterizeViews(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, cov6, views, cfg):
-        h, w, sh_degree, shared_campos, max_instances, check, want_radii, cov9, sh_channel_major = cfg
+        h, w, sh_degree, shared_campos, max_instances, check, want_radii, cov9, sh_channel_major, keep_offsets = cfg
         if not means3D.is_cuda:
             raise RuntimeError("means3D must live on the GPU (hip device); the rasteriser has no CPU path")
         with torch.cuda.device(means3D.device):
@@ -152,8 +152,10 @@ class _RasterizeViews(torch.autograd.Function):
             prm.M = 0 if sh is None else int(sh.shape[2] if sh_channel_major else sh.shape[1])
             if sh is not None and p == 0:
                 prm.M = max(prm.M, (int(sh_degree) + 1) ** 2)
+            needs_bwd = any(ctx.needs_input_grad[:6])  # (grad mode is off inside Function.forward; this reflects apply-time)
             prm.flags = (_lib.FLAG_SHARED_CAMPOS if (shared_campos or v == 1) else 0) | (
-                _lib.FLAG_COV9 if cov9 else 0) | (_lib.FLAG_SH_CHANNEL_MAJOR if sh_channel_major else 0)
+                _lib.FLAG_COV9 if cov9 else 0) | (_lib.FLAG_SH_CHANNEL_MAJOR if sh_channel_major else 0) | (
+                0 if (needs_bwd or keep_offsets) else _lib.FLAG_FORWARD_ONLY)
             prm.max_instances = int(max_instances) if max_instances else default_capacity(p, v)
             images, radii, state = _forward_call(prm, vw, m3, c6, op, sh, col, want_radii)
             if check == "sync" and state.overflowed():
@@ -203,9 +205,11 @@ def rasterize_views(means3D: Tensor, cov6: Tensor, opacities: Tensor, shs: Optio
                     colors_precomp: Optional[Tensor] = None, *, views: Tensor, image_height: int, image_width: int,
                     sh_degree: int = 0, shared_campos: bool = False, max_instances: Optional[int] = None,
                     check: str = "sync", want_radii: bool = True, means2D: Optional[Tensor] = None,
-                    cov9: bool = False, sh_channel_major: bool = False):
+                    cov9: bool = False, sh_channel_major: bool = False, keep_offsets: bool = False):
     """Render V views ([V,44] packed, see pack_views) of one cloud.  cov9: cov6 is [P,3,3];
-    sh_channel_major: shs is [P,3,M] (the reference's Gaussians layouts, consumed without copies).  Returns (images[V,3,H,W],
+    sh_channel_major: shs is [P,3,M] (the reference's Gaussians layouts, consumed without copies).
+    When no input requires grad the per-pair offsets scan (backward-only state) is skipped unless
+    keep_offsets=True.  Returns (images[V,3,H,W],
     radii[V,P] int32).  opacities may be [P] or [P,1]; its gradient has the same shape.
     check="sync": read the overflow flag after the forward (one host sync, like upstream's own
     scan read-back) and re-run with the exact size if the binning capacity was exceeded;
@@ -214,7 +218,7 @@ def rasterize_views(means3D: Tensor, cov6: Tensor, opacities: Tensor, shs: Optio
         raise Exception("Please provide excatly one of either SHs or precomputed colors!")
     op2 = opacities.reshape(-1, 1)
     cfg = (image_height, image_width, sh_degree, shared_campos, max_instances, check, want_radii, cov9,
-           sh_channel_major)
+           sh_channel_major, keep_offsets)
     return _RasterizeViews.apply(means3D, means2D, shs, colors_precomp, op2, cov6, views, cfg)
 
 

@@ -23,7 +23,8 @@ def big(gpu):
 
 def test_binning_invariants_and_sortedness_at_1m(gpu, big):
     cloud, params, (ext, K, near, far) = big
-    faces = decoder.render_views_fused(ext, K, near, far, (256, 256), torch.zeros(3, device=gpu), *params)
+    params = [p.clone().requires_grad_(True) for p in params]   # training mode: the offsets scan is part of the state
+    faces = decoder.render_views_fused(ext, K, near, far, (256, 256), torch.zeros(3, device=gpu), *params).detach()
     st = rasterizer.last_state()
     t = st.tensors()
     L = st.num_rendered()
