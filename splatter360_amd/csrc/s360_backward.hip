@@ -182,6 +182,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
                 g_C = -0.5f * gdy * dy * dL_dG;
                 g_op = G * dL_dalpha;
             }
+#ifdef S360_PLAIN_REDUCE
             wave_sum9_lane63(g_x, g_y, g_A, g_B, g_C, g_op, g_r, g_g, g_b);
             const uint32_t inst = (uint32_t)__builtin_amdgcn_readlane((int)einst, bit);
             if (lane == 63 && inst < kp.cap) {
@@ -191,6 +192,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
                 o[2] = make_float4(g_b, 0.f, 0.f, 0.f);
                 valid[(size_t)inst * 4 + wave] = 1;
             }
+#else
+            // 8 sums through the transposing butterfly (lanes 0..7 end up with values 0,1,3,2,6,7,5,4 of
+            // the record), the ninth (g_b) through a plain DPP chain into lane 63
+            const float tot = wave_sum8_transposed(g_x, g_y, g_A, g_B, g_C, g_op, g_r, g_g);
+            g_b = wave_sum1_lane63(g_b);
+            const uint32_t inst = (uint32_t)__builtin_amdgcn_readlane((int)einst, bit);
+            if (inst < kp.cap) {
+                float* o = reinterpret_cast<float*>(part + ((size_t)inst * 4 + wave) * (GREC / 4));
+                if (lane < 8) o[lane ^ (lane >> 1)] = tot;  // Gray code: lane -> value index
+                if (lane == 63) {
+                    o[8] = g_b;
+                    valid[(size_t)inst * 4 + wave] = 1;
+                }
+            }
+#endif
         }
     }
 }

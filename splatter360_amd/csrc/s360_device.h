@@ -281,6 +281,82 @@ __device__ __forceinline__ void wave_sum9_lane63(float& a, float& b, float& c, f
 #undef S360_DPP_STEP
 }
 
+// Eight wave64 sums for the price of ~3: "transposing" butterfly.  At level k (k = 1, 2, 3) a lane and
+// its mirror partner inside the 2^k-lane group each hold two registers (X, Y); the lane whose role bit
+// t_k = bit_{k-1}(lane) ^ bit_k(lane) is 0 keeps X and adds the partner's X, the other keeps Y — so the
+// register count halves per level (8 -> 4 -> 2 -> 1) instead of every register paying all six steps.
+// Mirror partners (quad_perm [1,0,3,2] / [3,2,1,0], row_half_mirror, row_mirror) flip all lower lane bits,
+// which leaves every earlier role bit unchanged (adjacent-bit XOR), so the partial sums line up.
+// Levels 4-6 (row mirror, xor 16, xor 32) are plain adds on the single remaining register.
+// Result: EVERY lane holds the wave total of value idx = t1 + 2 t2 + 4 t3, i.e. lanes 0..7 hold values
+// 0,1,3,2,6,7,5,4.  26 VALU/LDS-crossbar ops instead of 48.
+__device__ __forceinline__ float wave_sum8_transposed(float v0, float v1, float v2, float v3, float v4, float v5,
+                                                      float v6, float v7) {
+    const unsigned long long m1 = 0x6666666666666666ull;  // lanes with bit0 != bit1
+    const unsigned long long m2 = 0x3C3C3C3C3C3C3C3Cull;  // lanes with bit1 != bit2
+    const unsigned long long m3 = 0x0FF00FF00FF00FF0ull;  // lanes with bit2 != bit3
+    float s0, s1, s2, s3, k0, k1, k2, k3, r0, r1, r2, r3;
+    asm volatile(
+        "s_nop 1\n"
+        // level 1: (v0,v1) (v2,v3) (v4,v5) (v6,v7); give = t1 ? X : Y, keep = t1 ? Y : X
+        "v_cndmask_b32_e64 %0, %13, %12, %20\n"
+        "v_cndmask_b32_e64 %4, %12, %13, %20\n"
+        "v_cndmask_b32_e64 %1, %15, %14, %20\n"
+        "v_cndmask_b32_e64 %5, %14, %15, %20\n"
+        "v_cndmask_b32_e64 %2, %17, %16, %20\n"
+        "v_cndmask_b32_e64 %6, %16, %17, %20\n"
+        "v_cndmask_b32_e64 %3, %19, %18, %20\n"
+        "v_cndmask_b32_e64 %7, %18, %19, %20\n"
+        "v_add_f32_dpp %8, %0, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %9, %1, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %10, %2, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %11, %3, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+        // level 2: (r0,r1) (r2,r3)
+        "v_cndmask_b32_e64 %0, %9, %8, %21\n"
+        "v_cndmask_b32_e64 %4, %8, %9, %21\n"
+        "v_cndmask_b32_e64 %1, %11, %10, %21\n"
+        "v_cndmask_b32_e64 %5, %10, %11, %21\n"
+        "s_nop 0\n"
+        "v_add_f32_dpp %8, %0, %4 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %9, %1, %5 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n"
+        // level 3: (r0,r1)
+        "v_cndmask_b32_e64 %0, %9, %8, %22\n"
+        "v_cndmask_b32_e64 %4, %8, %9, %22\n"
+        "s_nop 1\n"
+        "v_add_f32_dpp %8, %0, %4 row_half_mirror row_mask:0xf bank_mask:0xf\n"
+        // level 4: plain mirror add inside the 16-lane row
+        "s_nop 1\n"
+        "v_add_f32_dpp %8, %8, %8 row_mirror row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n"
+        : "=&v"(s0), "=&v"(s1), "=&v"(s2), "=&v"(s3), "=&v"(k0), "=&v"(k1), "=&v"(k2), "=&v"(k3), "=&v"(r0), "=&v"(r1),
+          "=&v"(r2), "=&v"(r3)
+        : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v7), "s"(m1), "s"(m2), "s"(m3));
+    // levels 5, 6: across the four rows (LDS crossbar permute, no LDS memory)
+    r0 += __shfl_xor(r0, 16);
+    r0 += __shfl_xor(r0, 32);
+    return r0;
+}
+
+// One more wave64 sum with plain DPP adds; total valid in lane 63.
+__device__ __forceinline__ float wave_sum1_lane63(float a) {
+    asm volatile(
+        "s_nop 1\n"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n"
+        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n"
+        "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
+        "s_nop 1\n"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+        "s_nop 1\n"
+        : "+v"(a));
+    return a;
+}
+
 __device__ __forceinline__ float readlane63(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }

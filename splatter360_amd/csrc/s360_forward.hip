@@ -571,7 +571,10 @@ __global__ __launch_bounds__(S360_BLOCK) void k_sort_tiles_global(const uint32_t
 //              64 ENTRIES in the lanes, one live pixel per iteration, and only entries passing the
 //              tests are replayed in list order.  Same arithmetic per (pixel, entry) pair.
 // A wave retires as soon as its own 64 pixels are saturated (no tile-wide barrier to wait for).
-constexpr int SPARSE_PIXELS = 12;
+#ifndef S360_SPARSE_PIXELS
+#define S360_SPARSE_PIXELS 6
+#endif
+constexpr int SPARSE_PIXELS = S360_SPARSE_PIXELS;
 
 __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_render(KParams kp, const S360View* __restrict__ views,
                                                       const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ list,
