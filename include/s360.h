@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define S360_ABI_VERSION 4
+#define S360_ABI_VERSION 5
 #define S360_MAX_VIEWS 8
 #define S360_TILE 16
 
@@ -55,7 +55,7 @@ enum {
 
 /*
  * One camera: the per-call fields of GaussianRasterizationSettings (cuda_splatting.py:99-112)
- * plus the scale-invariant factor of cuda_splatting.py:64-71.  44 floats, DEVICE memory (array
+ * plus the scale-invariant factor of cuda_splatting.py:64-71 and the view's near/far.  44 floats, DEVICE memory (array
  * of V).  `scale` multiplies means3D (and scale^2 the covariances) inside the kernels — pass the
  * UNSCALED cloud and scale = 1/near to fuse the reference's three full-size rescale copies; pass
  * 1.0 when the cloud is already scaled (drop-in rasteriser call).
@@ -69,7 +69,8 @@ typedef struct S360View {
     float tanfovx, tanfovy;
     float bg[3];
     float scale;
-    float _pad[3];
+    float near_plane, far_plane; /* UNSCALED near / far of the view (only read when a depth map is requested) */
+    float _pad;
 } S360View;
 
 typedef struct S360Params {
@@ -127,6 +128,23 @@ int s360_forward(const S360Params* prm, const S360View* views, const float* mean
                  const float* cov6, const float* opacities, const float* shs,
                  const float* colors_precomp, float* images, int32_t* radii, void* workspace,
                  size_t workspace_bytes, void* stream);
+
+/*
+ * Forward with a fused depth map: colour AND the alpha-premultiplied expected depth of
+ * render_depth_cuda (cuda_splatting.py:226-269: camera-space z of every Gaussian composited with the
+ * colour weights, background 0, not normalised) in ONE pass instead of a second full rasterisation
+ * (decoder_splatting_cuda.py:72-97 renders every face twice when depth is wanted).
+ *   depth_mode: S360_DEPTH_* (the reference's DepthRenderingMode); depth_maps[V,H,W].
+ * The depth output carries no gradient (the reference only renders depth in evaluation / videos).
+ */
+#define S360_DEPTH_DEPTH 0
+#define S360_DEPTH_DISPARITY 1
+#define S360_DEPTH_RELATIVE_DISPARITY 2
+#define S360_DEPTH_LOG 3
+int s360_forward_depth(const S360Params* prm, const S360View* views, const float* means3D,
+                       const float* cov6, const float* opacities, const float* shs,
+                       const float* colors_precomp, float* images, float* depth_maps, int32_t depth_mode,
+                       int32_t* radii, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * Backward: replaces upstream `rasterize_gaussians_backward(...)` (autograd backward of the

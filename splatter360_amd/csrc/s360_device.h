@@ -218,6 +218,20 @@ __device__ __forceinline__ float power2(float a, float b, float c, float dx, flo
     return __builtin_fmaf(t, dx, (c * dy) * dy);
 }
 
+// Per-Gaussian "colour" of the fused depth map for the reference's DepthRenderingMode
+// (cuda_splatting.py:244-251; z = camera-space depth in unscaled units).  The "log" mode reproduces the
+// reference's swapped clamp (z.minimum(near).maximum(far)) as is.
+__device__ __forceinline__ float depth_value(float z, float nearp, float farp, int mode) {
+    if (mode == 1) return 1.0f / z;
+    if (mode == 2) {
+        const float eps = 1e-10f;
+        const float disp_near = 1.0f / (nearp + eps), disp_far = 1.0f / (farp + eps), disp = 1.0f / (z + eps);
+        return 1.0f - (disp - disp_far) / (disp_near - disp_far + eps);
+    }
+    if (mode == 3) return __logf(fmaxf(fminf(z, nearp), farp));
+    return z;
+}
+
 // Tile rectangle of a splat (same float expression everywhere it is needed: preprocess, emit and
 // the backward instance index all recompute it from the stored centre and integer radius).
 __device__ __forceinline__ void tile_rect(float px, float py, int radius, int gx, int gy, int& minx, int& miny,

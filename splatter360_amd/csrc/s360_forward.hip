@@ -576,13 +576,15 @@ __global__ __launch_bounds__(S360_BLOCK) void k_sort_tiles_global(const uint32_t
 #endif
 constexpr int SPARSE_PIXELS = S360_SPARSE_PIXELS;
 
+template <bool WITH_DEPTH>
 __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_render(KParams kp, const S360View* __restrict__ views,
                                                       const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ list,
                                                       const float4* __restrict__ recA, const float4* __restrict__ recB,
                                                       const float4* __restrict__ recC, float* __restrict__ images,
                                                       float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
                                                       uint32_t* __restrict__ tile_max_contrib, uint32_t* __restrict__ strip_last,
-                                                      uint32_t* __restrict__ dbg) {
+                                                      uint32_t* __restrict__ dbg, const float* __restrict__ depths,
+                                                      float* __restrict__ depth_maps, int depth_mode) {
 #ifdef S360_DBG_TIMING
     const long long t_begin = wall_clock64();
 #endif
@@ -597,23 +599,30 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
     const float x0 = (float)(tx * 16), ys0 = (float)(ty * 16 + wave * 4);  // strip origin
 
     const uint32_t start = min(tile_start[t], kp.cap), end = min(tile_start[t + 1], kp.cap);
-    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
+    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
     uint32_t last = 0;
     bool done = !inside;
+    const float inv_scale = WITH_DEPTH ? 1.0f / views[v].scale : 0.f;
+    const float v_near = WITH_DEPTH ? views[v].near_plane : 0.f, v_far = WITH_DEPTH ? views[v].far_plane : 0.f;
 
     // software pipeline: list indices two chunks ahead, records one chunk ahead
     uint32_t p_n1 = 0, p_n2 = 0;
     if (start + lane < end) p_n1 = list[start + lane];
     if (start + 64 + lane < end) p_n2 = list[start + 64 + lane];
     float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na, nc = na;
+    float nz = 0.f;
     if (start + lane < end) {
         na = recA[3 * (size_t)(p_n1)];
         nb = recA[3 * (size_t)(p_n1) + 1];
         nc = recA[3 * (size_t)(p_n1) + 2];
+        if (WITH_DEPTH) nz = depths[p_n1];
     }
     for (uint32_t b = start; b < end; b += 64) {
         if (__ballot(!done) == 0ull) break;
         const float4 ea = na, eb = nb;
+        // fused depth "colour" of this lane's entry: camera z in unscaled units, then the reference's mode
+        float ez = 0.f;
+        if (WITH_DEPTH) ez = depth_value(nz * inv_scale, v_near, v_far, depth_mode);
         const float ec = nc.x, ewx = nc.z, ewy = nc.w;
         const bool ev = b + lane < end;
         // issue the next chunk's loads before touching this one
@@ -622,6 +631,7 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
             na = recA[3 * (size_t)(p_n1)];
             nb = recA[3 * (size_t)(p_n1) + 1];
             nc = recA[3 * (size_t)(p_n1) + 2];
+            if (WITH_DEPTH) nz = depths[p_n1];
         }
         if (b + 128 + lane < end) p_n2 = list[b + 128 + lane];
 
@@ -673,6 +683,7 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
                     C0 += rl(eb.z, b0) * w;
                     C1 += rl(eb.w, b0) * w;
                     C2 += rl(ec, b0) * w;
+                    if (WITH_DEPTH) D += rl(ez, b0) * w;
                     T = contrib ? test_T : T;
                     last = contrib ? rel + (uint32_t)b0 + 1u : last;
                 }
@@ -686,6 +697,7 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
                     C0 += rl(eb.z, b1) * w;
                     C1 += rl(eb.w, b1) * w;
                     C2 += rl(ec, b1) * w;
+                    if (WITH_DEPTH) D += rl(ez, b1) * w;
                     T = contrib ? test_T : T;
                     last = contrib ? rel + (uint32_t)b1 + 1u : last;
                 }
@@ -712,6 +724,7 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
                     C0 += rl(eb.z, eb_) * w;
                     C1 += rl(eb.w, eb_) * w;
                     C2 += rl(ec, eb_) * w;
+                    if (WITH_DEPTH) D += rl(ez, eb_) * w;
                     T = contrib ? test_T : T;
                     last = contrib ? rel + (uint32_t)eb_ + 1u : last;
                     done = done || stop;
@@ -730,6 +743,7 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
         img[2 * hw + pix] = C2 + T * vw.bg[2];
         final_T[(size_t)v * hw + pix] = T;
         n_contrib[(size_t)v * hw + pix] = last;
+        if (WITH_DEPTH) depth_maps[(size_t)v * hw + pix] = D;  // background depth is 0 (cuda_splatting.py:258)
     }
     const uint32_t wm = wave_max_u32(inside ? last : 0u);
     if (lane == 0) {
@@ -837,9 +851,10 @@ extern "C" int s360_layout(const S360Params* prm, S360Layout* out) {
         }                                                                                            \
     } while (0)
 
-extern "C" int s360_forward(const S360Params* prm, const S360View* views, const float* means3D, const float* cov6,
-                            const float* opacities, const float* shs, const float* colors_precomp, float* images,
-                            int32_t* radii, void* workspace, size_t workspace_bytes, void* stream_) {
+static int forward_impl(const S360Params* prm, const S360View* views, const float* means3D, const float* cov6,
+                        const float* opacities, const float* shs, const float* colors_precomp, float* images,
+                        float* depth_maps, int depth_mode, int32_t* radii, void* workspace, size_t workspace_bytes,
+                        void* stream_) {
     if (!prm || !views || !images || !workspace) return S360_E_BADARG;
     if (prm->P > 0 && (shs == nullptr) == (colors_precomp == nullptr)) return S360_E_BADARG;
     if (prm->P > 0 && (!means3D || !cov6 || !opacities)) return S360_E_BADARG;
@@ -952,9 +967,31 @@ extern "C" int s360_forward(const S360Params* prm, const S360View* views, const 
     }
     {
         ProfScope ps(PS_RENDER, st);
-        hipLaunchKernelGGL(k_render, dim3(nt), dim3(S360_BLOCK), occupancy_cap_lds("S360_RENDER_LDS", 0), st, kp, views, tile_start, list, recA, recB, recC, images,
-                           final_T, n_contrib, tile_max_contrib, strip_last, header + 8);
+        if (depth_maps)
+            hipLaunchKernelGGL(k_render<true>, dim3(nt), dim3(S360_BLOCK), occupancy_cap_lds("S360_RENDER_LDS", 0), st, kp, views, tile_start,
+                               list, recA, recB, recC, images, final_T, n_contrib, tile_max_contrib, strip_last, header + 8,
+                               depths, depth_maps, depth_mode);
+        else
+            hipLaunchKernelGGL(k_render<false>, dim3(nt), dim3(S360_BLOCK), occupancy_cap_lds("S360_RENDER_LDS", 0), st, kp, views, tile_start,
+                               list, recA, recB, recC, images, final_T, n_contrib, tile_max_contrib, strip_last, header + 8,
+                               depths, depth_maps, depth_mode);
     }
     S360_CHECK_LAUNCH();
     return S360_OK;
+}
+
+extern "C" int s360_forward(const S360Params* prm, const S360View* views, const float* means3D, const float* cov6,
+                            const float* opacities, const float* shs, const float* colors_precomp, float* images,
+                            int32_t* radii, void* workspace, size_t workspace_bytes, void* stream_) {
+    return forward_impl(prm, views, means3D, cov6, opacities, shs, colors_precomp, images, nullptr, 0, radii, workspace,
+                        workspace_bytes, stream_);
+}
+
+extern "C" int s360_forward_depth(const S360Params* prm, const S360View* views, const float* means3D, const float* cov6,
+                                  const float* opacities, const float* shs, const float* colors_precomp, float* images,
+                                  float* depth_maps, int32_t depth_mode, int32_t* radii, void* workspace,
+                                  size_t workspace_bytes, void* stream_) {
+    if (!depth_maps || depth_mode < 0 || depth_mode > 3) return S360_E_BADARG;
+    return forward_impl(prm, views, means3D, cov6, opacities, shs, colors_precomp, images, depth_maps, depth_mode, radii,
+                        workspace, workspace_bytes, stream_);
 }

@@ -175,26 +175,29 @@ def pack_camera_views(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far:
     rescale happens inside the kernels (S360View.scale).  Device math only, no host sync."""
     vs = cameras.view_setup(extrinsics, intrinsics, near, far, scale_invariant)
     return rasterizer.pack_views(vs["view_matrix"], vs["full_projection"], vs["campos"], vs["tan_fov_x"],
-                                 vs["tan_fov_y"], background, scale=vs["scale"])
+                                 vs["tan_fov_y"], background, scale=vs["scale"], near=near, far=far)
 
 
 def render_views_fused(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, image_shape: tuple,
                        background: Tensor, gaussian_means: Tensor, gaussian_covariances: Tensor,
                        gaussian_sh_coefficients: Tensor, gaussian_opacities: Tensor, *, shared_campos: bool = True,
-                       max_instances: Optional[int] = None, check: str = "sync", views: Optional[Tensor] = None) -> Tensor:
+                       max_instances: Optional[int] = None, check: str = "sync", views: Optional[Tensor] = None,
+                       depth_mode: Optional[DepthRenderingMode] = None):
     """V <= 8 views of ONE cloud in one fused rasteriser call: means[G,3], covariances[G,3,3],
     harmonics[G,3,d_sh] (the reference's Gaussians layout, src/model/types.py:7-12, read in place),
     opacities[G] -> [V,3,h,w].  With the six face cameras of a panorama (shared_campos=True: one camera
-    centre) this is bit-for-bit the result of six reference-style render_cuda calls."""
+    centre) this is bit-for-bit the result of six reference-style render_cuda calls.  With depth_mode set,
+    returns (colour, depth[V,h,w]): the depth maps of render_depth_cuda from the SAME pass (the reference
+    rasterises every face a second time for them, decoder_splatting_cuda.py:72-97)."""
     if views is None:  # callers may pass pre-packed views (e.g. prepared on a side stream, see CameraPrefetcher)
         views = pack_camera_views(extrinsics, intrinsics, near, far, background)
     n = gaussian_sh_coefficients.shape[-1]
     h, w = image_shape
-    images, _ = rasterizer.rasterize_views(
+    out = rasterizer.rasterize_views(
         gaussian_means, gaussian_covariances, gaussian_opacities, gaussian_sh_coefficients, None, views=views,
         image_height=h, image_width=w, sh_degree=isqrt(n) - 1, shared_campos=shared_campos, want_radii=False,
-        max_instances=max_instances, check=check, cov9=True, sh_channel_major=True)
-    return images
+        max_instances=max_instances, check=check, cov9=True, sh_channel_major=True, depth_mode=depth_mode)
+    return out[0] if depth_mode is None else (out[0], out[2])
 
 
 class CameraPrefetcher:
@@ -235,6 +238,38 @@ def render_cube_faces(pano_c2w: Tensor, near: Tensor, far: Tensor, face_w: int, 
 class DecoderOutput:
     color: Tensor
     depth: Optional[Tensor]
+
+
+class DecoderSplattingFused(torch.nn.Module):
+    """Decoder with the reference's forward contract (decoder.py:37-48) on the fused path: the v views of
+    every batch item are rendered `views_per_group` at a time (6 = the cube faces of one target panorama,
+    which share a camera centre) in single rasteriser calls, colour and depth together."""
+
+    def __init__(self, background_color=(0.0, 0.0, 0.0), views_per_group: int = 6, shared_campos: bool = True):
+        super().__init__()
+        self.register_buffer("background_color", torch.tensor(background_color, dtype=torch.float32), persistent=False)
+        self.views_per_group, self.shared_campos = views_per_group, shared_campos
+
+    def forward(self, gaussians, extrinsics, intrinsics, near, far, image_shape, depth_mode=None) -> "DecoderOutput":
+        b, v = extrinsics.shape[:2]
+        colors, depths = [], []
+        for i in range(b):
+            cs, ds = [], []
+            for s in range(0, v, self.views_per_group):
+                e = slice(s, min(v, s + self.views_per_group))
+                out = render_views_fused(extrinsics[i, e], intrinsics[i, e], near[i, e], far[i, e], image_shape,
+                                         self.background_color, gaussians.means[i], gaussians.covariances[i],
+                                         gaussians.harmonics[i], gaussians.opacities[i], shared_campos=self.shared_campos,
+                                         depth_mode=depth_mode)
+                if depth_mode is None:
+                    cs.append(out)
+                else:
+                    cs.append(out[0])
+                    ds.append(out[1])
+            colors.append(torch.cat(cs))
+            if depth_mode is not None:
+                depths.append(torch.cat(ds))
+        return DecoderOutput(torch.stack(colors), None if depth_mode is None else torch.stack(depths))
 
 
 class DecoderSplattingCUDA(torch.nn.Module):

@@ -34,10 +34,14 @@ class GaussianRasterizationSettings(NamedTuple):
     debug: bool
 
 
+DEPTH_MODES = {"depth": 0, "disparity": 1, "relative_disparity": 2, "log": 3}
+
+
 def pack_views(viewmatrix: Tensor, projmatrix: Tensor, campos: Tensor, tanfovx, tanfovy, bg: Tensor,
-               scale=1.0) -> Tensor:
+               scale=1.0, near=0.0, far=0.0) -> Tensor:
     """-> float32 [V,44] device tensor in S360View layout.  Tensors may carry a leading view dim;
-    tanfov / scale may be python floats or [V] tensors.  No host synchronisation."""
+    tanfov / scale / near / far may be python floats or [V] tensors (near / far: the UNSCALED planes, only
+    read when a fused depth map is requested).  No host synchronisation."""
     vm = viewmatrix.reshape(-1, 16).float()
     v = vm.shape[0]
     dev = vm.device
@@ -50,8 +54,9 @@ def pack_views(viewmatrix: Tensor, projmatrix: Tensor, campos: Tensor, tanfovx, 
             return t.reshape(-1, 1).float().to(dev).expand(v, 1)
         return torch.full((v, 1), float(t), dtype=torch.float32, device=dev)
 
-    pad = torch.zeros((v, 3), dtype=torch.float32, device=dev)
-    return torch.cat([vm, pm, cp.expand(v, 3), col(tanfovx), col(tanfovy), b, col(scale), pad], dim=1).contiguous()
+    pad = torch.zeros((v, 1), dtype=torch.float32, device=dev)
+    return torch.cat([vm, pm, cp.expand(v, 3), col(tanfovx), col(tanfovy), b, col(scale), col(near), col(far), pad],
+                     dim=1).contiguous()
 
 
 def default_capacity(p: int, v: int) -> int:
@@ -115,17 +120,24 @@ def _f32c(t: Tensor, name: str) -> Tensor:
     return t.detach().float().contiguous()
 
 
-def _forward_call(prm, views, means3D, cov6, opac, shs, colors, want_radii: bool):
+def _forward_call(prm, views, means3D, cov6, opac, shs, colors, want_radii: bool, depth_mode=None):
     lay = _lib.layout(prm)
     dev = means3D.device
     ws = torch.empty(lay.total_bytes, dtype=torch.uint8, device=dev)
     images = torch.empty((prm.V, 3, prm.H, prm.W), dtype=torch.float32, device=dev)
     radii = torch.empty((prm.V, prm.P), dtype=torch.int32, device=dev) if want_radii else None
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    rc = _lib.lib().s360_forward(C.byref(prm), _ptr(views), _ptr(means3D), _ptr(cov6), _ptr(opac), _ptr(shs),
-                                 _ptr(colors), _ptr(images), _ptr(radii), _ptr(ws), lay.total_bytes, stream)
+    depth = None
+    if depth_mode is None:
+        rc = _lib.lib().s360_forward(C.byref(prm), _ptr(views), _ptr(means3D), _ptr(cov6), _ptr(opac), _ptr(shs),
+                                     _ptr(colors), _ptr(images), _ptr(radii), _ptr(ws), lay.total_bytes, stream)
+    else:
+        depth = torch.empty((prm.V, prm.H, prm.W), dtype=torch.float32, device=dev)
+        rc = _lib.lib().s360_forward_depth(C.byref(prm), _ptr(views), _ptr(means3D), _ptr(cov6), _ptr(opac), _ptr(shs),
+                                           _ptr(colors), _ptr(images), _ptr(depth), DEPTH_MODES[depth_mode], _ptr(radii),
+                                           _ptr(ws), lay.total_bytes, stream)
     _lib.check(rc, "s360_forward")
-    return images, radii, RasterState(prm, lay, ws)
+    return images, radii, RasterState(prm, lay, ws), depth
 
 
 class _RasterizeViews(torch.autograd.Function):
@@ -133,7 +145,7 @@ class _RasterizeViews(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, cov6, views, cfg):
-        h, w, sh_degree, shared_campos, max_instances, check, want_radii, cov9, sh_channel_major, keep_offsets = cfg
+        h, w, sh_degree, shared_campos, max_instances, check, want_radii, cov9, sh_channel_major, keep_offsets, depth_mode = cfg
         if not means3D.is_cuda:
             raise RuntimeError("means3D must live on the GPU (hip device); the rasteriser has no CPU path")
         with torch.cuda.device(means3D.device):
@@ -157,21 +169,23 @@ class _RasterizeViews(torch.autograd.Function):
                 _lib.FLAG_COV9 if cov9 else 0) | (_lib.FLAG_SH_CHANNEL_MAJOR if sh_channel_major else 0) | (
                 0 if (needs_bwd or keep_offsets) else _lib.FLAG_FORWARD_ONLY)
             prm.max_instances = int(max_instances) if max_instances else default_capacity(p, v)
-            images, radii, state = _forward_call(prm, vw, m3, c6, op, sh, col, want_radii)
+            images, radii, state, depth = _forward_call(prm, vw, m3, c6, op, sh, col, want_radii, depth_mode)
             if check == "sync" and state.overflowed():
                 prm.max_instances = state.num_rendered()
-                images, radii, state = _forward_call(prm, vw, m3, c6, op, sh, col, want_radii)
+                images, radii, state, depth = _forward_call(prm, vw, m3, c6, op, sh, col, want_radii, depth_mode)
         ctx.state = state
         ctx.has_means2D = means2D is not None
         ctx.save_for_backward(m3, c6, op, sh, col, vw)
         _RasterizeViews.last_state = state
         if radii is None:
             radii = torch.empty(0, dtype=torch.int32, device=images.device)
-        ctx.mark_non_differentiable(radii)
-        return images, radii
+        if depth is None:
+            depth = torch.empty(0, dtype=torch.float32, device=images.device)
+        ctx.mark_non_differentiable(radii, depth)
+        return images, radii, depth
 
     @staticmethod
-    def backward(ctx, grad_images, _grad_radii):
+    def backward(ctx, grad_images, _grad_radii, _grad_depth):
         m3, c6, op, sh, col, vw = ctx.saved_tensors
         state: RasterState = ctx.state
         prm, lay = state.prm, state.layout
@@ -205,11 +219,13 @@ def rasterize_views(means3D: Tensor, cov6: Tensor, opacities: Tensor, shs: Optio
                     colors_precomp: Optional[Tensor] = None, *, views: Tensor, image_height: int, image_width: int,
                     sh_degree: int = 0, shared_campos: bool = False, max_instances: Optional[int] = None,
                     check: str = "sync", want_radii: bool = True, means2D: Optional[Tensor] = None,
-                    cov9: bool = False, sh_channel_major: bool = False, keep_offsets: bool = False):
+                    cov9: bool = False, sh_channel_major: bool = False, keep_offsets: bool = False,
+                    depth_mode: Optional[str] = None):
     """Render V views ([V,44] packed, see pack_views) of one cloud.  cov9: cov6 is [P,3,3];
     sh_channel_major: shs is [P,3,M] (the reference's Gaussians layouts, consumed without copies).
     When no input requires grad the per-pair offsets scan (backward-only state) is skipped unless
-    keep_offsets=True.  Returns (images[V,3,H,W],
+    keep_offsets=True.  depth_mode ("depth" | "disparity" | "relative_disparity" | "log"): also return the
+    fused depth map [V,H,W] of render_depth_cuda as a third result (no gradient; needs near / far in `views`).  Returns (images[V,3,H,W],
     radii[V,P] int32).  opacities may be [P] or [P,1]; its gradient has the same shape.
     check="sync": read the overflow flag after the forward (one host sync, like upstream's own
     scan read-back) and re-run with the exact size if the binning capacity was exceeded;
@@ -217,9 +233,12 @@ def rasterize_views(means3D: Tensor, cov6: Tensor, opacities: Tensor, shs: Optio
     if (shs is None) == (colors_precomp is None):
         raise Exception("Please provide excatly one of either SHs or precomputed colors!")
     op2 = opacities.reshape(-1, 1)
+    if depth_mode is not None and depth_mode not in DEPTH_MODES:
+        raise ValueError(f"depth_mode must be one of {sorted(DEPTH_MODES)}")
     cfg = (image_height, image_width, sh_degree, shared_campos, max_instances, check, want_radii, cov9,
-           sh_channel_major, keep_offsets)
-    return _RasterizeViews.apply(means3D, means2D, shs, colors_precomp, op2, cov6, views, cfg)
+           sh_channel_major, keep_offsets, depth_mode)
+    images, radii, depth = _RasterizeViews.apply(means3D, means2D, shs, colors_precomp, op2, cov6, views, cfg)
+    return (images, radii) if depth_mode is None else (images, radii, depth)
 
 
 def last_state() -> Optional[RasterState]:

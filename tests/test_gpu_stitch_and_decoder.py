@@ -107,3 +107,23 @@ def test_scales_rotations_input_form(gpu):
         rast(means3D=t(means), opacities=t(opac), shs=t(shs))
     with pytest.raises(Exception):
         rast(means3D=t(means), opacities=t(opac), shs=t(shs), colors_precomp=t(means), cov3D_precomp=cov)
+
+
+@pytest.mark.parametrize("mode", ["depth", "disparity", "relative_disparity", "log"])
+def test_fused_depth_equals_second_pass_depth_render(gpu, mode):
+    """Colour + depth from ONE pass (s360_forward_depth) vs the reference-style second rasterisation
+    (render_depth_cuda) for every DepthRenderingMode, on the six faces of a panorama."""
+    from types import SimpleNamespace
+    cloud = synthetic.uniform_cloud(8000, seed=21, extent=3.0, scale_range=(0.02, 0.3))
+    fw = 64
+    gs = SimpleNamespace(**{k: torch.tensor(v, device=gpu)[None] for k, v in cloud.items()})
+    ext = cameras.cube_face_extrinsics(torch.tensor(synthetic.target_pano_pose((0.1, 0.0, -0.2)))[None]).to(gpu)
+    k = cameras.cube_face_intrinsics(1).to(gpu)
+    near = torch.full((1, 6), 0.1, device=gpu)
+    far = torch.full((1, 6), 10.0, device=gpu)
+    ref = decoder.DecoderSplattingCUDA().to(gpu)(gs, ext, k, near, far, (fw, fw), depth_mode=mode)
+    fused = decoder.DecoderSplattingFused().to(gpu)(gs, ext, k, near, far, (fw, fw), depth_mode=mode)
+    assert torch.equal(fused.color, ref.color)
+    scale = ref.depth.abs().max().item() + 1e-12
+    assert (fused.depth - ref.depth).abs().max().item() <= 2e-5 * scale
+    assert (fused.depth - ref.depth).abs().mean().item() <= 2e-6 * scale
