@@ -45,7 +45,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--mode", choices=("fwdbwd", "fwd"), default="fwdbwd")
+    ap.add_argument("--mode", choices=("fwdbwd", "fwd", "eval"), default="fwdbwd",
+                    help="eval = BASELINE configs[3] shape: 3 target panoramas x 6 faces, colour + depth, forward only")
     ap.add_argument("--pano-h", type=int, default=512, help="context/target ERP height (width = 2h)")
     ap.add_argument("--face", type=int, default=0, help="cube face size (default pano_h/2)")
     ap.add_argument("--cpu-baseline", type=int, default=1)
@@ -105,7 +106,18 @@ def main():
     cams = decoder.CameraPrefetcher(dev)
     out = {}
 
-    def step():
+    eval_poses = [decoder.cube_cameras(torch.tensor(synthetic.target_pano_pose((0.1 * i, 0.0, -0.05 * i)), device=dev), 0.1, 10.0)
+                  for i in range(3)]
+
+    def step_eval():
+        # evaluation_index_replica.json: 3 target views per scene -> 18 faces, colour + depth (test_step :336-345)
+        for (e, k, n, f) in eval_poses:
+            col, dep = decoder.render_views_fused(e, k, n, f, (face_w, face_w), bg, *params, check="lazy", depth_mode="depth",
+                                                  views=cams.pack(e, k, n, f, bg))
+            out["erp"] = c2e.stitch_rendered(col)
+            out["faces"] = col
+
+    def step_train():
         for p in params:
             p.grad = None
         views = cams.pack(ext, K, near, far, bg)  # camera glue of this step, overlapped on a side stream
@@ -116,6 +128,9 @@ def main():
             loss.backward()
             distributed.allreduce_gradients([p.grad for p in params])
         out["faces"] = faces
+
+    step = step_eval if a.mode == "eval" else step_train
+    views_per_step = 3 if a.mode == "eval" else 1
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -174,11 +189,12 @@ def main():
             traffic = json.loads(pmc.read_text()).get(dom, {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    bytes_step = (BYTES_FWD + (BYTES_BWD if a.mode == "fwdbwd" else 0.0)) * G
+    bytes_step = (BYTES_FWD + (BYTES_BWD if a.mode == "fwdbwd" else 0.0)) * G * views_per_step
 
-    value = G * world / (dt / a.steps) / 1e6
+    value = G * views_per_step * world / (dt / a.steps) / 1e6
     res = {
-        "metric": "Msplats/s fwd+bwd @1M Gaussians, 1024x512 ERP" if a.mode == "fwdbwd" else "Msplats/s fwd @1M Gaussians, 1024x512 ERP",
+        "metric": {"fwdbwd": "Msplats/s fwd+bwd @1M Gaussians, 1024x512 ERP", "fwd": "Msplats/s fwd @1M Gaussians, 1024x512 ERP",
+                   "eval": "Msplats/s fwd colour+depth, 3 ERP views @1M Gaussians, 1024x512 ERP"}[a.mode],
         "value": value, "unit": "Msplats/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
@@ -196,7 +212,24 @@ def main():
                           "frac_of_8TBps": bytes_step / (dt / a.steps) / 1e9 / HBM_PEAK_GBPS},
         "kernels": kernels,
     }
-    if rank == 0 and world == 1 and a.cpu_baseline:
+    if a.mode == "eval" and rank == 0:
+        # the same 18 colour + 18 depth face renders through the reference-style per-face drop-in calls
+        from types import SimpleNamespace
+        gs = SimpleNamespace(means=params[0][None], covariances=params[1][None], harmonics=params[2][None], opacities=params[3][None])
+        dec = decoder.DecoderSplattingCUDA().to(dev)
+        e18 = torch.cat([e for (e, _, _, _) in eval_poses])[None]
+        k18 = torch.cat([k for (_, k, _, _) in eval_poses])[None]
+        n18 = torch.cat([n for (_, _, n, _) in eval_poses])[None]
+        f18 = torch.cat([f for (_, _, _, f) in eval_poses])[None]
+        with torch.no_grad():
+            dec(gs, e18, k18, n18, f18, (face_w, face_w), depth_mode="depth")
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                dec(gs, e18, k18, n18, f18, (face_w, face_w), depth_mode="depth")
+            torch.cuda.synchronize(dev)
+        res["per_face_dropin_ms_per_step"] = (time.perf_counter() - t0) / 3 * 1e3
+    if rank == 0 and world == 1 and a.cpu_baseline and a.mode != "eval":
         res["cpu_baseline"] = cpu_baseline(cloud, face_w, 0.1, 10.0, a.mode)
     elif rank == 0:
         res["cpu_baseline"] = None
