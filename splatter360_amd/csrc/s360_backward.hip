@@ -241,13 +241,17 @@ __global__ __launch_bounds__(S360_BLOCK) void k_gather_pairs(KParams kp, const u
     pairgrad[p * 3 + 2] = make_float4(gb, 0.f, 0.f, 0.f);
 }
 
-template <bool USE_SH>
+// SH_PASS = true : SH backward inside this kernel (slab through LDS; required when the views have different
+//                   camera centres).  SH_PASS = false (shared camera centre): the kernel only exports the
+//                   clamp-masked sum of dL/dRGB per Gaussian and k_sh_bwd streams the SH slabs afterwards —
+//                   two lean kernels instead of one register- and LDS-bound one.
+template <bool USE_SH, bool SH_PASS>
 __global__ __launch_bounds__(S360_BLOCK) void k_preprocess_bwd(
     KParams kp, const S360View* __restrict__ views, const float* __restrict__ means, const float* __restrict__ cov6,
     const float* __restrict__ shs, const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ offsets,
     const uint8_t* __restrict__ clamped, const float4* __restrict__ pairgrad, float* __restrict__ d_means3D,
     float* __restrict__ d_means2D, float* __restrict__ d_cov6, float* __restrict__ d_opac, float* __restrict__ d_shs,
-    float* __restrict__ d_colors) {
+    float* __restrict__ d_colors, float4* __restrict__ drgb_out) {
     extern __shared__ __attribute__((aligned(16))) float lds_sh[];  // [256*M*3] SH slab, then [256*V*3] dRGB
     const int tid = threadIdx.x;
     const int g0 = blockIdx.x * S360_BLOCK;
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess_bwd(
     const int nb = min(S360_BLOCK, P - g0);
     const int nfl = nb * kp.M * 3;
     float* lds_drgb = lds_sh + S360_BLOCK * kp.M * 3;  // per-thread, per-view dRGB (non-shared campos)
-    const bool want_sh = USE_SH && d_shs != nullptr;
+    const bool want_sh = USE_SH && SH_PASS && d_shs != nullptr;
 
     if (want_sh) {
         const float* src = shs + (size_t)g0 * kp.M * 3;
@@ -463,6 +467,8 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess_bwd(
         d_means3D[3 * g] = dm0;
         d_means3D[3 * g + 1] = dm1;
         d_means3D[3 * g + 2] = dm2;
+        if (USE_SH && !SH_PASS && drgb_out)
+            drgb_out[g] = make_float4(drgb_sum[0], drgb_sum[1], drgb_sum[2], __int_as_float(first_visible));
         if (cov9) {
             // adjoint of the upper-triangle gather: lower triangle receives no gradient
             float* o = d_cov6 + 9 * (size_t)g;
@@ -492,6 +498,112 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess_bwd(
         } else {
             for (int i = tid; i < nfl; i += S360_BLOCK) dst[i] = lds_sh[i];
         }
+    }
+}
+
+// SH backward for views sharing one camera centre: a pure streaming kernel, ONE WAVE per workgroup so the
+// load / compute / store phases of the (up to 8) waves on a CU overlap freely.  Per Gaussian a lane reads
+// its 300-byte SH slab directly (16-byte loads, every byte of every line consumed by that lane) and the
+// summed dL/dRGB, computes dL/dSH = Y_k * dRGB_c and the view-direction term of dL/dmean; the 64 output
+// slabs (19.2 KB, contiguous in memory) go through LDS so the global stores are fully coalesced 16-byte
+// writes (lane-strided stores of partial lines cost ~2x here).
+template <bool CH_MAJOR, bool FAST>  // FAST: degree 4, 25 stored coefficients (the reference's configuration)
+__global__ __launch_bounds__(64) void k_sh_bwd(KParams kp, const S360View* __restrict__ views, const float* __restrict__ means,
+                                              const float* __restrict__ shs, const float4* __restrict__ drgb_in,
+                                              float* __restrict__ d_means3D, float* __restrict__ d_shs) {
+    extern __shared__ __attribute__((aligned(16))) float lds_o[];  // [64][M*3]
+    const int lane = threadIdx.x;
+    const int g0 = blockIdx.x * 64;
+    const int g = g0 + lane;
+    const int slab = kp.M * 3;
+    float* mine = lds_o + lane * slab;
+    const int deg = FAST ? 4 : kp.deg;
+    const int n_sh = (deg + 1) * (deg + 1);
+    if (g < kp.P) {
+        const float4 dr = drgb_in[g];
+        const int fv = __float_as_int(dr.w);
+        if (fv < 0) {  // invisible in every view: zero gradient
+            for (int k = 0; k < slab; ++k) mine[k] = 0.f;
+        } else {
+            const S360View& vw = views[fv];
+            const float sc = vw.scale;
+            const float ddx = means[3 * g] * sc - vw.campos[0], ddy = means[3 * g + 1] * sc - vw.campos[1],
+                        ddz = means[3 * g + 2] * sc - vw.campos[2];
+            const float inv = 1.f / sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
+            const float x = ddx * inv, y = ddy * inv, z = ddz * inv;
+            float Y[25], s[25];
+            sh_basis(deg, x, y, z, Y);
+            const float* sh = shs + (size_t)g * slab;
+            const float drc[3] = {dr.x, dr.y, dr.z};
+            if (FAST && CH_MAJOR) {
+#pragma unroll
+                for (int k = 0; k < 25; ++k) s[k] = 0.f;
+#pragma unroll 1
+                for (int ch = 0; ch < 3; ++ch) {
+                    float c[25];
+                    load25(sh + 25 * ch, c);
+                    const float d = drc[ch];
+#pragma unroll
+                    for (int k = 0; k < 25; ++k) {
+                        s[k] += c[k] * d;
+                        mine[25 * ch + k] = Y[k] * d;
+                    }
+                }
+            } else if (FAST) {
+#pragma unroll 1
+                for (int q = 0; q < 5; ++q) {
+                    float c[15];
+                    load15(sh + 15 * q, c);
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) {
+                        s[5 * q + k] = c[3 * k] * drc[0] + c[3 * k + 1] * drc[1] + c[3 * k + 2] * drc[2];
+                        mine[15 * q + 3 * k] = Y[5 * q + k] * drc[0];
+                        mine[15 * q + 3 * k + 1] = Y[5 * q + k] * drc[1];
+                        mine[15 * q + 3 * k + 2] = Y[5 * q + k] * drc[2];
+                    }
+                }
+            } else {
+                const int sk = CH_MAJOR ? 1 : 3, sc_ = CH_MAJOR ? kp.M : 1;
+#pragma unroll
+                for (int k = 0; k < 25; ++k) {  // generic layout / degree (<= 25 active coefficients)
+                    if (k < n_sh) {
+                        s[k] = sh[k * sk] * drc[0] + sh[k * sk + sc_] * drc[1] + sh[k * sk + 2 * sc_] * drc[2];
+                        mine[k * sk] = Y[k] * drc[0];
+                        mine[k * sk + sc_] = Y[k] * drc[1];
+                        mine[k * sk + 2 * sc_] = Y[k] * drc[2];
+                    }
+                }
+                for (int k = n_sh; k < kp.M; ++k) mine[k * sk] = mine[k * sk + sc_] = mine[k * sk + 2 * sc_] = 0.f;
+            }
+            float bx[25], by[25], bz[25];
+            sh_basis_grad(deg, x, y, z, bx, by, bz);
+            float q0 = 0.f, q1 = 0.f, q2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 25; ++k) {
+                if (k < n_sh) {
+                    q0 += bx[k] * s[k];
+                    q1 += by[k] * s[k];
+                    q2 += bz[k] * s[k];
+                }
+            }
+            const float dot = x * q0 + y * q1 + z * q2;
+            d_means3D[3 * g] += sc * ((q0 - x * dot) * inv);
+            d_means3D[3 * g + 1] += sc * ((q1 - y * dot) * inv);
+            d_means3D[3 * g + 2] += sc * ((q2 - z * dot) * inv);
+        }
+    }
+    __syncthreads();  // single wave: orders the LDS writes above before the cooperative read below
+    const int nb = min(64, kp.P - g0);
+    const int nfl = nb * slab;
+    float* dst = d_shs + (size_t)g0 * slab;
+    if ((((uintptr_t)dst) & 15) == 0) {
+        const int n4 = nfl >> 2;
+        float4* o4 = reinterpret_cast<float4*>(dst);
+        const float4* l4 = reinterpret_cast<const float4*>(lds_o);
+        for (int i = lane; i < n4; i += 64) o4[i] = l4[i];
+        for (int i = (n4 << 2) + lane; i < nfl; i += 64) dst[i] = lds_o[i];
+    } else {
+        for (int i = lane; i < nfl; i += 64) dst[i] = lds_o[i];
     }
 }
 
@@ -578,25 +690,47 @@ extern "C" int s360_backward(const S360Params* prm, const S360View* views, const
                            tiles_touched, offsets, part, valid_words, pairgrad);
     }
     const int nblk = (kp.P + S360_BLOCK - 1) / S360_BLOCK;
+    float4* drgb = pairgrad + (size_t)kp.V * kp.P * 3;  // [P] summed dL/dRGB (+ first visible view) for k_sh_bwd
     if (shs) {
-        size_t lds = d_shs ? (size_t)S360_BLOCK * kp.M * 3 * 4 : 0;
-        if (d_shs && !(kp.flags & S360_FLAG_SHARED_CAMPOS)) lds += (size_t)S360_BLOCK * kp.V * 3 * 4;
-        if (lds > 160 * 1024) return S360_E_UNSUPPORTED;
-        {
-            static bool attr_done[64] = {};
-            int dev = 0;
-            if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !attr_done[dev]) {
-                (void)hipFuncSetAttribute((const void*)k_preprocess_bwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                attr_done[dev] = true;
+        const bool shared = (kp.flags & S360_FLAG_SHARED_CAMPOS) != 0;
+        if (shared || !d_shs) {
+            hipLaunchKernelGGL((k_preprocess_bwd<true, false>), dim3(nblk), dim3(S360_BLOCK), 0, st, kp, views, means3D, cov6, shs,
+                               tiles_touched, offsets, clamped, pairgrad, d_means3D, d_means2D, d_cov6, d_opacities, d_shs,
+                               d_colors, d_shs ? drgb : (float4*)nullptr);
+            if (d_shs) {
+                const bool fast = kp.M == 25 && kp.deg == 4, chm = (kp.flags & S360_FLAG_SH_CHANNEL_MAJOR) != 0;
+                const int wblk = (kp.P + 63) / 64;
+                const size_t wlds = (size_t)64 * kp.M * 3 * 4;
+                if (wlds > 64 * 1024) return S360_E_UNSUPPORTED;
+                if (chm && fast)
+                    hipLaunchKernelGGL((k_sh_bwd<true, true>), dim3(wblk), dim3(64), wlds, st, kp, views, means3D, shs, drgb, d_means3D, d_shs);
+                else if (chm)
+                    hipLaunchKernelGGL((k_sh_bwd<true, false>), dim3(wblk), dim3(64), wlds, st, kp, views, means3D, shs, drgb, d_means3D, d_shs);
+                else if (fast)
+                    hipLaunchKernelGGL((k_sh_bwd<false, true>), dim3(wblk), dim3(64), wlds, st, kp, views, means3D, shs, drgb, d_means3D, d_shs);
+                else
+                    hipLaunchKernelGGL((k_sh_bwd<false, false>), dim3(wblk), dim3(64), wlds, st, kp, views, means3D, shs, drgb, d_means3D, d_shs);
             }
+        } else {
+            size_t lds = (size_t)S360_BLOCK * kp.M * 3 * 4 + (size_t)S360_BLOCK * kp.V * 3 * 4;
+            if (lds > 160 * 1024) return S360_E_UNSUPPORTED;
+            {
+                static bool attr_done[64] = {};
+                int dev = 0;
+                if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !attr_done[dev]) {
+                    (void)hipFuncSetAttribute((const void*)k_preprocess_bwd<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    (void)hipGetLastError();
+                    attr_done[dev] = true;
+                }
+            }
+            hipLaunchKernelGGL((k_preprocess_bwd<true, true>), dim3(nblk), dim3(S360_BLOCK), lds, st, kp, views, means3D, cov6, shs,
+                               tiles_touched, offsets, clamped, pairgrad, d_means3D, d_means2D, d_cov6, d_opacities, d_shs,
+                               d_colors, (float4*)nullptr);
         }
-        hipLaunchKernelGGL(k_preprocess_bwd<true>, dim3(nblk), dim3(S360_BLOCK), lds, st, kp, views, means3D, cov6, shs,
-                           tiles_touched, offsets, clamped, pairgrad, d_means3D, d_means2D, d_cov6, d_opacities, d_shs,
-                           d_colors);
     } else {
-        hipLaunchKernelGGL(k_preprocess_bwd<false>, dim3(nblk), dim3(S360_BLOCK), 0, st, kp, views, means3D, cov6, shs,
+        hipLaunchKernelGGL((k_preprocess_bwd<false, false>), dim3(nblk), dim3(S360_BLOCK), 0, st, kp, views, means3D, cov6, shs,
                            tiles_touched, offsets, clamped, pairgrad, d_means3D, d_means2D, d_cov6, d_opacities, d_shs,
-                           d_colors);
+                           d_colors, (float4*)nullptr);
     }
     S360_CHECK_LAUNCH();
     return S360_OK;

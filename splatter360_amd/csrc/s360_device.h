@@ -151,6 +151,25 @@ __device__ __forceinline__ void load25(const float* __restrict__ p, float* c) {
     c[24] = p[24];
 }
 
+__device__ __forceinline__ void store15(float* __restrict__ p, const float* c) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        F4U v;
+        v.x = c[4 * i]; v.y = c[4 * i + 1]; v.z = c[4 * i + 2]; v.w = c[4 * i + 3];
+        *reinterpret_cast<F4U*>(p + 4 * i) = v;
+    }
+    p[12] = c[12]; p[13] = c[13]; p[14] = c[14];
+}
+__device__ __forceinline__ void store25(float* __restrict__ p, const float* c) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        F4U v;
+        v.x = c[4 * i]; v.y = c[4 * i + 1]; v.z = c[4 * i + 2]; v.w = c[4 * i + 3];
+        *reinterpret_cast<F4U*>(p + 4 * i) = v;
+    }
+    p[24] = c[24];
+}
+
 // Upper triangle (00,01,02,11,12,22) of Gaussian g's covariance from either layout.
 __device__ __forceinline__ void load_cov6(const float* __restrict__ cov, int g, bool cov9, float* c6) {
     if (cov9) {
