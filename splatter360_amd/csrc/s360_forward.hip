@@ -398,6 +398,94 @@ __global__ __launch_bounds__(THREADS) void k_sort_tiles(const uint32_t* __restri
 #endif
 }
 
+// Merge sort of one tile's bucket in LDS: every thread sorts E keys in registers (odd-even transposition
+// network), then log2(THREADS) merge passes; in each pass a thread finds its slice of the two runs being
+// merged with a merge-path binary search and merges E outputs serially.  ~2 barriers and ~(2E + log n)
+// LDS accesses per thread per pass — against log^2(n)/2 barriers and 4 accesses per compare-exchange of
+// the bitonic network.  Keys are unique, so the result is the one ascending order (== stable radix sort
+// by (tile, depth), index-ordered emission).  Measured alternatives that were slower on this workload:
+// 4-ary merge-path search + in-register bitonic merge of 2E candidates (more instructions; the kernel is
+// issue-bound on 64-bit compares/selects, not LDS-latency-bound), and the LDS radix sort below.
+template <int THREADS, int E>
+__global__ __launch_bounds__(THREADS) void k_sort_tiles_merge(const uint32_t* __restrict__ tile_start, uint64_t* __restrict__ keys,
+                                                             uint32_t* __restrict__ list, uint32_t lo, uint32_t cap) {
+    constexpr int CAP = THREADS * E;
+    // [CAP + CAP/E]: one pad slot per E keys.  Threads walk the runs with a stride of ~E (or ~E/2) keys;
+    // without the skew those 64 / 128-byte strides land on 4 / 2 bank groups (16- / 32-way conflicts).
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds_m[];
+#define S360_PHYS(i) ((i) + (i) / E)
+    const uint32_t s = min(tile_start[blockIdx.x], cap), e = min(tile_start[blockIdx.x + 1], cap);
+    const uint32_t n = e - s;
+    if (n <= lo || n > (uint32_t)CAP) return;
+    const int tid = threadIdx.x;
+    uint64_t k[E];
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+        const uint32_t i = (uint32_t)(tid * E + q);
+        k[q] = i < n ? keys[s + i] : ~0ull;
+    }
+    // in-register sort of the thread's E keys
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+#pragma unroll
+        for (int q = (r & 1); q + 1 < E; q += 2) {
+            const uint64_t a = k[q], b = k[q + 1];
+            k[q] = a < b ? a : b;
+            k[q + 1] = a < b ? b : a;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < E; ++q) lds_m[S360_PHYS((uint32_t)(tid * E + q))] = k[q];
+    __syncthreads();
+    // runs of length `width` are sorted; merge neighbouring pairs until one run remains.  Runs that lie
+    // entirely in the padding (start >= n) never need merging, so stop once width covers n.
+    uint32_t npad = E;
+    while (npad < n) npad <<= 1;
+    for (uint32_t width = E; width < npad; width <<= 1) {
+        const uint32_t out0 = (uint32_t)tid * E;                  // first output element of this thread
+        const uint32_t pair = out0 / (2 * width) * (2 * width);   // start of the run pair
+        const uint32_t pa = pair, pb = pair + width;              // run starts (logical indices)
+#define S360_A(x) lds_m[S360_PHYS(pa + (x))]
+#define S360_B(x) lds_m[S360_PHYS(pb + (x))]
+        const uint32_t diag = out0 - pair;
+        uint32_t lo_a = diag > width ? diag - width : 0u, hi_a = diag < width ? diag : width;
+        while (lo_a < hi_a) {  // merge path: first a with A[a] > B[diag-1-a]
+            const uint32_t mid = (lo_a + hi_a) >> 1;
+            if (S360_A(mid) <= S360_B(diag - 1 - mid)) lo_a = mid + 1; else hi_a = mid;
+        }
+        uint32_t a = lo_a, b = diag - lo_a;
+        uint64_t ka = a < width ? S360_A(a) : ~0ull, kb = b < width ? S360_B(b) : ~0ull;
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+            const bool take_a = ka <= kb;
+            k[q] = take_a ? ka : kb;
+            if (take_a) {
+                ++a;
+                ka = a < width ? S360_A(a) : ~0ull;
+            } else {
+                ++b;
+                kb = b < width ? S360_B(b) : ~0ull;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < E; ++q) lds_m[S360_PHYS(out0 + q)] = k[q];
+        __syncthreads();
+#undef S360_A
+#undef S360_B
+    }
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+        const uint32_t i = (uint32_t)(tid * E + q);
+        if (i < n) {
+            const uint64_t kq = lds_m[S360_PHYS(i)];
+            keys[s + i] = kq;
+            list[s + i] = (uint32_t)kq;
+        }
+    }
+#undef S360_PHYS
+}
+
 // LDS radix sort of one tile's bucket: LSD, 4-bit digits over the 32 depth bits (passes whose digit is
 // constant over the tile are skipped), E contiguous keys per thread so every pass is stable.  ~6x less
 // LDS traffic than the bitonic network for the common 1-4 K lists.  The low 32 bits (pair index) only
@@ -797,7 +885,7 @@ static void ensure_func_attributes() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || done[dev]) return;
     hipError_t e1 = hipFuncSetAttribute((const void*)k_sort_tiles<16384, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipError_t e2 = hipFuncSetAttribute((const void*)k_sort_tiles_radix<512, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e2 = hipFuncSetAttribute((const void*)k_sort_tiles_merge<1024, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (getenv("S360_DEBUG")) fprintf(stderr, "s360: set attr %s / %s\n", hipGetErrorString(e1), hipGetErrorString(e2));
     (void)hipGetLastError();
     done[dev] = true;
@@ -951,18 +1039,35 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
         // The few very long lists (polar tiles, > 4096 entries) take ~150 us each but occupy < 100 CUs:
         // fork them onto a side stream so they overlap with the ~1.5 K short lists on the main stream.
         SideStream* ss = side_stream();
-        if (ss) {
-            (void)hipEventRecord(ss->fork, st);
-            (void)hipStreamWaitEvent(ss->stream, ss->fork, 0);
-            hipLaunchKernelGGL((k_sort_tiles<16384, 1024>), dim3(nt), dim3(1024), 16384 * 8, ss->stream, tile_start, keys, list, 4096u, kp.cap, tile_cursor);
-            (void)hipEventRecord(ss->join, ss->stream);
+        const bool bitonic = getenv("S360_SORT_BITONIC") != nullptr;
+        if (bitonic) {
+            if (ss) {
+                (void)hipEventRecord(ss->fork, st);
+                (void)hipStreamWaitEvent(ss->stream, ss->fork, 0);
+                hipLaunchKernelGGL((k_sort_tiles<16384, 1024>), dim3(nt), dim3(1024), 16384 * 8, ss->stream, tile_start, keys, list, 4096u, kp.cap, tile_cursor);
+                (void)hipEventRecord(ss->join, ss->stream);
+            }
+            hipLaunchKernelGGL((k_sort_tiles<1024, 256>), dim3(nt), dim3(256), 1024 * 8, st, tile_start, keys, list, 0u, kp.cap, tile_cursor);
+            hipLaunchKernelGGL((k_sort_tiles<4096, 512>), dim3(nt), dim3(512), 4096 * 8, st, tile_start, keys, list, 1024u, kp.cap, tile_cursor);
+            if (ss)
+                (void)hipStreamWaitEvent(st, ss->join, 0);
+            else
+                hipLaunchKernelGGL((k_sort_tiles<16384, 1024>), dim3(nt), dim3(1024), 16384 * 8, st, tile_start, keys, list, 4096u, kp.cap, tile_cursor);
+        } else {
+            // merge-sort classes; the few > 4096-entry lists go to the side stream and overlap with the rest
+            if (ss) {
+                (void)hipEventRecord(ss->fork, st);
+                (void)hipStreamWaitEvent(ss->stream, ss->fork, 0);
+                hipLaunchKernelGGL((k_sort_tiles_merge<1024, 16>), dim3(nt), dim3(1024), (16384 + 1024) * 8, ss->stream, tile_start, keys, list, 4096u, kp.cap);
+                (void)hipEventRecord(ss->join, ss->stream);
+            }
+            hipLaunchKernelGGL((k_sort_tiles_merge<256, 8>), dim3(nt), dim3(256), (2048 + 256) * 8, st, tile_start, keys, list, 0u, kp.cap);
+            hipLaunchKernelGGL((k_sort_tiles_merge<512, 8>), dim3(nt), dim3(512), (4096 + 512) * 8, st, tile_start, keys, list, 2048u, kp.cap);
+            if (ss)
+                (void)hipStreamWaitEvent(st, ss->join, 0);
+            else
+                hipLaunchKernelGGL((k_sort_tiles_merge<1024, 16>), dim3(nt), dim3(1024), (16384 + 1024) * 8, st, tile_start, keys, list, 4096u, kp.cap);
         }
-        hipLaunchKernelGGL((k_sort_tiles<1024, 256>), dim3(nt), dim3(256), 1024 * 8, st, tile_start, keys, list, 0u, kp.cap, tile_cursor);
-        hipLaunchKernelGGL((k_sort_tiles<4096, 512>), dim3(nt), dim3(512), 4096 * 8, st, tile_start, keys, list, 1024u, kp.cap, tile_cursor);
-        if (ss)
-            (void)hipStreamWaitEvent(st, ss->join, 0);
-        else
-            hipLaunchKernelGGL((k_sort_tiles<16384, 1024>), dim3(nt), dim3(1024), 16384 * 8, st, tile_start, keys, list, 4096u, kp.cap, tile_cursor);
         hipLaunchKernelGGL(k_sort_tiles_global, dim3(nt), dim3(S360_BLOCK), 0, st, tile_start, keys, list, 16384u, kp.cap);
         S360_CHECK_LAUNCH();
     }
