@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define S360_ABI_VERSION 5
+#define S360_ABI_VERSION 6
 #define S360_MAX_VIEWS 8
 #define S360_TILE 16
 
@@ -162,6 +162,26 @@ int s360_backward(const S360Params* prm, const S360View* views, const float* mea
                   const float* dL_dimages, float* d_means3D, float* d_means2D, float* d_cov6,
                   float* d_opacities, float* d_shs, float* d_colors, void* bwd_workspace,
                   size_t bwd_workspace_bytes, void* stream);
+
+/*
+ * Split backward for multi-GPU view sharding (no reference counterpart: the reference all-reduces encoder
+ * parameters under DDP, src/main.py:117-130).  dL/dSH of one rendered panorama is, per Gaussian, the rank-1
+ * product Y(dir) (x) dL/dRGB; summing it over N ranks by all-reducing N full 300-byte slabs moves 25x more
+ * bytes than exchanging the factors.  s360_backward_split() is s360_backward() for views sharing one camera
+ * centre (S360_FLAG_SHARED_CAMPOS) WITHOUT the SH pass: it returns d_means3D (without the view-direction
+ * term), d_cov6, d_opacities and d_rgb_sum[P,4] = (clamp-masked sum of dL/dRGB, index of the first view that
+ * saw the Gaussian or -1 as int32 bits).  After all-gathering d_rgb_sum (with .w rewritten to the index of the
+ * owning rank's representative view, or -1) and one S360View per rank, s360_sh_backward() produces the summed
+ * dL/dSH and adds every rank's view-direction term to d_means3D (already all-reduced).
+ */
+int s360_backward_split(const S360Params* prm, const S360View* views, const float* means3D,
+                        const float* cov6, const float* opacities, const float* shs,
+                        const void* workspace, size_t workspace_bytes, const float* dL_dimages,
+                        float* d_means3D, float* d_means2D, float* d_cov6, float* d_opacities,
+                        float* d_rgb_sum, void* bwd_workspace, size_t bwd_workspace_bytes, void* stream);
+int s360_sh_backward(const S360Params* prm, int32_t n_groups, const S360View* views,
+                     const float* means3D, const float* shs, const float* d_rgb_sums /* [n_groups,P,4] */,
+                     float* d_means3D_inout, float* d_shs, void* stream);
 
 /*
  * Cube -> equirectangular stitch: replaces Cube2Equirec.forward

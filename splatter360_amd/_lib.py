@@ -23,7 +23,7 @@ FLAG_SHARED_CAMPOS = 1
 FLAG_COV9 = 2
 FLAG_SH_CHANNEL_MAJOR = 4
 FLAG_FORWARD_ONLY = 8
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class S360Params(C.Structure):
@@ -39,7 +39,7 @@ class S360Layout(C.Structure):
         "tile_max_contrib", "strip_last", "backward_bytes")]
 
 
-EXPORTS = ("s360_abi_version", "s360_error_string", "s360_layout", "s360_forward", "s360_forward_depth", "s360_backward",
+EXPORTS = ("s360_abi_version", "s360_error_string", "s360_layout", "s360_forward", "s360_forward_depth", "s360_backward", "s360_backward_split", "s360_sh_backward",
            "s360_cube2erp_forward", "s360_cube2erp_backward", "s360_profile_slots", "s360_profile_slot_name",
            "s360_profile_enable", "s360_profile_collect")
 
@@ -99,6 +99,10 @@ def lib() -> C.CDLL:
     l.s360_forward_depth.argtypes = [C.POINTER(S360Params)] + [vp] * 8 + [i32, vp, vp, sz, vp]
     l.s360_backward.restype = C.c_int
     l.s360_backward.argtypes = [C.POINTER(S360Params)] + [vp] * 7 + [sz] + [vp] * 8 + [sz, vp]
+    l.s360_backward_split.restype = C.c_int
+    l.s360_backward_split.argtypes = [C.POINTER(S360Params)] + [vp] * 6 + [sz] + [vp] * 7 + [sz, vp]
+    l.s360_sh_backward.restype = C.c_int
+    l.s360_sh_backward.argtypes = [C.POINTER(S360Params), i32] + [vp] * 7
     l.s360_cube2erp_forward.restype = C.c_int
     l.s360_cube2erp_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(C.c_int64), vp]
     l.s360_cube2erp_backward.restype = C.c_int

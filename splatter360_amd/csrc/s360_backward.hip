@@ -509,7 +509,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess_bwd(
 // writes (lane-strided stores of partial lines cost ~2x here).
 template <bool CH_MAJOR, bool FAST>  // FAST: degree 4, 25 stored coefficients (the reference's configuration)
 __global__ __launch_bounds__(64) void k_sh_bwd(KParams kp, const S360View* __restrict__ views, const float* __restrict__ means,
-                                              const float* __restrict__ shs, const float4* __restrict__ drgb_in,
+                                              const float* __restrict__ shs, const float4* __restrict__ drgb_in, int n_groups,
                                               float* __restrict__ d_means3D, float* __restrict__ d_shs) {
     extern __shared__ __attribute__((aligned(16))) float lds_o[];  // [64][M*3]
     const int lane = threadIdx.x;
@@ -519,12 +519,19 @@ __global__ __launch_bounds__(64) void k_sh_bwd(KParams kp, const S360View* __res
     float* mine = lds_o + lane * slab;
     const int deg = FAST ? 4 : kp.deg;
     const int n_sh = (deg + 1) * (deg + 1);
+    // n_groups (view, summed dL/dRGB) pairs per Gaussian: 1 for a local backward; N when the factors of the
+    // rank-1 products Y (x) dRGB of N ranks were all-gathered instead of all-reducing N full SH gradients.
     if (g < kp.P) {
-        const float4 dr = drgb_in[g];
-        const int fv = __float_as_int(dr.w);
-        if (fv < 0) {  // invisible in every view: zero gradient
-            for (int k = 0; k < slab; ++k) mine[k] = 0.f;
-        } else {
+        for (int k = 0; k < slab; ++k) mine[k] = 0.f;
+        const float* sh = shs + (size_t)g * slab;
+        float dm0 = 0.f, dm1 = 0.f, dm2 = 0.f;
+        bool any = false;
+#pragma unroll 1
+        for (int j = 0; j < n_groups; ++j) {
+            const float4 dr = drgb_in[(size_t)j * kp.P + g];
+            const int fv = __float_as_int(dr.w);
+            if (fv < 0) continue;  // invisible in that group's views: no contribution
+            any = true;
             const S360View& vw = views[fv];
             const float sc = vw.scale;
             const float ddx = means[3 * g] * sc - vw.campos[0], ddy = means[3 * g + 1] * sc - vw.campos[1],
@@ -533,7 +540,6 @@ __global__ __launch_bounds__(64) void k_sh_bwd(KParams kp, const S360View* __res
             const float x = ddx * inv, y = ddy * inv, z = ddz * inv;
             float Y[25], s[25];
             sh_basis(deg, x, y, z, Y);
-            const float* sh = shs + (size_t)g * slab;
             const float drc[3] = {dr.x, dr.y, dr.z};
             if (FAST && CH_MAJOR) {
 #pragma unroll
@@ -546,7 +552,7 @@ __global__ __launch_bounds__(64) void k_sh_bwd(KParams kp, const S360View* __res
 #pragma unroll
                     for (int k = 0; k < 25; ++k) {
                         s[k] += c[k] * d;
-                        mine[25 * ch + k] = Y[k] * d;
+                        mine[25 * ch + k] += Y[k] * d;
                     }
                 }
             } else if (FAST) {
@@ -557,9 +563,9 @@ __global__ __launch_bounds__(64) void k_sh_bwd(KParams kp, const S360View* __res
 #pragma unroll
                     for (int k = 0; k < 5; ++k) {
                         s[5 * q + k] = c[3 * k] * drc[0] + c[3 * k + 1] * drc[1] + c[3 * k + 2] * drc[2];
-                        mine[15 * q + 3 * k] = Y[5 * q + k] * drc[0];
-                        mine[15 * q + 3 * k + 1] = Y[5 * q + k] * drc[1];
-                        mine[15 * q + 3 * k + 2] = Y[5 * q + k] * drc[2];
+                        mine[15 * q + 3 * k] += Y[5 * q + k] * drc[0];
+                        mine[15 * q + 3 * k + 1] += Y[5 * q + k] * drc[1];
+                        mine[15 * q + 3 * k + 2] += Y[5 * q + k] * drc[2];
                     }
                 }
             } else {
@@ -568,12 +574,11 @@ __global__ __launch_bounds__(64) void k_sh_bwd(KParams kp, const S360View* __res
                 for (int k = 0; k < 25; ++k) {  // generic layout / degree (<= 25 active coefficients)
                     if (k < n_sh) {
                         s[k] = sh[k * sk] * drc[0] + sh[k * sk + sc_] * drc[1] + sh[k * sk + 2 * sc_] * drc[2];
-                        mine[k * sk] = Y[k] * drc[0];
-                        mine[k * sk + sc_] = Y[k] * drc[1];
-                        mine[k * sk + 2 * sc_] = Y[k] * drc[2];
+                        mine[k * sk] += Y[k] * drc[0];
+                        mine[k * sk + sc_] += Y[k] * drc[1];
+                        mine[k * sk + 2 * sc_] += Y[k] * drc[2];
                     }
                 }
-                for (int k = n_sh; k < kp.M; ++k) mine[k * sk] = mine[k * sk + sc_] = mine[k * sk + 2 * sc_] = 0.f;
             }
             float bx[25], by[25], bz[25];
             sh_basis_grad(deg, x, y, z, bx, by, bz);
@@ -587,9 +592,14 @@ __global__ __launch_bounds__(64) void k_sh_bwd(KParams kp, const S360View* __res
                 }
             }
             const float dot = x * q0 + y * q1 + z * q2;
-            d_means3D[3 * g] += sc * ((q0 - x * dot) * inv);
-            d_means3D[3 * g + 1] += sc * ((q1 - y * dot) * inv);
-            d_means3D[3 * g + 2] += sc * ((q2 - z * dot) * inv);
+            dm0 += sc * ((q0 - x * dot) * inv);
+            dm1 += sc * ((q1 - y * dot) * inv);
+            dm2 += sc * ((q2 - z * dot) * inv);
+        }
+        if (any) {
+            d_means3D[3 * g] += dm0;
+            d_means3D[3 * g + 1] += dm1;
+            d_means3D[3 * g + 2] += dm2;
         }
     }
     __syncthreads();  // single wave: orders the LDS writes above before the cooperative read below
@@ -620,11 +630,28 @@ using namespace s360;
         }                                                                                            \
     } while (0)
 
-extern "C" int s360_backward(const S360Params* prm, const S360View* views, const float* means3D, const float* cov6,
-                             const float* opacities, const float* shs, const float* colors_precomp,
-                             const void* workspace, size_t workspace_bytes, const float* dL_dimages, float* d_means3D,
-                             float* d_means2D, float* d_cov6, float* d_opacities, float* d_shs, float* d_colors,
-                             void* bwd_workspace, size_t bwd_workspace_bytes, void* stream_) {
+static int launch_sh_bwd(const KParams& kp, const S360View* views, const float* means3D, const float* shs,
+                         const float4* drgb, int n_groups, float* d_means3D, float* d_shs, hipStream_t st) {
+    const bool fast = kp.M == 25 && kp.deg == 4, chm = (kp.flags & S360_FLAG_SH_CHANNEL_MAJOR) != 0;
+    const int wblk = (kp.P + 63) / 64;
+    const size_t wlds = (size_t)64 * kp.M * 3 * 4;
+    if (wlds > 64 * 1024) return S360_E_UNSUPPORTED;
+    if (chm && fast)
+        hipLaunchKernelGGL((k_sh_bwd<true, true>), dim3(wblk), dim3(64), wlds, st, kp, views, means3D, shs, drgb, n_groups, d_means3D, d_shs);
+    else if (chm)
+        hipLaunchKernelGGL((k_sh_bwd<true, false>), dim3(wblk), dim3(64), wlds, st, kp, views, means3D, shs, drgb, n_groups, d_means3D, d_shs);
+    else if (fast)
+        hipLaunchKernelGGL((k_sh_bwd<false, true>), dim3(wblk), dim3(64), wlds, st, kp, views, means3D, shs, drgb, n_groups, d_means3D, d_shs);
+    else
+        hipLaunchKernelGGL((k_sh_bwd<false, false>), dim3(wblk), dim3(64), wlds, st, kp, views, means3D, shs, drgb, n_groups, d_means3D, d_shs);
+    return S360_OK;
+}
+
+static int backward_impl(const S360Params* prm, const S360View* views, const float* means3D, const float* cov6,
+                         const float* opacities, const float* shs, const float* colors_precomp,
+                         const void* workspace, size_t workspace_bytes, const float* dL_dimages, float* d_means3D,
+                         float* d_means2D, float* d_cov6, float* d_opacities, float* d_shs, float* d_colors,
+                         float* d_rgb_sum, void* bwd_workspace, size_t bwd_workspace_bytes, void* stream_) {
     (void)opacities;
     if (!prm || !views || !workspace || !dL_dimages || !bwd_workspace) return S360_E_BADARG;
     if (prm->flags & S360_FLAG_FORWARD_ONLY) return S360_E_BADARG;
@@ -690,26 +717,17 @@ extern "C" int s360_backward(const S360Params* prm, const S360View* views, const
                            tiles_touched, offsets, part, valid_words, pairgrad);
     }
     const int nblk = (kp.P + S360_BLOCK - 1) / S360_BLOCK;
-    float4* drgb = pairgrad + (size_t)kp.V * kp.P * 3;  // [P] summed dL/dRGB (+ first visible view) for k_sh_bwd
+    float4* drgb = d_rgb_sum ? (float4*)d_rgb_sum : pairgrad + (size_t)kp.V * kp.P * 3;  // [P] summed dL/dRGB (+ first visible view)
     if (shs) {
         const bool shared = (kp.flags & S360_FLAG_SHARED_CAMPOS) != 0;
+        if (d_rgb_sum && !shared) return S360_E_UNSUPPORTED;  // the split form needs one camera centre per call
         if (shared || !d_shs) {
             hipLaunchKernelGGL((k_preprocess_bwd<true, false>), dim3(nblk), dim3(S360_BLOCK), 0, st, kp, views, means3D, cov6, shs,
                                tiles_touched, offsets, clamped, pairgrad, d_means3D, d_means2D, d_cov6, d_opacities, d_shs,
-                               d_colors, d_shs ? drgb : (float4*)nullptr);
-            if (d_shs) {
-                const bool fast = kp.M == 25 && kp.deg == 4, chm = (kp.flags & S360_FLAG_SH_CHANNEL_MAJOR) != 0;
-                const int wblk = (kp.P + 63) / 64;
-                const size_t wlds = (size_t)64 * kp.M * 3 * 4;
-                if (wlds > 64 * 1024) return S360_E_UNSUPPORTED;
-                if (chm && fast)
-                    hipLaunchKernelGGL((k_sh_bwd<true, true>), dim3(wblk), dim3(64), wlds, st, kp, views, means3D, shs, drgb, d_means3D, d_shs);
-                else if (chm)
-                    hipLaunchKernelGGL((k_sh_bwd<true, false>), dim3(wblk), dim3(64), wlds, st, kp, views, means3D, shs, drgb, d_means3D, d_shs);
-                else if (fast)
-                    hipLaunchKernelGGL((k_sh_bwd<false, true>), dim3(wblk), dim3(64), wlds, st, kp, views, means3D, shs, drgb, d_means3D, d_shs);
-                else
-                    hipLaunchKernelGGL((k_sh_bwd<false, false>), dim3(wblk), dim3(64), wlds, st, kp, views, means3D, shs, drgb, d_means3D, d_shs);
+                               d_colors, (d_shs || d_rgb_sum) ? drgb : (float4*)nullptr);
+            if (d_shs && !d_rgb_sum) {
+                const int rc2 = launch_sh_bwd(kp, views, means3D, shs, drgb, 1, d_means3D, d_shs, st);
+                if (rc2) return rc2;
             }
         } else {
             size_t lds = (size_t)S360_BLOCK * kp.M * 3 * 4 + (size_t)S360_BLOCK * kp.V * 3 * 4;
@@ -732,6 +750,45 @@ extern "C" int s360_backward(const S360Params* prm, const S360View* views, const
                            tiles_touched, offsets, clamped, pairgrad, d_means3D, d_means2D, d_cov6, d_opacities, d_shs,
                            d_colors, (float4*)nullptr);
     }
+    S360_CHECK_LAUNCH();
+    return S360_OK;
+}
+
+extern "C" int s360_backward(const S360Params* prm, const S360View* views, const float* means3D, const float* cov6,
+                             const float* opacities, const float* shs, const float* colors_precomp,
+                             const void* workspace, size_t workspace_bytes, const float* dL_dimages, float* d_means3D,
+                             float* d_means2D, float* d_cov6, float* d_opacities, float* d_shs, float* d_colors,
+                             void* bwd_workspace, size_t bwd_workspace_bytes, void* stream_) {
+    return backward_impl(prm, views, means3D, cov6, opacities, shs, colors_precomp, workspace, workspace_bytes, dL_dimages,
+                         d_means3D, d_means2D, d_cov6, d_opacities, d_shs, d_colors, nullptr, bwd_workspace,
+                         bwd_workspace_bytes, stream_);
+}
+
+extern "C" int s360_backward_split(const S360Params* prm, const S360View* views, const float* means3D, const float* cov6,
+                                   const float* opacities, const float* shs, const void* workspace, size_t workspace_bytes,
+                                   const float* dL_dimages, float* d_means3D, float* d_means2D, float* d_cov6,
+                                   float* d_opacities, float* d_rgb_sum, void* bwd_workspace, size_t bwd_workspace_bytes,
+                                   void* stream_) {
+    if (!shs || !d_rgb_sum) return S360_E_BADARG;
+    return backward_impl(prm, views, means3D, cov6, opacities, shs, nullptr, workspace, workspace_bytes, dL_dimages, d_means3D,
+                         d_means2D, d_cov6, d_opacities, nullptr, nullptr, d_rgb_sum, bwd_workspace, bwd_workspace_bytes,
+                         stream_);
+}
+
+extern "C" int s360_sh_backward(const S360Params* prm, int32_t n_groups, const S360View* views, const float* means3D,
+                                const float* shs, const float* d_rgb_sums, float* d_means3D_inout, float* d_shs,
+                                void* stream_) {
+    if (!prm || !views || !means3D || !shs || !d_rgb_sums || !d_means3D_inout || !d_shs || n_groups < 1) return S360_E_BADARG;
+    if (prm->M < 1 || prm->sh_degree < 0 || prm->sh_degree > 4 || (prm->sh_degree + 1) * (prm->sh_degree + 1) > prm->M)
+        return S360_E_BADARG;
+    if (prm->P == 0) return S360_OK;
+    KParams kp;
+    kp.P = prm->P; kp.V = prm->V; kp.H = prm->H; kp.W = prm->W; kp.deg = prm->sh_degree; kp.M = prm->M;
+    kp.gx = kp.gy = kp.T = 0;
+    kp.flags = prm->flags; kp.cap = prm->max_instances;
+    const int rc = launch_sh_bwd(kp, views, means3D, shs, (const float4*)d_rgb_sums, n_groups, d_means3D_inout, d_shs,
+                                 (hipStream_t)stream_);
+    if (rc) return rc;
     S360_CHECK_LAUNCH();
     return S360_OK;
 }

@@ -182,7 +182,7 @@ def render_views_fused(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far
                        background: Tensor, gaussian_means: Tensor, gaussian_covariances: Tensor,
                        gaussian_sh_coefficients: Tensor, gaussian_opacities: Tensor, *, shared_campos: bool = True,
                        max_instances: Optional[int] = None, check: str = "sync", views: Optional[Tensor] = None,
-                       depth_mode: Optional[DepthRenderingMode] = None):
+                       depth_mode: Optional[DepthRenderingMode] = None, defer_sh: bool = False):
     """V <= 8 views of ONE cloud in one fused rasteriser call: means[G,3], covariances[G,3,3],
     harmonics[G,3,d_sh] (the reference's Gaussians layout, src/model/types.py:7-12, read in place),
     opacities[G] -> [V,3,h,w].  With the six face cameras of a panorama (shared_campos=True: one camera
@@ -196,7 +196,8 @@ def render_views_fused(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far
     out = rasterizer.rasterize_views(
         gaussian_means, gaussian_covariances, gaussian_opacities, gaussian_sh_coefficients, None, views=views,
         image_height=h, image_width=w, sh_degree=isqrt(n) - 1, shared_campos=shared_campos, want_radii=False,
-        max_instances=max_instances, check=check, cov9=True, sh_channel_major=True, depth_mode=depth_mode)
+        max_instances=max_instances, check=check, cov9=True, sh_channel_major=True, depth_mode=depth_mode,
+        defer_sh=defer_sh)
     return out[0] if depth_mode is None else (out[0], out[2])
 
 

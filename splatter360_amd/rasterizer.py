@@ -145,7 +145,8 @@ class _RasterizeViews(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, cov6, views, cfg):
-        h, w, sh_degree, shared_campos, max_instances, check, want_radii, cov9, sh_channel_major, keep_offsets, depth_mode = cfg
+        (h, w, sh_degree, shared_campos, max_instances, check, want_radii, cov9, sh_channel_major, keep_offsets, depth_mode,
+         defer_sh) = cfg
         if not means3D.is_cuda:
             raise RuntimeError("means3D must live on the GPU (hip device); the rasteriser has no CPU path")
         with torch.cuda.device(means3D.device):
@@ -174,6 +175,7 @@ class _RasterizeViews(torch.autograd.Function):
                 prm.max_instances = state.num_rendered()
                 images, radii, state, depth = _forward_call(prm, vw, m3, c6, op, sh, col, want_radii, depth_mode)
         ctx.state = state
+        ctx.defer_sh = bool(defer_sh) and sh is not None
         ctx.has_means2D = means2D is not None
         ctx.save_for_backward(m3, c6, op, sh, col, vw)
         _RasterizeViews.last_state = state
@@ -202,6 +204,18 @@ class _RasterizeViews(torch.autograd.Function):
             d_col = torch.empty((p, 3), dtype=torch.float32, device=dev) if (col is not None and need[3]) else None
             bws = torch.empty(lay.backward_bytes, dtype=torch.uint8, device=dev)
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            if ctx.defer_sh:
+                # multi-GPU factored form: no SH pass here; the caller exchanges d_rgb_sum and finishes with
+                # finish_deferred_sh() (see distributed.sync_gradients_factored)
+                d_rgb = torch.empty((p, 4), dtype=torch.float32, device=dev)
+                rc = _lib.lib().s360_backward_split(
+                    C.byref(prm), _ptr(vw), _ptr(m3), _ptr(c6), _ptr(op), _ptr(sh), _ptr(state.workspace), lay.total_bytes,
+                    _ptr(g), _ptr(d_m3), _ptr(d_m2), _ptr(d_c6), _ptr(d_op), _ptr(d_rgb), _ptr(bws), lay.backward_bytes, stream)
+                _lib.check(rc, "s360_backward_split")
+                _RasterizeViews.last_deferred = DeferredSH(prm, vw, m3, sh, d_rgb)
+                if d_m2 is not None:
+                    d_m2 = d_m2.sum(0) if v > 1 else d_m2[0]
+                return d_m3, d_m2, None, None, d_op.view(-1, 1), d_c6, None, None
             rc = _lib.lib().s360_backward(
                 C.byref(prm), _ptr(vw), _ptr(m3), _ptr(c6), _ptr(op), _ptr(sh), _ptr(col), _ptr(state.workspace),
                 lay.total_bytes, _ptr(g), _ptr(d_m3), _ptr(d_m2), _ptr(d_c6), _ptr(d_op), _ptr(d_sh), _ptr(d_col),
@@ -213,6 +227,34 @@ class _RasterizeViews(torch.autograd.Function):
 
 
 _RasterizeViews.last_state = None
+_RasterizeViews.last_deferred = None
+
+
+class DeferredSH:
+    """What a deferred-SH backward leaves behind: the S360Params, the packed views, the inputs the SH pass
+    needs and d_rgb_sum[P,4] (xyz = clamp-masked sum of dL/dRGB over this call's views, w = int32 bits of the
+    first view that saw the Gaussian, -1 if none)."""
+
+    def __init__(self, prm, views, means3D, shs, d_rgb_sum):
+        self.prm, self.views, self.means3D, self.shs, self.d_rgb_sum = prm, views, means3D, shs, d_rgb_sum
+
+
+def last_deferred() -> Optional[DeferredSH]:
+    return _RasterizeViews.last_deferred
+
+
+def finish_deferred_sh(prm, views: Tensor, means3D: Tensor, shs: Tensor, d_rgb_sums: Tensor, d_means3D: Tensor) -> Tensor:
+    """s360_sh_backward: views[n,44] (one representative camera per group), d_rgb_sums[n,P,4] with .w = the
+    group's index into `views` (int32 bits) or -1.  Adds the view-direction terms to d_means3D in place and
+    returns dL/dSH (same layout as shs)."""
+    d_sh = torch.empty_like(shs)
+    n = int(d_rgb_sums.shape[0])
+    with torch.cuda.device(shs.device):
+        stream = C.c_void_p(torch.cuda.current_stream(shs.device).cuda_stream)
+        rc = _lib.lib().s360_sh_backward(C.byref(prm), n, _ptr(views.contiguous()), _ptr(means3D), _ptr(shs),
+                                         _ptr(d_rgb_sums.contiguous()), _ptr(d_means3D), _ptr(d_sh), stream)
+    _lib.check(rc, "s360_sh_backward")
+    return d_sh
 
 
 def rasterize_views(means3D: Tensor, cov6: Tensor, opacities: Tensor, shs: Optional[Tensor] = None,
@@ -220,12 +262,14 @@ def rasterize_views(means3D: Tensor, cov6: Tensor, opacities: Tensor, shs: Optio
                     sh_degree: int = 0, shared_campos: bool = False, max_instances: Optional[int] = None,
                     check: str = "sync", want_radii: bool = True, means2D: Optional[Tensor] = None,
                     cov9: bool = False, sh_channel_major: bool = False, keep_offsets: bool = False,
-                    depth_mode: Optional[str] = None):
+                    depth_mode: Optional[str] = None, defer_sh: bool = False):
     """Render V views ([V,44] packed, see pack_views) of one cloud.  cov9: cov6 is [P,3,3];
     sh_channel_major: shs is [P,3,M] (the reference's Gaussians layouts, consumed without copies).
     When no input requires grad the per-pair offsets scan (backward-only state) is skipped unless
     keep_offsets=True.  depth_mode ("depth" | "disparity" | "relative_disparity" | "log"): also return the
-    fused depth map [V,H,W] of render_depth_cuda as a third result (no gradient; needs near / far in `views`).  Returns (images[V,3,H,W],
+    fused depth map [V,H,W] of render_depth_cuda as a third result (no gradient; needs near / far in `views`).
+    defer_sh=True (views sharing one camera centre): the backward skips the SH pass, returns no gradient for
+    `shs` and leaves a DeferredSH (last_deferred()) for distributed.sync_gradients_factored.  Returns (images[V,3,H,W],
     radii[V,P] int32).  opacities may be [P] or [P,1]; its gradient has the same shape.
     check="sync": read the overflow flag after the forward (one host sync, like upstream's own
     scan read-back) and re-run with the exact size if the binning capacity was exceeded;
@@ -236,7 +280,7 @@ def rasterize_views(means3D: Tensor, cov6: Tensor, opacities: Tensor, shs: Optio
     if depth_mode is not None and depth_mode not in DEPTH_MODES:
         raise ValueError(f"depth_mode must be one of {sorted(DEPTH_MODES)}")
     cfg = (image_height, image_width, sh_degree, shared_campos, max_instances, check, want_radii, cov9,
-           sh_channel_major, keep_offsets, depth_mode)
+           sh_channel_major, keep_offsets, depth_mode, defer_sh)
     images, radii, depth = _RasterizeViews.apply(means3D, means2D, shs, colors_precomp, op2, cov6, views, cfg)
     return (images, radii) if depth_mode is None else (images, radii, depth)
 

@@ -1,0 +1,126 @@
+"""Factored multi-GPU gradient exchange (s360_backward_split + s360_sh_backward,
+distributed.sync_gradients_factored) against the plain "all-reduce everything" path: same gradients up to
+float summation order, checked (a) in one process by playing both ranks, (b) with two gloo processes sharing
+the one GPU of the box."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+POSITIONS = ((0.0, 0.0, 0.0), (0.35, -0.1, 0.2))
+
+
+def _cloud(dev, w=128, seed=3):
+    from splatter360_amd import synthetic
+    cloud = synthetic.encoder_like_cloud(w // 2, w, seed=seed)
+    return [torch.tensor(cloud[k], device=dev).requires_grad_(True) for k in ("means", "covariances", "harmonics", "opacities")]
+
+
+def _cams(dev, pos):
+    from splatter360_amd import decoder, synthetic
+    pano = torch.from_numpy(synthetic.target_pano_pose(pos)).to(dev)
+    return decoder.cube_cameras(pano, 0.1, 10.0)
+
+
+def _render_backward(dev, ps, pos, seed, defer):
+    from splatter360_amd import decoder, rasterizer
+    ext, K, near, far = _cams(dev, pos)
+    faces = decoder.render_views_fused(ext, K, near, far, (64, 64), torch.zeros(3, device=dev), *ps, defer_sh=defer)
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    faces.backward(torch.randn(faces.shape, generator=g).to(dev))
+    return rasterizer.last_deferred() if defer else None
+
+
+def _close(a, b, tol=2e-5):
+    scale = b.abs().max().item() + 1e-20
+    assert (a - b).abs().max().item() / scale <= tol
+
+
+def test_factored_equals_plain_sum_single_process(gpu):
+    from splatter360_amd import rasterizer
+    ps = _cloud(gpu)
+    for r, pos in enumerate(POSITIONS):          # plain: autograd accumulates both "ranks"
+        _render_backward(gpu, ps, pos, 10 + r, False)
+    want = [p.grad.clone() for p in ps]
+    for p in ps:
+        p.grad = None
+    defs = [_render_backward(gpu, ps, pos, 10 + r, True) for r, pos in enumerate(POSITIONS)]
+    assert ps[2].grad is None                     # SH gradient deferred
+    rgbs = []
+    for r, d in enumerate(defs):
+        rgb = d.d_rgb_sum.clone()
+        w = rgb[:, 3].view(torch.int32)
+        assert bool(((w >= -1) & (w < 6)).all())
+        rgb[:, 3] = torch.where(w >= 0, torch.full_like(w, r), torch.full_like(w, -1)).view(torch.float32)
+        rgbs.append(rgb)
+    views = torch.stack([d.views[0] for d in defs])
+    d_sh = rasterizer.finish_deferred_sh(defs[0].prm, views, defs[0].means3D, defs[0].shs, torch.stack(rgbs), ps[0].grad)
+    _close(d_sh, want[2])
+    _close(ps[0].grad, want[0])
+    _close(ps[1].grad, want[1])
+    _close(ps[3].grad, want[3])
+
+
+def test_world_size_one_sync(gpu):
+    from splatter360_amd import distributed as D
+    ps = _cloud(gpu)
+    _render_backward(gpu, ps, POSITIONS[1], 5, False)
+    want = [p.grad.clone() for p in ps]
+    for p in ps:
+        p.grad = None
+    d = _render_backward(gpu, ps, POSITIONS[1], 5, True)
+    D.sync_gradients_factored(*ps, d)
+    for p, w in zip(ps, want):
+        _close(p.grad, w, 1e-6)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    sys.path[:0] = [str(root), str(root / "tests")]
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), S360_DIST_BACKEND="gloo", S360_FORCE_DEVICE="0")
+    from splatter360_amd import distributed as D
+    D.init()
+    dev = torch.device("cuda:0")
+    ps = _cloud(dev)
+    _render_backward(dev, ps, POSITIONS[rank], 10 + rank, False)
+    D.allreduce_gradients([p.grad for p in ps])
+    plain = [p.grad.clone() for p in ps]
+    for p in ps:
+        p.grad = None
+    d = _render_backward(dev, ps, POSITIONS[rank], 10 + rank, True)
+    D.sync_gradients_factored(*ps, d)
+    err = []
+    for p, w in zip(ps, plain):
+        err.append((p.grad - w).abs().max().item() / (w.abs().max().item() + 1e-20))
+    q.put((rank, err, float(plain[2].abs().sum().item())))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_factored_sync_gloo_on_one_gpu(gpu):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    outs = [q.get(timeout=600) for _ in range(world)]
+    [p.join(timeout=120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    for rank, err, mass in outs:
+        assert mass > 0
+        assert max(err) <= 2e-5, (rank, err)
