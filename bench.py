@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--pano-h", type=int, default=512, help="context/target ERP height (width = 2h)")
     ap.add_argument("--face", type=int, default=0, help="cube face size (default pano_h/2)")
     ap.add_argument("--cpu-baseline", type=int, default=1)
+    ap.add_argument("--fused-loss", type=int, default=1, help="1: L2 loss + its gradient seed fused into the render epilogue; "
+                    "0: the reference's torch ops on the rendered faces")
     ap.add_argument("--grad-sync", choices=("factored", "allreduce"), default="factored",
                     help="N>1 gradient exchange: factored (default) or one all-reduce of the full 352 B/Gaussian set")
     return ap.parse_args()
@@ -123,11 +125,16 @@ def main():
         for p in params:
             p.grad = None
         views = cams.pack(ext, K, near, far, bg)  # camera glue of this step, overlapped on a side stream
-        faces = decoder.render_views_fused(ext, K, near, far, (face_w, face_w), bg, *params, check="lazy", views=views,
-                                           defer_sh=factored)
+        if a.mode == "fwdbwd" and a.fused_loss:   # LossMse fused into the composite store
+            faces, fm = decoder.render_views_fused(ext, K, near, far, (face_w, face_w), bg, *params, check="lazy", views=views,
+                                                   defer_sh=factored, mse_target=gt)
+            loss = fm.loss
+        else:
+            faces = decoder.render_views_fused(ext, K, near, far, (face_w, face_w), bg, *params, check="lazy", views=views,
+                                               defer_sh=factored)
+            loss = ((faces - gt) ** 2).mean() if a.mode == "fwdbwd" else None
         out["erp"] = c2e.stitch_rendered(faces.detach())
         if a.mode == "fwdbwd":
-            loss = ((faces - gt) ** 2).mean()
             loss.backward()
             if factored:   # all-reduce 52 B/Gaussian + all-gather 16 B/Gaussian/rank, SH gradient rebuilt locally
                 distributed.sync_gradients_factored(*params, rasterizer.last_deferred())
@@ -206,7 +213,8 @@ def main():
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[2]: {G} encoder-like synthetic Gaussians (seed 0, deg-4 SH), "
-                               f"{pano_w}x{pano_h} ERP = 6 faces {face_w}x{face_w} + stitch, {a.mode}, L2 loss on faces",
+                               f"{pano_w}x{pano_h} ERP = 6 faces {face_w}x{face_w} + stitch, {a.mode}, L2 loss on faces"
+                               + (" (fused epilogue)" if a.mode == "fwdbwd" and a.fused_loss else ""),
                    "gaussians": G, "erp": [pano_w, pano_h], "face": face_w, "views_per_gpu": 1,
                    "parallelism": f"view-sharded x{world}" + ((", RCCL factored grad exchange (all-reduce 52 B/G + all-gather dRGB 16 B/G/rank)" if factored else
                                                                   ", RCCL all-reduce of Gaussian grads") if world > 1 and a.mode == "fwdbwd" else ""),

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define S360_ABI_VERSION 6
+#define S360_ABI_VERSION 7
 #define S360_MAX_VIEWS 8
 #define S360_TILE 16
 
@@ -145,6 +145,22 @@ int s360_forward_depth(const S360Params* prm, const S360View* views, const float
                        const float* cov6, const float* opacities, const float* shs,
                        const float* colors_precomp, float* images, float* depth_maps, int32_t depth_mode,
                        int32_t* radii, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Forward with the cube-face loss epilogue fused into the composite store: replaces the
+ * torch ops the reference runs on the rendered faces right after the decoder —
+ *   LossMse.forward       src/loss/loss_mse.py:30-31   weight * mean((color - target)^2)
+ *   compute_psnr          src/evaluation/metrics.py:11-21   -10 log10(mean((clip01(gt) - clip01(pred))^2))
+ * and the loss's autograd seed.  target[V,3,H,W]; d_images[V,3,H,W] = grad_scale * (image - target) (pass
+ * grad_scale = 2*weight/N, N = elements averaged over); partials[V*tiles*4, 2] = per 16x4 strip (in tile
+ * order, strips top to bottom) the sums of squared differences, plain and clipped — summed in a fixed order
+ * by the caller (deterministic).  depth_maps may be null (no depth channel).
+ */
+int s360_forward_mse(const S360Params* prm, const S360View* views, const float* means3D,
+                     const float* cov6, const float* opacities, const float* shs,
+                     const float* colors_precomp, float* images, float* depth_maps, int32_t depth_mode,
+                     int32_t* radii, const float* target, float grad_scale, float* d_images, float* partials,
+                     void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * Backward: replaces upstream `rasterize_gaussians_backward(...)` (autograd backward of the

@@ -23,7 +23,7 @@ FLAG_SHARED_CAMPOS = 1
 FLAG_COV9 = 2
 FLAG_SH_CHANNEL_MAJOR = 4
 FLAG_FORWARD_ONLY = 8
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class S360Params(C.Structure):
@@ -39,7 +39,7 @@ class S360Layout(C.Structure):
         "tile_max_contrib", "strip_last", "backward_bytes")]
 
 
-EXPORTS = ("s360_abi_version", "s360_error_string", "s360_layout", "s360_forward", "s360_forward_depth", "s360_backward", "s360_backward_split", "s360_sh_backward",
+EXPORTS = ("s360_abi_version", "s360_error_string", "s360_layout", "s360_forward", "s360_forward_depth", "s360_forward_mse", "s360_backward", "s360_backward_split", "s360_sh_backward",
            "s360_cube2erp_forward", "s360_cube2erp_backward", "s360_profile_slots", "s360_profile_slot_name",
            "s360_profile_enable", "s360_profile_collect")
 
@@ -97,6 +97,8 @@ def lib() -> C.CDLL:
     l.s360_forward.argtypes = [C.POINTER(S360Params)] + [vp] * 9 + [sz, vp]
     l.s360_forward_depth.restype = C.c_int
     l.s360_forward_depth.argtypes = [C.POINTER(S360Params)] + [vp] * 8 + [i32, vp, vp, sz, vp]
+    l.s360_forward_mse.restype = C.c_int
+    l.s360_forward_mse.argtypes = [C.POINTER(S360Params)] + [vp] * 8 + [i32, vp, vp, C.c_float, vp, vp, vp, sz, vp]
     l.s360_backward.restype = C.c_int
     l.s360_backward.argtypes = [C.POINTER(S360Params)] + [vp] * 7 + [sz] + [vp] * 8 + [sz, vp]
     l.s360_backward_split.restype = C.c_int

@@ -507,7 +507,15 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess_bwd(
 // summed dL/dRGB, computes dL/dSH = Y_k * dRGB_c and the view-direction term of dL/dmean; the 64 output
 // slabs (19.2 KB, contiguous in memory) go through LDS so the global stores are fully coalesced 16-byte
 // writes (lane-strided stores of partial lines cost ~2x here).
-template <bool CH_MAJOR, bool FAST>  // FAST: degree 4, 25 stored coefficients (the reference's configuration)
+// MULTI: more than one (view, dRGB) group per Gaussian — the slab is accumulated in LDS instead of stored once.
+#define S360_SH_PUT(i, v)            \
+    do {                             \
+        if (MULTI)                   \
+            mine[i] += (v);          \
+        else                         \
+            mine[i] = (v);           \
+    } while (0)
+template <bool CH_MAJOR, bool FAST, bool MULTI>  // FAST: degree 4, 25 stored coefficients (the reference's configuration)
 __global__ __launch_bounds__(64) void k_sh_bwd(KParams kp, const S360View* __restrict__ views, const float* __restrict__ means,
                                               const float* __restrict__ shs, const float4* __restrict__ drgb_in, int n_groups,
                                               float* __restrict__ d_means3D, float* __restrict__ d_shs) {
@@ -522,7 +530,8 @@ __global__ __launch_bounds__(64) void k_sh_bwd(KParams kp, const S360View* __res
     // n_groups (view, summed dL/dRGB) pairs per Gaussian: 1 for a local backward; N when the factors of the
     // rank-1 products Y (x) dRGB of N ranks were all-gathered instead of all-reducing N full SH gradients.
     if (g < kp.P) {
-        for (int k = 0; k < slab; ++k) mine[k] = 0.f;
+        if (MULTI)
+            for (int k = 0; k < slab; ++k) mine[k] = 0.f;
         const float* sh = shs + (size_t)g * slab;
         float dm0 = 0.f, dm1 = 0.f, dm2 = 0.f;
         bool any = false;
@@ -530,7 +539,11 @@ __global__ __launch_bounds__(64) void k_sh_bwd(KParams kp, const S360View* __res
         for (int j = 0; j < n_groups; ++j) {
             const float4 dr = drgb_in[(size_t)j * kp.P + g];
             const int fv = __float_as_int(dr.w);
-            if (fv < 0) continue;  // invisible in that group's views: no contribution
+            if (fv < 0) {  // invisible in that group's views: no contribution
+                if (!MULTI)
+                    for (int k = 0; k < slab; ++k) mine[k] = 0.f;
+                continue;
+            }
             any = true;
             const S360View& vw = views[fv];
             const float sc = vw.scale;
@@ -552,7 +565,7 @@ __global__ __launch_bounds__(64) void k_sh_bwd(KParams kp, const S360View* __res
 #pragma unroll
                     for (int k = 0; k < 25; ++k) {
                         s[k] += c[k] * d;
-                        mine[25 * ch + k] += Y[k] * d;
+                        S360_SH_PUT(25 * ch + k, Y[k] * d);
                     }
                 }
             } else if (FAST) {
@@ -563,20 +576,22 @@ __global__ __launch_bounds__(64) void k_sh_bwd(KParams kp, const S360View* __res
 #pragma unroll
                     for (int k = 0; k < 5; ++k) {
                         s[5 * q + k] = c[3 * k] * drc[0] + c[3 * k + 1] * drc[1] + c[3 * k + 2] * drc[2];
-                        mine[15 * q + 3 * k] += Y[5 * q + k] * drc[0];
-                        mine[15 * q + 3 * k + 1] += Y[5 * q + k] * drc[1];
-                        mine[15 * q + 3 * k + 2] += Y[5 * q + k] * drc[2];
+                        S360_SH_PUT(15 * q + 3 * k, Y[5 * q + k] * drc[0]);
+                        S360_SH_PUT(15 * q + 3 * k + 1, Y[5 * q + k] * drc[1]);
+                        S360_SH_PUT(15 * q + 3 * k + 2, Y[5 * q + k] * drc[2]);
                     }
                 }
             } else {
                 const int sk = CH_MAJOR ? 1 : 3, sc_ = CH_MAJOR ? kp.M : 1;
+                if (!MULTI)
+                    for (int k = 0; k < slab; ++k) mine[k] = 0.f;  // stored coefficients beyond the active degree
 #pragma unroll
                 for (int k = 0; k < 25; ++k) {  // generic layout / degree (<= 25 active coefficients)
                     if (k < n_sh) {
                         s[k] = sh[k * sk] * drc[0] + sh[k * sk + sc_] * drc[1] + sh[k * sk + 2 * sc_] * drc[2];
-                        mine[k * sk] += Y[k] * drc[0];
-                        mine[k * sk + sc_] += Y[k] * drc[1];
-                        mine[k * sk + 2 * sc_] += Y[k] * drc[2];
+                        S360_SH_PUT(k * sk, Y[k] * drc[0]);
+                        S360_SH_PUT(k * sk + sc_, Y[k] * drc[1]);
+                        S360_SH_PUT(k * sk + 2 * sc_, Y[k] * drc[2]);
                     }
                 }
             }
@@ -636,14 +651,24 @@ static int launch_sh_bwd(const KParams& kp, const S360View* views, const float* 
     const int wblk = (kp.P + 63) / 64;
     const size_t wlds = (size_t)64 * kp.M * 3 * 4;
     if (wlds > 64 * 1024) return S360_E_UNSUPPORTED;
+#define S360_SH_LAUNCH(A, B)                                                                                        \
+    do {                                                                                                             \
+        if (n_groups > 1)                                                                                            \
+            hipLaunchKernelGGL((k_sh_bwd<A, B, true>), dim3(wblk), dim3(64), wlds, st, kp, views, means3D, shs, drgb, \
+                               n_groups, d_means3D, d_shs);                                                          \
+        else                                                                                                         \
+            hipLaunchKernelGGL((k_sh_bwd<A, B, false>), dim3(wblk), dim3(64), wlds, st, kp, views, means3D, shs, drgb, \
+                               n_groups, d_means3D, d_shs);                                                          \
+    } while (0)
     if (chm && fast)
-        hipLaunchKernelGGL((k_sh_bwd<true, true>), dim3(wblk), dim3(64), wlds, st, kp, views, means3D, shs, drgb, n_groups, d_means3D, d_shs);
+        S360_SH_LAUNCH(true, true);
     else if (chm)
-        hipLaunchKernelGGL((k_sh_bwd<true, false>), dim3(wblk), dim3(64), wlds, st, kp, views, means3D, shs, drgb, n_groups, d_means3D, d_shs);
+        S360_SH_LAUNCH(true, false);
     else if (fast)
-        hipLaunchKernelGGL((k_sh_bwd<false, true>), dim3(wblk), dim3(64), wlds, st, kp, views, means3D, shs, drgb, n_groups, d_means3D, d_shs);
+        S360_SH_LAUNCH(false, true);
     else
-        hipLaunchKernelGGL((k_sh_bwd<false, false>), dim3(wblk), dim3(64), wlds, st, kp, views, means3D, shs, drgb, n_groups, d_means3D, d_shs);
+        S360_SH_LAUNCH(false, false);
+#undef S360_SH_LAUNCH
     return S360_OK;
 }
 

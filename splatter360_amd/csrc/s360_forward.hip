@@ -664,6 +664,15 @@ __global__ __launch_bounds__(S360_BLOCK) void k_sort_tiles_global(const uint32_t
 #endif
 constexpr int SPARSE_PIXELS = S360_SPARSE_PIXELS;
 
+// Optional loss epilogue of the composite store (the reference computes it as separate torch ops right after
+// the decoder: LossMse, src/loss/loss_mse.py:30-31; compute_psnr, src/evaluation/metrics.py:11-21).
+struct MseEp {
+    const float* target;  // [V,3,H,W] or null (epilogue off)
+    float* d_images;      // [V,3,H,W]  grad_scale * (image - target)
+    float* partials;      // [V*T*4, 2] per 16x4 strip: sum (image-target)^2, sum (clip01(image)-clip01(target))^2
+    float grad_scale;
+};
+
 template <bool WITH_DEPTH>
 __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_render(KParams kp, const S360View* __restrict__ views,
                                                       const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ list,
@@ -672,7 +681,7 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
                                                       float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
                                                       uint32_t* __restrict__ tile_max_contrib, uint32_t* __restrict__ strip_last,
                                                       uint32_t* __restrict__ dbg, const float* __restrict__ depths,
-                                                      float* __restrict__ depth_maps, int depth_mode) {
+                                                      float* __restrict__ depth_maps, int depth_mode, MseEp ep) {
 #ifdef S360_DBG_TIMING
     const long long t_begin = wall_clock64();
 #endif
@@ -821,17 +830,40 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
             }
         }
     }
+    float sq = 0.f, sqc = 0.f;
     if (inside) {
         const S360View& vw = views[v];
         const size_t hw = (size_t)kp.H * kp.W;
         const size_t pix = (size_t)py * kp.W + px;
         float* img = images + (size_t)v * 3 * hw;
-        img[pix] = C0 + T * vw.bg[0];
-        img[hw + pix] = C1 + T * vw.bg[1];
-        img[2 * hw + pix] = C2 + T * vw.bg[2];
+        const float o0 = C0 + T * vw.bg[0], o1 = C1 + T * vw.bg[1], o2 = C2 + T * vw.bg[2];
+        img[pix] = o0;
+        img[hw + pix] = o1;
+        img[2 * hw + pix] = o2;
+        if (ep.target) {
+            const float* gt = ep.target + (size_t)v * 3 * hw;
+            float* dg = ep.d_images + (size_t)v * 3 * hw;
+            const float g0 = gt[pix], g1 = gt[hw + pix], g2 = gt[2 * hw + pix];
+            const float d0 = o0 - g0, d1 = o1 - g1, d2 = o2 - g2;
+            dg[pix] = ep.grad_scale * d0;
+            dg[hw + pix] = ep.grad_scale * d1;
+            dg[2 * hw + pix] = ep.grad_scale * d2;
+            sq = d0 * d0 + d1 * d1 + d2 * d2;
+            const float c0 = fminf(fmaxf(g0, 0.f), 1.f) - fminf(fmaxf(o0, 0.f), 1.f);
+            const float c1 = fminf(fmaxf(g1, 0.f), 1.f) - fminf(fmaxf(o1, 0.f), 1.f);
+            const float c2 = fminf(fmaxf(g2, 0.f), 1.f) - fminf(fmaxf(o2, 0.f), 1.f);
+            sqc = c0 * c0 + c1 * c1 + c2 * c2;
+        }
         final_T[(size_t)v * hw + pix] = T;
         n_contrib[(size_t)v * hw + pix] = last;
         if (WITH_DEPTH) depth_maps[(size_t)v * hw + pix] = D;  // background depth is 0 (cuda_splatting.py:258)
+    }
+    if (ep.target) {  // wave-uniform
+        const float s0 = wave_sum1_lane63(sq), s1 = wave_sum1_lane63(sqc);
+        if (lane == 63) {
+            ep.partials[2 * (4 * (size_t)t + wave)] = s0;
+            ep.partials[2 * (4 * (size_t)t + wave) + 1] = s1;
+        }
     }
     const uint32_t wm = wave_max_u32(inside ? last : 0u);
     if (lane == 0) {
@@ -943,7 +975,7 @@ extern "C" int s360_layout(const S360Params* prm, S360Layout* out) {
 static int forward_impl(const S360Params* prm, const S360View* views, const float* means3D, const float* cov6,
                         const float* opacities, const float* shs, const float* colors_precomp, float* images,
                         float* depth_maps, int depth_mode, int32_t* radii, void* workspace, size_t workspace_bytes,
-                        void* stream_) {
+                        void* stream_, MseEp ep = MseEp{nullptr, nullptr, nullptr, 0.f}) {
     if (!prm || !views || !images || !workspace) return S360_E_BADARG;
     if (prm->P > 0 && (shs == nullptr) == (colors_precomp == nullptr)) return S360_E_BADARG;
     if (prm->P > 0 && (!means3D || !cov6 || !opacities)) return S360_E_BADARG;
@@ -1076,11 +1108,11 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
         if (depth_maps)
             hipLaunchKernelGGL(k_render<true>, dim3(nt), dim3(S360_BLOCK), occupancy_cap_lds("S360_RENDER_LDS", 0), st, kp, views, tile_start,
                                list, recA, recB, recC, images, final_T, n_contrib, tile_max_contrib, strip_last, header + 8,
-                               depths, depth_maps, depth_mode);
+                               depths, depth_maps, depth_mode, ep);
         else
             hipLaunchKernelGGL(k_render<false>, dim3(nt), dim3(S360_BLOCK), occupancy_cap_lds("S360_RENDER_LDS", 0), st, kp, views, tile_start,
                                list, recA, recB, recC, images, final_T, n_contrib, tile_max_contrib, strip_last, header + 8,
-                               depths, depth_maps, depth_mode);
+                               depths, depth_maps, depth_mode, ep);
     }
     S360_CHECK_LAUNCH();
     return S360_OK;
@@ -1100,4 +1132,15 @@ extern "C" int s360_forward_depth(const S360Params* prm, const S360View* views, 
     if (!depth_maps || depth_mode < 0 || depth_mode > 3) return S360_E_BADARG;
     return forward_impl(prm, views, means3D, cov6, opacities, shs, colors_precomp, images, depth_maps, depth_mode, radii,
                         workspace, workspace_bytes, stream_);
+}
+
+extern "C" int s360_forward_mse(const S360Params* prm, const S360View* views, const float* means3D, const float* cov6,
+                                const float* opacities, const float* shs, const float* colors_precomp, float* images,
+                                float* depth_maps, int32_t depth_mode, int32_t* radii, const float* target,
+                                float grad_scale, float* d_images, float* partials, void* workspace,
+                                size_t workspace_bytes, void* stream_) {
+    if (!target || !d_images || !partials) return S360_E_BADARG;
+    if (depth_maps && (depth_mode < 0 || depth_mode > 3)) return S360_E_BADARG;
+    return forward_impl(prm, views, means3D, cov6, opacities, shs, colors_precomp, images, depth_maps, depth_mode, radii,
+                        workspace, workspace_bytes, stream_, s360::MseEp{target, d_images, partials, grad_scale});
 }

@@ -182,13 +182,16 @@ def render_views_fused(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far
                        background: Tensor, gaussian_means: Tensor, gaussian_covariances: Tensor,
                        gaussian_sh_coefficients: Tensor, gaussian_opacities: Tensor, *, shared_campos: bool = True,
                        max_instances: Optional[int] = None, check: str = "sync", views: Optional[Tensor] = None,
-                       depth_mode: Optional[DepthRenderingMode] = None, defer_sh: bool = False):
+                       depth_mode: Optional[DepthRenderingMode] = None, defer_sh: bool = False,
+                       mse_target: Optional[Tensor] = None, mse_weight: float = 1.0, mse_count: Optional[int] = None):
     """V <= 8 views of ONE cloud in one fused rasteriser call: means[G,3], covariances[G,3,3],
     harmonics[G,3,d_sh] (the reference's Gaussians layout, src/model/types.py:7-12, read in place),
     opacities[G] -> [V,3,h,w].  With the six face cameras of a panorama (shared_campos=True: one camera
     centre) this is bit-for-bit the result of six reference-style render_cuda calls.  With depth_mode set,
     returns (colour, depth[V,h,w]): the depth maps of render_depth_cuda from the SAME pass (the reference
-    rasterises every face a second time for them, decoder_splatting_cuda.py:72-97)."""
+    rasterises every face a second time for them, decoder_splatting_cuda.py:72-97).
+    With mse_target[V,3,h,w] (the supervising cube faces) the L2 loss / PSNR epilogue is fused into the render
+    (rasterizer.FusedMse appended as the last result)."""
     if views is None:  # callers may pass pre-packed views (e.g. prepared on a side stream, see CameraPrefetcher)
         views = pack_camera_views(extrinsics, intrinsics, near, far, background)
     n = gaussian_sh_coefficients.shape[-1]
@@ -197,8 +200,11 @@ def render_views_fused(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far
         gaussian_means, gaussian_covariances, gaussian_opacities, gaussian_sh_coefficients, None, views=views,
         image_height=h, image_width=w, sh_degree=isqrt(n) - 1, shared_campos=shared_campos, want_radii=False,
         max_instances=max_instances, check=check, cov9=True, sh_channel_major=True, depth_mode=depth_mode,
-        defer_sh=defer_sh)
-    return out[0] if depth_mode is None else (out[0], out[2])
+        defer_sh=defer_sh, mse_target=mse_target, mse_weight=mse_weight, mse_count=mse_count)
+    res = (out[0],) if depth_mode is None else (out[0], out[2])
+    if mse_target is not None:
+        res = res + (out[-1],)
+    return res[0] if len(res) == 1 else res
 
 
 class CameraPrefetcher:

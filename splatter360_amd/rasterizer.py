@@ -120,7 +120,7 @@ def _f32c(t: Tensor, name: str) -> Tensor:
     return t.detach().float().contiguous()
 
 
-def _forward_call(prm, views, means3D, cov6, opac, shs, colors, want_radii: bool, depth_mode=None):
+def _forward_call(prm, views, means3D, cov6, opac, shs, colors, want_radii: bool, depth_mode=None, mse=None):
     lay = _lib.layout(prm)
     dev = means3D.device
     ws = torch.empty(lay.total_bytes, dtype=torch.uint8, device=dev)
@@ -128,6 +128,21 @@ def _forward_call(prm, views, means3D, cov6, opac, shs, colors, want_radii: bool
     radii = torch.empty((prm.V, prm.P), dtype=torch.int32, device=dev) if want_radii else None
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     depth = None
+    if mse is not None:     # (target[V,3,H,W], grad_scale): loss epilogue fused into the composite store
+        target, grad_scale = mse
+        if depth_mode is not None:
+            depth = torch.empty((prm.V, prm.H, prm.W), dtype=torch.float32, device=dev)
+        d_images = torch.empty_like(images)
+        nstrips = prm.V * ((prm.H + 15) // 16) * ((prm.W + 15) // 16) * 4
+        partials = torch.empty((nstrips, 2), dtype=torch.float32, device=dev)
+        rc = _lib.lib().s360_forward_mse(C.byref(prm), _ptr(views), _ptr(means3D), _ptr(cov6), _ptr(opac), _ptr(shs),
+                                         _ptr(colors), _ptr(images), _ptr(depth), DEPTH_MODES.get(depth_mode, 0), _ptr(radii),
+                                         _ptr(target), C.c_float(grad_scale), _ptr(d_images), _ptr(partials),
+                                         _ptr(ws), lay.total_bytes, stream)
+        _lib.check(rc, "s360_forward_mse")
+        st = RasterState(prm, lay, ws)
+        st.d_images, st.mse_partials = d_images, partials
+        return images, radii, st, depth
     if depth_mode is None:
         rc = _lib.lib().s360_forward(C.byref(prm), _ptr(views), _ptr(means3D), _ptr(cov6), _ptr(opac), _ptr(shs),
                                      _ptr(colors), _ptr(images), _ptr(radii), _ptr(ws), lay.total_bytes, stream)
@@ -144,9 +159,9 @@ class _RasterizeViews(torch.autograd.Function):
     """autograd node of one multi-view rasterisation (forward saves inputs + workspace)."""
 
     @staticmethod
-    def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, cov6, views, cfg):
+    def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, cov6, views, cfg, mse_target=None):
         (h, w, sh_degree, shared_campos, max_instances, check, want_radii, cov9, sh_channel_major, keep_offsets, depth_mode,
-         defer_sh) = cfg
+         defer_sh, mse_weight, mse_count) = cfg
         if not means3D.is_cuda:
             raise RuntimeError("means3D must live on the GPU (hip device); the rasteriser has no CPU path")
         with torch.cuda.device(means3D.device):
@@ -170,10 +185,25 @@ class _RasterizeViews(torch.autograd.Function):
                 _lib.FLAG_COV9 if cov9 else 0) | (_lib.FLAG_SH_CHANNEL_MAJOR if sh_channel_major else 0) | (
                 0 if (needs_bwd or keep_offsets) else _lib.FLAG_FORWARD_ONLY)
             prm.max_instances = int(max_instances) if max_instances else default_capacity(p, v)
-            images, radii, state, depth = _forward_call(prm, vw, m3, c6, op, sh, col, want_radii, depth_mode)
+            mse = None
+            if mse_target is not None:
+                tgt = _f32c(mse_target, "mse_target")
+                if tuple(tgt.shape) != (v, 3, int(h), int(w)):
+                    raise RuntimeError(f"mse_target must be [{v},3,{h},{w}], got {tuple(tgt.shape)}")
+                n_mean = int(mse_count) if mse_count else v * 3 * int(h) * int(w)
+                mse = (tgt, 2.0 * float(mse_weight) / n_mean)
+            images, radii, state, depth = _forward_call(prm, vw, m3, c6, op, sh, col, want_radii, depth_mode, mse)
             if check == "sync" and state.overflowed():
                 prm.max_instances = state.num_rendered()
-                images, radii, state, depth = _forward_call(prm, vw, m3, c6, op, sh, col, want_radii, depth_mode)
+                images, radii, state, depth = _forward_call(prm, vw, m3, c6, op, sh, col, want_radii, depth_mode, mse)
+            if mse is not None:
+                sums = state.mse_partials.view(v, -1, 2).sum(1)          # fixed order: deterministic
+                loss = sums[:, 0].sum() * (float(mse_weight) / n_mean)
+                clipped_mse = sums[:, 1] / float(3 * int(h) * int(w))
+            else:
+                loss = torch.empty(0, dtype=torch.float32, device=images.device)
+                clipped_mse = loss
+        ctx.set_materialize_grads(False)
         ctx.state = state
         ctx.defer_sh = bool(defer_sh) and sh is not None
         ctx.has_means2D = means2D is not None
@@ -183,17 +213,23 @@ class _RasterizeViews(torch.autograd.Function):
             radii = torch.empty(0, dtype=torch.int32, device=images.device)
         if depth is None:
             depth = torch.empty(0, dtype=torch.float32, device=images.device)
-        ctx.mark_non_differentiable(radii, depth)
-        return images, radii, depth
+        ctx.mark_non_differentiable(radii, depth, clipped_mse)
+        return images, radii, depth, loss, clipped_mse
 
     @staticmethod
-    def backward(ctx, grad_images, _grad_radii, _grad_depth):
+    def backward(ctx, grad_images, _grad_radii, _grad_depth, grad_loss, _grad_clipped):
         m3, c6, op, sh, col, vw = ctx.saved_tensors
         state: RasterState = ctx.state
         prm, lay = state.prm, state.layout
         dev = m3.device
         with torch.cuda.device(dev):
-            g = grad_images.detach().float().contiguous()
+            g = None if grad_images is None else grad_images.detach().float()
+            if grad_loss is not None and getattr(state, "d_images", None) is not None:
+                seed = state.d_images * grad_loss.detach().float()   # d_images = 2w/N (image - target) from the epilogue
+                g = seed if g is None else g + seed
+            if g is None:
+                g = torch.zeros((prm.V, 3, prm.H, prm.W), dtype=torch.float32, device=dev)
+            g = g.contiguous()
             p, v = prm.P, prm.V
             d_m3 = torch.empty((p, 3), dtype=torch.float32, device=dev)
             d_c6 = torch.empty_like(c6)
@@ -215,7 +251,7 @@ class _RasterizeViews(torch.autograd.Function):
                 _RasterizeViews.last_deferred = DeferredSH(prm, vw, m3, sh, d_rgb)
                 if d_m2 is not None:
                     d_m2 = d_m2.sum(0) if v > 1 else d_m2[0]
-                return d_m3, d_m2, None, None, d_op.view(-1, 1), d_c6, None, None
+                return d_m3, d_m2, None, None, d_op.view(-1, 1), d_c6, None, None, None
             rc = _lib.lib().s360_backward(
                 C.byref(prm), _ptr(vw), _ptr(m3), _ptr(c6), _ptr(op), _ptr(sh), _ptr(col), _ptr(state.workspace),
                 lay.total_bytes, _ptr(g), _ptr(d_m3), _ptr(d_m2), _ptr(d_c6), _ptr(d_op), _ptr(d_sh), _ptr(d_col),
@@ -223,11 +259,22 @@ class _RasterizeViews(torch.autograd.Function):
             _lib.check(rc, "s360_backward")
         if d_m2 is not None:
             d_m2 = d_m2.sum(0) if v > 1 else d_m2[0]
-        return d_m3, d_m2, d_sh, d_col, d_op.view(-1, 1), d_c6, None, None
+        return d_m3, d_m2, d_sh, d_col, d_op.view(-1, 1), d_c6, None, None, None
 
 
 _RasterizeViews.last_state = None
 _RasterizeViews.last_deferred = None
+
+
+class FusedMse(NamedTuple):
+    """Result of the loss epilogue: LossMse (src/loss/loss_mse.py:30-31) and the per-view clipped MSE that
+    compute_psnr (src/evaluation/metrics.py:11-21) takes the log of."""
+    loss: Tensor
+    clipped_mse: Tensor
+
+    def psnr(self) -> Tensor:
+        m = torch.where(self.clipped_mse == 0.0, torch.full_like(self.clipped_mse, 1e-10), self.clipped_mse)
+        return -10 * m.log10()
 
 
 class DeferredSH:
@@ -262,7 +309,8 @@ def rasterize_views(means3D: Tensor, cov6: Tensor, opacities: Tensor, shs: Optio
                     sh_degree: int = 0, shared_campos: bool = False, max_instances: Optional[int] = None,
                     check: str = "sync", want_radii: bool = True, means2D: Optional[Tensor] = None,
                     cov9: bool = False, sh_channel_major: bool = False, keep_offsets: bool = False,
-                    depth_mode: Optional[str] = None, defer_sh: bool = False):
+                    depth_mode: Optional[str] = None, defer_sh: bool = False, mse_target: Optional[Tensor] = None,
+                    mse_weight: float = 1.0, mse_count: Optional[int] = None):
     """Render V views ([V,44] packed, see pack_views) of one cloud.  cov9: cov6 is [P,3,3];
     sh_channel_major: shs is [P,3,M] (the reference's Gaussians layouts, consumed without copies).
     When no input requires grad the per-pair offsets scan (backward-only state) is skipped unless
@@ -271,6 +319,9 @@ def rasterize_views(means3D: Tensor, cov6: Tensor, opacities: Tensor, shs: Optio
     defer_sh=True (views sharing one camera centre): the backward skips the SH pass, returns no gradient for
     `shs` and leaves a DeferredSH (last_deferred()) for distributed.sync_gradients_factored.  Returns (images[V,3,H,W],
     radii[V,P] int32).  opacities may be [P] or [P,1]; its gradient has the same shape.
+    mse_target[V,3,H,W]: fuse the cube-face L2 loss into the composite store — an extra last result
+    FusedMse(loss = mse_weight * mean((images - target)^2) (differentiable scalar; mean over mse_count elements,
+    default all of this call's), clipped_mse[V] for psnr()).
     check="sync": read the overflow flag after the forward (one host sync, like upstream's own
     scan read-back) and re-run with the exact size if the binning capacity was exceeded;
     check="lazy": never synchronise — validate later via last_state().overflowed()."""
@@ -280,9 +331,11 @@ def rasterize_views(means3D: Tensor, cov6: Tensor, opacities: Tensor, shs: Optio
     if depth_mode is not None and depth_mode not in DEPTH_MODES:
         raise ValueError(f"depth_mode must be one of {sorted(DEPTH_MODES)}")
     cfg = (image_height, image_width, sh_degree, shared_campos, max_instances, check, want_radii, cov9,
-           sh_channel_major, keep_offsets, depth_mode, defer_sh)
-    images, radii, depth = _RasterizeViews.apply(means3D, means2D, shs, colors_precomp, op2, cov6, views, cfg)
-    return (images, radii) if depth_mode is None else (images, radii, depth)
+           sh_channel_major, keep_offsets, depth_mode, defer_sh, mse_weight, mse_count)
+    images, radii, depth, loss, clipped = _RasterizeViews.apply(means3D, means2D, shs, colors_precomp, op2, cov6, views,
+                                                                cfg, mse_target)
+    out = (images, radii) if depth_mode is None else (images, radii, depth)
+    return out if mse_target is None else out + (FusedMse(loss, clipped),)
 
 
 def last_state() -> Optional[RasterState]:
