@@ -37,3 +37,15 @@ def full():
     e = c2e.stitch_rendered(f.detach())
     ((f - gt) ** 2).mean().backward()
 timeit("full step", full)
+cams = decoder.CameraPrefetcher(dev)
+def fwd_step():
+    with torch.no_grad():
+        v = cams.pack(ext, K, near, far, bg)
+        f = decoder.render_views_fused(ext, K, near, far, (256, 256), bg, *[p.detach() for p in params], check="lazy", views=v)
+        return c2e.stitch_rendered(f)
+timeit("bench fwd step (prefetcher)", fwd_step)
+def fwd_step_noglue():
+    with torch.no_grad():
+        f = decoder.render_views_fused(ext, K, near, far, (256, 256), bg, *[p.detach() for p in params], check="lazy", views=views)
+        return c2e.stitch_rendered(f)
+timeit("bench fwd step (views cached)", fwd_step_noglue)

@@ -213,18 +213,53 @@ class CameraPrefetcher:
     then overlap with the previous call's heavy kernels instead of serialising in front of them; the
     main stream only waits on an event.  Results are identical to pack_camera_views."""
 
-    def __init__(self, device):
+    def __init__(self, device, use_graph: bool = True):
+        """use_graph: replay the glue as ONE captured HIP graph per call instead of ~60 eager launches.  The
+        kernels and therefore the results are the same; what disappears is ~0.7 ms of host-side launch cost per
+        call, which otherwise makes a forward-only step (0.6 ms of GPU work at 1 M Gaussians) host-bound."""
         self.stream = torch.cuda.Stream(device=device)
         self.event = torch.cuda.Event()
+        self.use_graph = use_graph
+        self._graphs: dict = {}
+
+    def _capture(self, key, args):
+        static_in = [torch.empty(tuple(a.shape), dtype=torch.float32, device=self.stream.device) for a in args]
+        with torch.cuda.stream(self.stream):
+            torch._foreach_copy_(static_in, [a.detach() for a in args])
+            for _ in range(2):      # warm-up: library handles, cached constants, allocator pools
+                pack_camera_views(*static_in)
+        self.stream.synchronize()
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=self.stream):
+                out = pack_camera_views(*static_in)
+            entry = (graph, static_in, out)
+        except Exception as e:  # capture not possible in this environment: eager side-stream path still works
+            import warnings
+            warnings.warn(f"CameraPrefetcher: HIP graph capture failed ({e!r}); using eager launches")
+            entry = None
+        self._graphs[key] = entry
+        return entry
 
     def pack(self, extrinsics, intrinsics, near, far, background, inputs_ready: bool = True) -> Tensor:
         """inputs_ready=True: the camera tensors come from the data loader / an earlier step and are
         already materialised (the normal case: poses do not depend on the model).  Pass False when they
         were just produced on the current stream; the side stream then waits for it (no overlap)."""
+        args = (extrinsics, intrinsics, near, far, background)
+        entry = None
+        if self.use_graph:
+            key = tuple(tuple(a.shape) for a in args)
+            entry = self._graphs[key] if key in self._graphs else self._capture(key, args)
         if not inputs_ready:
             self.stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.stream):
-            views = pack_camera_views(extrinsics, intrinsics, near, far, background)
+            if entry is not None:
+                graph, static_in, out = entry
+                torch._foreach_copy_(static_in, [a.detach() for a in args])
+                graph.replay()
+                views = out.clone()     # the static output is overwritten by the next replay
+            else:
+                views = pack_camera_views(*args)
             self.event.record(self.stream)
         torch.cuda.current_stream().wait_event(self.event)
         views.record_stream(torch.cuda.current_stream())
@@ -252,14 +287,30 @@ class DecoderSplattingFused(torch.nn.Module):
     every batch item are rendered `views_per_group` at a time (6 = the cube faces of one target panorama,
     which share a camera centre) in single rasteriser calls, colour and depth together."""
 
-    def __init__(self, background_color=(0.0, 0.0, 0.0), views_per_group: int = 6, shared_campos: bool = True):
+    def __init__(self, background_color=(0.0, 0.0, 0.0), views_per_group: int = 6, shared_campos: bool = True,
+                 cameras_ready: bool = False, use_graph: bool = True):
+        """cameras_ready: the camera tensors were materialised before earlier work on the current stream was
+        queued (data-loader output), so their glue may overlap with that work on the side stream."""
         super().__init__()
         self.register_buffer("background_color", torch.tensor(background_color, dtype=torch.float32), persistent=False)
         self.views_per_group, self.shared_campos = views_per_group, shared_campos
+        self.cameras_ready, self.use_graph = cameras_ready, use_graph
+        self._cams: dict = {}
+
+    def _prefetcher(self, device) -> "CameraPrefetcher":
+        c = self._cams.get(device)
+        if c is None:
+            c = self._cams[device] = CameraPrefetcher(device, use_graph=self.use_graph)
+        return c
 
     def forward(self, gaussians, extrinsics, intrinsics, near, far, image_shape, depth_mode=None) -> "DecoderOutput":
         b, v = extrinsics.shape[:2]
         colors, depths = [], []
+        cams = self._prefetcher(extrinsics.device)
+        groups = [(i, slice(s, min(v, s + self.views_per_group))) for i in range(b) for s in range(0, v, self.views_per_group)]
+        # all camera records up front (one graph replay each), so the rasteriser calls queue back to back
+        packed = {(i, e.start): cams.pack(extrinsics[i, e], intrinsics[i, e], near[i, e], far[i, e], self.background_color,
+                                          inputs_ready=self.cameras_ready) for i, e in groups}
         for i in range(b):
             cs, ds = [], []
             for s in range(0, v, self.views_per_group):
@@ -267,7 +318,7 @@ class DecoderSplattingFused(torch.nn.Module):
                 out = render_views_fused(extrinsics[i, e], intrinsics[i, e], near[i, e], far[i, e], image_shape,
                                          self.background_color, gaussians.means[i], gaussians.covariances[i],
                                          gaussians.harmonics[i], gaussians.opacities[i], shared_campos=self.shared_campos,
-                                         depth_mode=depth_mode)
+                                         depth_mode=depth_mode, views=packed[(i, s)])
                 if depth_mode is None:
                     cs.append(out)
                 else:
