@@ -192,8 +192,6 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess(
 
 // ------------------------------------------------------------------------------ scans
 // Inclusive scan of n uint32 in three launches: per-block totals, scan of totals, final pass.
-constexpr int SCAN_ITEMS = 8;
-constexpr int SCAN_TILE = S360_BLOCK * SCAN_ITEMS;  // 2048 elements per block
 
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* lds, uint32_t& total) {
     // wave-level inclusive scan by shuffles, then 4 wave totals through LDS
@@ -218,51 +216,92 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* l
     return base + inc - v;
 }
 
-__global__ __launch_bounds__(S360_BLOCK) void k_scan_block_sums(const uint32_t* __restrict__ in, uint32_t* __restrict__ sums,
-                                                               size_t n) {
-    __shared__ uint32_t lds[8];
-    const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
-    uint32_t s = 0;
-#pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i)
-        if (base + i < n) s += in[base + i];
-    uint32_t tot;
-    block_exclusive_scan(s, lds, tot);
-    if (threadIdx.x == 0) sums[blockIdx.x] = tot;
-}
+// Single-pass inclusive scan (decoupled look-back): out[i] = in[0] + ... + in[i].  Blocks take their tile from
+// a ticket counter (so a block only ever waits for blocks that already hold a ticket and are therefore
+// resident), publish (flag, value) packed in one 64-bit word — flag 1 = tile aggregate, 2 = inclusive prefix —
+// and the first wave of each block walks back over its predecessors 64 at a time.  One 4-byte read and one
+// 4-byte write per element; coalesced 16-byte accesses (row k of a tile = 1024 consecutive elements, 4 per lane).
+// `state` ([ntiles] words) and `ticket` must be zero at launch (cleared together with tile_count).
+constexpr int LB_ROWS = 4;
+constexpr int LB_TILE = S360_BLOCK * 4 * LB_ROWS;  // 4096 elements per block
 
-// single block: exclusive scan of `sums` in place; optionally writes the grand total to *total_out
-__global__ __launch_bounds__(S360_BLOCK) void k_scan_sums(uint32_t* __restrict__ sums, int n, uint32_t* __restrict__ total_out) {
+__global__ __launch_bounds__(S360_BLOCK) void k_scan_lookback(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t n,
+                                                             unsigned long long* __restrict__ state, uint32_t* __restrict__ ticket) {
     __shared__ uint32_t lds[8];
-    uint32_t carry = 0;
-    for (int b = 0; b < n; b += S360_BLOCK) {
-        const int i = b + threadIdx.x;
-        const uint32_t v = i < n ? sums[i] : 0u;
-        uint32_t tot;
-        const uint32_t ex = block_exclusive_scan(v, lds, tot);
-        if (i < n) sums[i] = carry + ex;
-        carry += tot;
-    }
-    if (total_out && threadIdx.x == 0) *total_out = carry;
-}
-
-__global__ __launch_bounds__(S360_BLOCK) void k_scan_final(const uint32_t* __restrict__ in, const uint32_t* __restrict__ sums,
-                                                          uint32_t* __restrict__ out, size_t n) {
-    __shared__ uint32_t lds[8];
-    const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
-    uint32_t v[SCAN_ITEMS];
-    uint32_t s = 0;
+    __shared__ uint32_t s_bid, s_prefix;
+    if (threadIdx.x == 0) s_bid = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint32_t bid = s_bid;
+    const size_t tile0 = (size_t)bid * LB_TILE;
+    uint32_t v[LB_ROWS][4], row_ex[LB_ROWS], row_tot[LB_ROWS];
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i) {
-        v[i] = base + i < n ? in[base + i] : 0u;
-        s += v[i];
-    }
-    uint32_t tot;
-    uint32_t run = block_exclusive_scan(s, lds, tot) + sums[blockIdx.x];
+    for (int k = 0; k < LB_ROWS; ++k) {
+        const size_t i = tile0 + (size_t)k * (S360_BLOCK * 4) + (size_t)threadIdx.x * 4;
+        if (i + 3 < n) {
+            const uint4 q = *reinterpret_cast<const uint4*>(in + i);
+            v[k][0] = q.x; v[k][1] = q.y; v[k][2] = q.z; v[k][3] = q.w;
+        } else {
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i) {
-        run += v[i];
-        if (base + i < n) out[base + i] = run;
+            for (int j = 0; j < 4; ++j) v[k][j] = i + j < n ? in[i + j] : 0u;
+        }
+    }
+    uint32_t total = 0;
+#pragma unroll
+    for (int k = 0; k < LB_ROWS; ++k) {
+        row_ex[k] = block_exclusive_scan(v[k][0] + v[k][1] + v[k][2] + v[k][3], lds, row_tot[k]);
+        total += row_tot[k];
+    }
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        if (lane == 0)
+            __hip_atomic_store(&state[bid], ((unsigned long long)(bid == 0 ? 2u : 1u) << 32) | total, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t prefix = 0;
+        long long j = (long long)bid - 1;
+        while (j >= 0) {
+            const long long idx = j - lane;
+            unsigned long long w;
+            do {  // all 64 predecessors of this window must have published something
+                w = idx >= 0 ? __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 32);
+                if (__ballot((uint32_t)(w >> 32) == 0u) == 0ull) break;
+                __builtin_amdgcn_s_sleep(1);
+            } while (true);
+            const unsigned long long full = __ballot((uint32_t)(w >> 32) == 2u);
+            // nearest predecessor holding an inclusive prefix ends the walk: sum lanes 0..first
+            const int first = full ? __builtin_ctzll(full) : 63;
+            uint32_t part = lane <= first ? (uint32_t)w : 0u;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) part += (uint32_t)__shfl_xor((int)part, o);
+            prefix += part;
+            if (full) break;
+            j -= 64;
+        }
+        if (lane == 0) {
+            s_prefix = prefix;
+            if (bid > 0)
+                __hip_atomic_store(&state[bid], (2ull << 32) | (unsigned long long)(prefix + total), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    uint32_t run = s_prefix;
+#pragma unroll
+    for (int k = 0; k < LB_ROWS; ++k) {
+        const size_t i = tile0 + (size_t)k * (S360_BLOCK * 4) + (size_t)threadIdx.x * 4;
+        uint4 q;
+        q.x = run + row_ex[k] + v[k][0];
+        q.y = q.x + v[k][1];
+        q.z = q.y + v[k][2];
+        q.w = q.z + v[k][3];
+        if (i + 3 < n) {
+            *reinterpret_cast<uint4*>(out + i) = q;
+        } else {
+            const uint32_t qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (i + j < n) out[i + j] = qq[j];
+        }
+        run += row_tot[k];
     }
 }
 
@@ -940,13 +979,13 @@ extern "C" int s360_layout(const S360Params* prm, S360Layout* out) {
     out->header = take(64 * 4);
     out->tiles_touched = take(np * 4);
     out->offsets = take(np * 4);
-    out->scan_scratch = take((np / SCAN_TILE + 2) * 4);
     out->rec_a = take(np * 48);  // one 48-byte record per pair: rec_b / rec_c are the 2nd / 3rd float4 of it
     out->rec_b = out->rec_a + 16;
     out->rec_c = out->rec_a + 32;
     out->clamped = take(np);
     out->depths = take(np * 4);
     out->tile_count = take(nt * 4);
+    out->scan_scratch = take((np / LB_TILE + 2) * 8 + 16);  // look-back scan state + ticket; cleared with tile_count
     out->tile_start = take((nt + 1) * 4);
     out->tile_cursor = take(nt * 4);
     out->keys = take(cap * 8);
@@ -1016,7 +1055,8 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
     uint32_t* tile_max_contrib = (uint32_t*)(ws + L.tile_max_contrib);
     uint32_t* strip_last = (uint32_t*)(ws + L.strip_last);
 
-    if (hipMemsetAsync(tile_count, 0, (size_t)nt * 4, st) != hipSuccess) return S360_E_LAUNCH;
+    // one clear for the tile histogram and the (adjacent) look-back scan state
+    if (hipMemsetAsync(tile_count, 0, L.tile_start - L.tile_count, st) != hipSuccess) return S360_E_LAUNCH;
     if (kp.P > 0) {
         {
         ProfScope ps(PS_PREPROCESS, st);
@@ -1042,10 +1082,10 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
         S360_CHECK_LAUNCH();
         if (!(kp.flags & S360_FLAG_FORWARD_ONLY)) {  // offsets only feed the backward's instance slots
         ProfScope ps(PS_SCAN, st);
-        const int sblk = (int)((np + SCAN_TILE - 1) / SCAN_TILE);
-        hipLaunchKernelGGL(k_scan_block_sums, dim3(sblk), dim3(S360_BLOCK), 0, st, tiles_touched, scratch, np);
-        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(S360_BLOCK), 0, st, scratch, sblk, (uint32_t*)nullptr);
-        hipLaunchKernelGGL(k_scan_final, dim3(sblk), dim3(S360_BLOCK), 0, st, tiles_touched, scratch, offsets, np);
+        const int sblk = (int)((np + LB_TILE - 1) / LB_TILE);
+        unsigned long long* lb_state = (unsigned long long*)scratch;
+        hipLaunchKernelGGL(k_scan_lookback, dim3(sblk), dim3(S360_BLOCK), 0, st, tiles_touched, offsets, np, lb_state,
+                           (uint32_t*)(lb_state + sblk + 1));
         }
         S360_CHECK_LAUNCH();
     }
