@@ -76,11 +76,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
     const int t = (int)(unit >> 2), wave = (int)(unit & 3u), lane = threadIdx.x;
     const int v = t / kp.T, rem = t - v * kp.T;
     const int ty = rem / kp.gx, tx = rem - ty * kp.gx;
-    const int lx = lane & 15, ly = wave * 4 + (lane >> 4);
+    const int lx = sub_ox(wave) + lane % SUB_W, ly = sub_oy(wave) + lane / SUB_W;
     const int px = tx * 16 + lx, py = ty * 16 + ly;
     const bool inside = px < kp.W && py < kp.H;
     const float pxf = (float)px, pyf = (float)py;
-    const float x0 = (float)(tx * 16), ys0 = (float)(ty * 16 + wave * 4);
+    const float x0 = (float)(tx * 16 + sub_ox(wave)), ys0 = (float)(ty * 16 + sub_oy(wave));
 
     const uint32_t start = min(tile_start[t], kp.cap);
     const size_t hw = (size_t)kp.H * kp.W;
@@ -130,7 +130,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
         }
         if (hi - 128 - lane >= 0) p_n2 = list[start + (uint32_t)(hi - 128 - lane)];
 
-        const bool hit = ev && !(ea.x + ewx < x0 || ea.x - ewx > x0 + 15.0f || ea.y + ewy < ys0 || ea.y - ewy > ys0 + 3.0f);
+        const bool hit = ev && !(ea.x + ewx < x0 || ea.x - ewx > x0 + (float)(SUB_W - 1) || ea.y + ewy < ys0 ||
+                                 ea.y - ewy > ys0 + (float)(SUB_H - 1));
         unsigned long long m = __ballot(hit);
         if (m == 0ull) continue;
         // slot of this lane's entry: position of tile (tx,ty) inside the splat's tile rectangle,

@@ -13,7 +13,19 @@
 #define S360_WAVE 64
 #define S360_BLOCK 256
 
+// Pixel footprint of one wave inside a 16x16 tile: SUB_W x (64 / SUB_W) pixels, four of them per tile.
+// 16 -> four 16x4 strips stacked vertically; 8 -> four 8x8 quadrants (fewer (splat, wave) overlaps for the
+// roughly isotropic footprints of the encoder's Gaussians).
+#ifndef S360_SUB_W
+#define S360_SUB_W 8
+#endif
+
 namespace s360 {
+
+constexpr int SUB_W = S360_SUB_W, SUB_H = 64 / S360_SUB_W;
+__device__ __forceinline__ int sub_ox(int w) { return SUB_W == 16 ? 0 : 8 * (w & 1); }
+__device__ __forceinline__ int sub_oy(int w) { return SUB_W == 16 ? 4 * w : 8 * (w >> 1); }
+
 
 // Problem description passed by value to every kernel (lands in SGPRs).
 struct KParams {

@@ -191,7 +191,6 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess(
 }
 
 // ------------------------------------------------------------------------------ scans
-// Inclusive scan of n uint32 in three launches: per-block totals, scan of totals, final pass.
 
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* lds, uint32_t& total) {
     // wave-level inclusive scan by shuffles, then 4 wave totals through LDS
@@ -222,7 +221,10 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* l
 // and the first wave of each block walks back over its predecessors 64 at a time.  One 4-byte read and one
 // 4-byte write per element; coalesced 16-byte accesses (row k of a tile = 1024 consecutive elements, 4 per lane).
 // `state` ([ntiles] words) and `ticket` must be zero at launch (cleared together with tile_count).
-constexpr int LB_ROWS = 4;
+#ifndef S360_LB_ROWS
+#define S360_LB_ROWS 8
+#endif
+constexpr int LB_ROWS = S360_LB_ROWS;
 constexpr int LB_TILE = S360_BLOCK * 4 * LB_ROWS;  // 4096 elements per block
 
 __global__ __launch_bounds__(S360_BLOCK) void k_scan_lookback(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t n,
@@ -727,12 +729,12 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
     const int t = blockIdx.x;
     const int v = t / kp.T, rem = t - v * kp.T;
     const int ty = rem / kp.gx, tx = rem - ty * kp.gx;
-    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lx = sub_ox(wave) + lane % SUB_W, ly = sub_oy(wave) + lane / SUB_W;
     const int px = tx * 16 + lx, py = ty * 16 + ly;
     const bool inside = px < kp.W && py < kp.H;
     const float pxf = (float)px, pyf = (float)py;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const float x0 = (float)(tx * 16), ys0 = (float)(ty * 16 + wave * 4);  // strip origin
+    const float x0 = (float)(tx * 16 + sub_ox(wave)), ys0 = (float)(ty * 16 + sub_oy(wave));  // footprint origin
 
     const uint32_t start = min(tile_start[t], kp.cap), end = min(tile_start[t + 1], kp.cap);
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
@@ -771,7 +773,8 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
         }
         if (b + 128 + lane < end) p_n2 = list[b + 128 + lane];
 
-        const bool hit = ev && !(ea.x + ewx < x0 || ea.x - ewx > x0 + 15.0f || ea.y + ewy < ys0 || ea.y - ewy > ys0 + 3.0f);
+        const bool hit = ev && !(ea.x + ewx < x0 || ea.x - ewx > x0 + (float)(SUB_W - 1) || ea.y + ewy < ys0 ||
+                                 ea.y - ewy > ys0 + (float)(SUB_H - 1));
         unsigned long long m = __ballot(hit);
 #ifdef S360_DBG_COUNT
         {
