@@ -121,7 +121,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess(
                             a0 = acc[0]; a1 = acc[1]; a2 = acc[2];
                         } else if (kp.M == 25 && kp.deg == 4) {
                             // interleaved [k][rgb]: five chunks of 5 coefficients x 3 channels (15 floats)
-#pragma unroll 1
+#pragma unroll  // fully unrolled: Y[] indexed by constants stays in registers (a rolled loop put it in scratch)
                             for (int q = 0; q < 5; ++q) {
                                 float c[15];
                                 load15(sh + 15 * q, c);
