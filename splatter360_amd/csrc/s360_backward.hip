@@ -151,38 +151,39 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
             const float alpha = fminf(0.99f, op * G);
             const bool active = contributor < last && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
             if (__ballot(active) == 0ull) continue;  // wave-uniform: nothing to reduce
-            float g_x = 0.f, g_y = 0.f, g_A = 0.f, g_B = 0.f, g_C = 0.f, g_op = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f;
-            if (active) {
-                // 1/(1-alpha): hardware reciprocal + one Newton step (<= 1 ulp), shared by both quotients
-                const float om = 1.0f - alpha;
-                float rcp = __builtin_amdgcn_rcpf(om);
-                rcp = __builtin_fmaf(__builtin_fmaf(-om, rcp, 1.0f), rcp, rcp);
-                T = T * rcp;
-                const float dchannel_dcolor = alpha * T;
-                const float c0 = rl(eb.z, bit), c1 = rl(eb.w, bit), c2 = rl(ec, bit);
-                acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
-                acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
-                acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2;
-                lc0 = c0; lc1 = c1; lc2 = c2;
-                float dL_dalpha = (c0 - acc0) * dp0 + (c1 - acc1) * dp1 + (c2 - acc2) * dp2;
-                g_r = dchannel_dcolor * dp0;
-                g_g = dchannel_dcolor * dp1;
-                g_b = dchannel_dcolor * dp2;
-                dL_dalpha *= T;
-                last_alpha = alpha;
-                dL_dalpha += (-T_final * rcp) * bg_dot;
-                const float dL_dG = op * dL_dalpha;
-                const float gdx = G * dx, gdy = G * dy;
-                // dG/d(delta) = -G (a dx + b dy) = ln2 * G (2 a' dx + b' dy)   (a' = -log2e/2 a, b' = -log2e b)
-                const float dG_ddelx = 0.6931471805599453f * (2.0f * gdx * cA + gdy * cB);
-                const float dG_ddely = 0.6931471805599453f * (2.0f * gdy * cC + gdx * cB);
-                g_x = dL_dG * dG_ddelx;
-                g_y = dL_dG * dG_ddely;
-                g_A = -0.5f * gdx * dx * dL_dG;
-                g_B = -gdx * dy * dL_dG;
-                g_C = -0.5f * gdy * dy * dL_dG;
-                g_op = G * dL_dalpha;
-            }
+            // Branch-free: a lane that is not a contributor runs the same arithmetic with alpha = G = 0, which
+            // leaves its T / accumulated-colour state unchanged bit for bit (T*1; acc' = 0*c + 1*acc) and makes
+            // all nine products exactly zero — no exec-mask juggling, no zero-fill of the reduction inputs.
+            const float a_eff = active ? alpha : 0.0f, G_eff = active ? G : 0.0f;
+            // 1/(1-alpha): hardware reciprocal + one Newton step (<= 1 ulp), shared by both quotients
+            const float om = 1.0f - a_eff;
+            float rcp = __builtin_amdgcn_rcpf(om);
+            rcp = __builtin_fmaf(__builtin_fmaf(-om, rcp, 1.0f), rcp, rcp);
+            T = T * rcp;
+            const float dchannel_dcolor = a_eff * T;
+            const float c0 = rl(eb.z, bit), c1 = rl(eb.w, bit), c2 = rl(ec, bit);
+            acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
+            acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
+            acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2;
+            lc0 = c0; lc1 = c1; lc2 = c2;
+            float dL_dalpha = (c0 - acc0) * dp0 + (c1 - acc1) * dp1 + (c2 - acc2) * dp2;
+            float g_r = dchannel_dcolor * dp0;
+            float g_g = dchannel_dcolor * dp1;
+            float g_b = dchannel_dcolor * dp2;
+            dL_dalpha *= T;
+            last_alpha = a_eff;
+            dL_dalpha += (-T_final * rcp) * bg_dot;
+            const float dL_dG = op * dL_dalpha;
+            const float gdx = G_eff * dx, gdy = G_eff * dy;
+            // dG/d(delta) = -G (a dx + b dy) = ln2 * G (2 a' dx + b' dy)   (a' = -log2e/2 a, b' = -log2e b)
+            const float dG_ddelx = 0.6931471805599453f * (2.0f * gdx * cA + gdy * cB);
+            const float dG_ddely = 0.6931471805599453f * (2.0f * gdy * cC + gdx * cB);
+            float g_x = dL_dG * dG_ddelx;
+            float g_y = dL_dG * dG_ddely;
+            float g_A = -0.5f * gdx * dx * dL_dG;
+            float g_B = -gdx * dy * dL_dG;
+            float g_C = -0.5f * gdy * dy * dL_dG;
+            float g_op = G_eff * dL_dalpha;
 #ifdef S360_PLAIN_REDUCE
             wave_sum9_lane63(g_x, g_y, g_A, g_B, g_C, g_op, g_r, g_g, g_b);
             const uint32_t inst = (uint32_t)__builtin_amdgcn_readlane((int)einst, bit);
