@@ -105,7 +105,7 @@ typedef struct S360Layout {
     size_t final_T;             /* float[V*H*W] */
     size_t n_contrib;           /* uint32[V*H*W] */
     size_t tile_max_contrib;    /* uint32[V*T] */
-    size_t strip_last;          /* uint32[V*T*4] max n_contrib of each 16x4 strip */
+    size_t strip_last;          /* uint32[V*T*4] max n_contrib of each of the four 8x8 quadrants of a tile */
     size_t backward_bytes;      /* size of the separate backward scratch workspace */
 } S360Layout;
 
