@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define S360_ABI_VERSION 7
+#define S360_ABI_VERSION 8
 #define S360_MAX_VIEWS 8
 #define S360_TILE 16
 
@@ -90,7 +90,6 @@ typedef struct S360Layout {
     size_t header;              /* uint32[64]: [0]=num_instances [1]=overflow flag [2]=max tile list length */
     size_t tiles_touched;       /* uint32[V*P] */
     size_t offsets;             /* uint32[V*P]  inclusive scan of tiles_touched (upstream point_offsets) */
-    size_t scan_scratch;        /* uint32[...] */
     /* one 48-byte record per pair, stride 48 B: rec_b / rec_c = rec_a + 16 / + 32 (one cache line per gather) */
     size_t rec_a;               /* float4  x, y, -log2(e)/2 * conic.a, -log2(e) * conic.b */
     size_t rec_b;               /* float4  -log2(e)/2 * conic.c, opacity, r, g */
@@ -98,9 +97,12 @@ typedef struct S360Layout {
     size_t clamped;             /* uint8[V*P]   bit c set: colour channel c was clamped at 0 */
     size_t depths;              /* float[V*P]   view-space z of visible pairs (sort key) */
     size_t tile_count;          /* uint32[V*T] */
+    size_t scan_scratch;        /* look-back scan state + ticket (cleared together with tile_count) */
     size_t tile_start;          /* uint32[V*T+1] exclusive scan (upstream ranges: [start[t], start[t+1])) */
     size_t tile_cursor;         /* uint32[V*T] */
+    size_t chunk_start;         /* uint32[V*T+1] number of 4096-key sort chunks of long lists before tile t */
     size_t keys;                /* uint64[max_instances]  (depth bits << 32 | pair index), sorted per tile */
+    size_t keys_alt;            /* uint64[max_instances]  ping-pong buffer of the long-list merge passes */
     size_t list;                /* uint32[max_instances]  sorted pair indices p = v*P + g (upstream point_list) */
     size_t final_T;             /* float[V*H*W] */
     size_t n_contrib;           /* uint32[V*H*W] */

@@ -308,30 +308,46 @@ __global__ __launch_bounds__(S360_BLOCK) void k_scan_lookback(const uint32_t* __
 }
 
 // single block: tile_start[0..nt] = exclusive scan of tile_count; header bookkeeping.
+// Lists longer than SORT_SHORT keys are sorted as chunks of SORT_CHUNK keys (k_sort_chunks: one 512-thread
+// workgroup per chunk) followed, when there is more than one chunk, by global merge passes (k_merge_pass);
+// chunk_start[t] = number of such chunks before tile t (0 chunks for the short tiles, which have their own class).
+constexpr uint32_t SORT_SHORT = 2048;
+constexpr uint32_t SORT_CHUNK = 4096;
+constexpr uint32_t MAX_PASSES = 4;
+
 __global__ __launch_bounds__(S360_BLOCK) void k_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_start,
                                                          uint32_t* __restrict__ tile_cursor, uint32_t* __restrict__ tile_max_contrib,
-                                                         int nt, uint32_t cap, uint32_t* __restrict__ header) {
+                                                         int nt, uint32_t cap, uint32_t* __restrict__ header,
+                                                         uint32_t* __restrict__ chunk_start) {
     __shared__ uint32_t lds[8];
     __shared__ uint32_t lds_max;
     if (threadIdx.x == 0) lds_max = 0;
     __syncthreads();
-    uint32_t carry = 0, mx = 0;
+    uint32_t carry = 0, mx = 0, ccarry = 0;
     for (int b = 0; b < nt; b += S360_BLOCK) {
         const int i = b + threadIdx.x;
         const uint32_t v = i < nt ? tile_count[i] : 0u;
         mx = max(mx, v);
         uint32_t tot;
         const uint32_t ex = block_exclusive_scan(v, lds, tot);
+        // the sort kernels see list lengths clamped to the binning capacity
+        const uint32_t nclamp = min(carry + ex + v, cap) - min(carry + ex, cap);
+        const uint32_t nch = nclamp > SORT_SHORT ? (nclamp + SORT_CHUNK - 1) / SORT_CHUNK : 0u;
+        uint32_t ctot;
+        const uint32_t cex = block_exclusive_scan(nch, lds, ctot);
         if (i < nt) {
             tile_start[i] = carry + ex;
             tile_cursor[i] = 0;
             tile_max_contrib[i] = 0;
+            chunk_start[i] = ccarry + cex;
         }
         carry += tot;
+        ccarry += ctot;
     }
     atomicMax(&lds_max, mx);
     __syncthreads();
     if (threadIdx.x == 0) {
+        chunk_start[nt] = ccarry;
         tile_start[nt] = carry;
         header[0] = carry;                    // num_instances ("num_rendered")
         header[1] = carry > cap ? 1u : 0u;    // overflow flag
@@ -448,22 +464,17 @@ __global__ __launch_bounds__(THREADS) void k_sort_tiles(const uint32_t* __restri
 // 4-ary merge-path search + in-register bitonic merge of 2E candidates (more instructions; the kernel is
 // issue-bound on 64-bit compares/selects, not LDS-latency-bound), and the LDS radix sort below.
 template <int THREADS, int E>
-__global__ __launch_bounds__(THREADS) void k_sort_tiles_merge(const uint32_t* __restrict__ tile_start, uint64_t* __restrict__ keys,
-                                                             uint32_t* __restrict__ list, uint32_t lo, uint32_t cap) {
-    constexpr int CAP = THREADS * E;
+__device__ __forceinline__ void block_merge_sort(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
+                                                 uint32_t* __restrict__ list, uint32_t n, uint64_t* lds_m) {
     // [CAP + CAP/E]: one pad slot per E keys.  Threads walk the runs with a stride of ~E (or ~E/2) keys;
     // without the skew those 64 / 128-byte strides land on 4 / 2 bank groups (16- / 32-way conflicts).
-    extern __shared__ __attribute__((aligned(16))) uint64_t lds_m[];
 #define S360_PHYS(i) ((i) + (i) / E)
-    const uint32_t s = min(tile_start[blockIdx.x], cap), e = min(tile_start[blockIdx.x + 1], cap);
-    const uint32_t n = e - s;
-    if (n <= lo || n > (uint32_t)CAP) return;
     const int tid = threadIdx.x;
     uint64_t k[E];
 #pragma unroll
     for (int q = 0; q < E; ++q) {
         const uint32_t i = (uint32_t)(tid * E + q);
-        k[q] = i < n ? keys[s + i] : ~0ull;
+        k[q] = i < n ? in[i] : ~0ull;
     }
     // in-register sort of the thread's E keys
 #pragma unroll
@@ -520,8 +531,126 @@ __global__ __launch_bounds__(THREADS) void k_sort_tiles_merge(const uint32_t* __
         const uint32_t i = (uint32_t)(tid * E + q);
         if (i < n) {
             const uint64_t kq = lds_m[S360_PHYS(i)];
-            keys[s + i] = kq;
-            list[s + i] = (uint32_t)kq;
+            out[i] = kq;
+            if (list) list[i] = (uint32_t)kq;
+        }
+    }
+#undef S360_PHYS
+}
+
+// One workgroup per tile whose list length n satisfies lo < n <= THREADS*E.
+template <int THREADS, int E>
+__global__ __launch_bounds__(THREADS) void k_sort_tiles_merge(const uint32_t* __restrict__ tile_start, uint64_t* __restrict__ keys,
+                                                             uint32_t* __restrict__ list, uint32_t lo, uint32_t cap) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds_m[];
+    const uint32_t s = min(tile_start[blockIdx.x], cap), e = min(tile_start[blockIdx.x + 1], cap);
+    const uint32_t n = e - s;
+    if (n <= lo || n > (uint32_t)(THREADS * E)) return;
+    block_merge_sort<THREADS, E>(keys + s, keys + s, list + s, n, lds_m);
+}
+
+// ---- long lists (n > SORT_CHUNK): chunk sort + global merge passes ------------------------------------------
+// Work unit = one SORT_CHUNK-sized output chunk (t, k) of a long tile, found from the block index by a binary
+// search over chunk_start[].  A tile with c chunks needs P = ceil(log2 c) merge passes; it ping-pongs between
+// `keys` and `alt` such that the LAST pass lands in `keys`: the buffer holding the runs before pass i is
+// `alt` when (P - i) is odd.  Tiles needing more than max_passes passes are left to k_sort_tiles_global.
+__device__ __forceinline__ uint32_t ceil_log2_u32(uint32_t x) { return x <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(x - 1); }
+
+struct ChunkUnit {
+    uint32_t s, n, k, passes;  // tile start (clamped), tile length, chunk index inside the tile, merge passes of the tile
+    bool valid;
+};
+__device__ __forceinline__ ChunkUnit chunk_unit(const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ chunk_start,
+                                                 int nt, uint32_t cap, uint32_t b) {
+    ChunkUnit u;
+    u.valid = b < chunk_start[nt];
+    u.s = u.n = u.k = u.passes = 0;
+    if (!u.valid) return u;
+    int lo = 0, hi = nt;  // last t with chunk_start[t] <= b  (chunk_start is non-decreasing)
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (chunk_start[mid] <= b) lo = mid; else hi = mid;
+    }
+    u.s = min(tile_start[lo], cap);
+    u.n = min(tile_start[lo + 1], cap) - u.s;
+    u.k = b - chunk_start[lo];
+    u.passes = ceil_log2_u32((u.n + SORT_CHUNK - 1) / SORT_CHUNK);
+    return u;
+}
+
+__global__ __launch_bounds__(512) void k_sort_chunks(const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ chunk_start,
+                                                    int nt, uint64_t* __restrict__ keys, uint64_t* __restrict__ alt,
+                                                    uint32_t* __restrict__ list, uint32_t cap, uint32_t max_passes) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds_m[];
+    const ChunkUnit u = chunk_unit(tile_start, chunk_start, nt, cap, blockIdx.x);
+    if (!u.valid || u.passes > max_passes) return;
+    const uint32_t c0 = u.k * SORT_CHUNK, len = min(SORT_CHUNK, u.n - c0);
+    uint64_t* dst = ((u.passes & 1u) ? alt : keys) + u.s + c0;
+    block_merge_sort<512, 8>(keys + u.s + c0, dst, u.passes == 0 ? list + u.s : nullptr, len, lds_m);  // single chunk: done
+}
+
+// merge path over two sorted runs in global memory: number of A elements among the first d outputs
+__device__ __forceinline__ uint32_t merge_path_global(const uint64_t* __restrict__ A, uint32_t la, const uint64_t* __restrict__ B,
+                                                      uint32_t lb, uint32_t d) {
+    uint32_t lo = d > lb ? d - lb : 0u, hi = d < la ? d : la;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (A[mid] <= B[d - 1 - mid]) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(512) void k_merge_pass(const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ chunk_start,
+                                                   int nt, uint64_t* __restrict__ keys, uint64_t* __restrict__ alt,
+                                                   uint32_t* __restrict__ list, uint32_t cap, uint32_t pass, uint32_t max_passes) {
+    constexpr int THREADS = 512, E = 8;
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds_m[];  // [SORT_CHUNK + SORT_CHUNK/E] skewed
+    __shared__ uint32_t s_part[2];
+#define S360_PHYS(i) ((i) + (i) / E)
+    const ChunkUnit u = chunk_unit(tile_start, chunk_start, nt, cap, blockIdx.x);
+    if (!u.valid || u.passes > max_passes || pass >= u.passes) return;
+    const uint32_t R = SORT_CHUNK << pass;
+    const uint32_t o_tile = u.k * SORT_CHUNK, len = min(SORT_CHUNK, u.n - o_tile);
+    const uint32_t pair0 = o_tile / (2 * R) * (2 * R);
+    const uint32_t la = min(R, u.n - pair0), lb = min(R, u.n - pair0 - la);
+    const uint64_t* src = (((u.passes - pass) & 1u) ? alt : keys) + u.s + pair0;
+    uint64_t* dst = (((u.passes - pass - 1) & 1u) ? alt : keys) + u.s + o_tile;
+    const uint64_t* A = src;
+    const uint64_t* B = src + la;
+    const uint32_t o = o_tile - pair0;
+    if (threadIdx.x < 2) s_part[threadIdx.x] = merge_path_global(A, la, B, lb, o + threadIdx.x * len);
+    __syncthreads();
+    const uint32_t a0 = s_part[0], a1 = s_part[1], b0 = o - a0, b1 = o + len - a1;
+    const uint32_t na = a1 - a0, nb = b1 - b0;  // na + nb == len
+    for (uint32_t i = threadIdx.x; i < len; i += THREADS) lds_m[S360_PHYS(i)] = i < na ? A[a0 + i] : B[b0 + (i - na)];
+    __syncthreads();
+    // in-LDS merge of the two pieces: logical run A = [0, na), run B = [na, na + nb)
+    const uint32_t out0 = (uint32_t)threadIdx.x * E;
+    if (out0 < len) {
+        uint32_t lo_a = out0 > nb ? out0 - nb : 0u, hi_a = out0 < na ? out0 : na;
+        while (lo_a < hi_a) {
+            const uint32_t mid = (lo_a + hi_a) >> 1;
+            if (lds_m[S360_PHYS(mid)] <= lds_m[S360_PHYS(na + out0 - 1 - mid)]) lo_a = mid + 1; else hi_a = mid;
+        }
+        uint32_t a = lo_a, b = out0 - lo_a;
+        uint64_t ka = a < na ? lds_m[S360_PHYS(a)] : ~0ull, kb = b < nb ? lds_m[S360_PHYS(na + b)] : ~0ull;
+        const bool last_pass = pass + 1 == u.passes;
+        uint32_t* lst = list + u.s + o_tile;
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+            const bool take_a = ka <= kb;
+            const uint64_t kq = take_a ? ka : kb;
+            if (take_a) {
+                ++a;
+                ka = a < na ? lds_m[S360_PHYS(a)] : ~0ull;
+            } else {
+                ++b;
+                kb = b < nb ? lds_m[S360_PHYS(na + b)] : ~0ull;
+            }
+            if (out0 + q < len) {
+                dst[out0 + q] = kq;
+                if (last_pass) lst[out0 + q] = (uint32_t)kq;
+            }
         }
     }
 #undef S360_PHYS
@@ -991,7 +1120,9 @@ extern "C" int s360_layout(const S360Params* prm, S360Layout* out) {
     out->scan_scratch = take((np / LB_TILE + 2) * 8 + 16);  // look-back scan state + ticket; cleared with tile_count
     out->tile_start = take((nt + 1) * 4);
     out->tile_cursor = take(nt * 4);
+    out->chunk_start = take((nt + 1) * 4);
     out->keys = take(cap * 8);
+    out->keys_alt = take(cap * 8);
     out->list = take(cap * 4);
     out->final_T = take(npix * 4);
     out->n_contrib = take(npix * 4);
@@ -1052,6 +1183,8 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
     uint32_t* tile_start = (uint32_t*)(ws + L.tile_start);
     uint32_t* tile_cursor = (uint32_t*)(ws + L.tile_cursor);
     uint64_t* keys = (uint64_t*)(ws + L.keys);
+    uint64_t* keys_alt = (uint64_t*)(ws + L.keys_alt);
+    uint32_t* chunk_start = (uint32_t*)(ws + L.chunk_start);
     uint32_t* list = (uint32_t*)(ws + L.list);
     float* final_T = (float*)(ws + L.final_T);
     uint32_t* n_contrib = (uint32_t*)(ws + L.n_contrib);
@@ -1094,7 +1227,8 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
     }
     {
         ProfScope ps(PS_TILE_SCAN, st);
-        hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(S360_BLOCK), 0, st, tile_count, tile_start, tile_cursor, tile_max_contrib, nt, kp.cap, header);
+        hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(S360_BLOCK), 0, st, tile_count, tile_start, tile_cursor, tile_max_contrib, nt, kp.cap, header,
+                           chunk_start);
     }
     S360_CHECK_LAUNCH();
     if (kp.P > 0) {
@@ -1115,6 +1249,7 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
         // fork them onto a side stream so they overlap with the ~1.5 K short lists on the main stream.
         SideStream* ss = side_stream();
         const bool bitonic = getenv("S360_SORT_BITONIC") != nullptr;
+        uint32_t global_lo = 16384u;  // lists longer than this go to the global-memory network
         if (bitonic) {
             if (ss) {
                 (void)hipEventRecord(ss->fork, st);
@@ -1129,21 +1264,34 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
             else
                 hipLaunchKernelGGL((k_sort_tiles<16384, 1024>), dim3(nt), dim3(1024), 16384 * 8, st, tile_start, keys, list, 4096u, kp.cap, tile_cursor);
         } else {
-            // merge-sort classes; the few > 4096-entry lists go to the side stream and overlap with the rest
+            // Lists of up to 2 048 keys (the bulk) are sorted by one 256-thread workgroup each, on the side stream;
+            // meanwhile the main stream takes the rest as 4 096-key chunks, one 512-thread workgroup each
+            // (k_sort_chunks), followed for multi-chunk lists by `passes` global merge passes (k_merge_pass).  The
+            // number of pass launches is fixed on the host (no read-back): enough for the longest possible list,
+            // capped at MAX_PASSES (4 096 << 4 = 65 536 keys); anything longer falls through to the global network.
+            const size_t cap_keys = kp.cap < (uint32_t)kp.P ? kp.cap : (size_t)kp.P;   // a tile holds a Gaussian at most once
+            uint32_t passes = 0;
+            while (passes < MAX_PASSES && ((size_t)SORT_CHUNK << passes) < cap_keys) ++passes;
+            global_lo = SORT_CHUNK << passes;
+            // >= number of chunks: every chunk but the last of a tile is full, and a tile with chunks has > SORT_SHORT keys
+            const unsigned cgrid = (unsigned)((size_t)kp.cap / SORT_CHUNK + (size_t)kp.cap / SORT_SHORT + 2);
+            const size_t lds512 = (4096 + 512) * 8;
             if (ss) {
                 (void)hipEventRecord(ss->fork, st);
                 (void)hipStreamWaitEvent(ss->stream, ss->fork, 0);
-                hipLaunchKernelGGL((k_sort_tiles_merge<1024, 16>), dim3(nt), dim3(1024), (16384 + 1024) * 8, ss->stream, tile_start, keys, list, 4096u, kp.cap);
+                hipLaunchKernelGGL((k_sort_tiles_merge<256, 8>), dim3(nt), dim3(256), (2048 + 256) * 8, ss->stream, tile_start, keys, list, 0u, kp.cap);
                 (void)hipEventRecord(ss->join, ss->stream);
             }
-            hipLaunchKernelGGL((k_sort_tiles_merge<256, 8>), dim3(nt), dim3(256), (2048 + 256) * 8, st, tile_start, keys, list, 0u, kp.cap);
-            hipLaunchKernelGGL((k_sort_tiles_merge<512, 8>), dim3(nt), dim3(512), (4096 + 512) * 8, st, tile_start, keys, list, 2048u, kp.cap);
+            hipLaunchKernelGGL(k_sort_chunks, dim3(cgrid), dim3(512), lds512, st, tile_start, chunk_start, nt, keys, keys_alt, list, kp.cap, passes);
+            for (uint32_t p = 0; p < passes; ++p)
+                hipLaunchKernelGGL(k_merge_pass, dim3(cgrid), dim3(512), lds512, st, tile_start, chunk_start, nt, keys, keys_alt, list,
+                                   kp.cap, p, passes);
             if (ss)
                 (void)hipStreamWaitEvent(st, ss->join, 0);
             else
-                hipLaunchKernelGGL((k_sort_tiles_merge<1024, 16>), dim3(nt), dim3(1024), (16384 + 1024) * 8, st, tile_start, keys, list, 4096u, kp.cap);
+                hipLaunchKernelGGL((k_sort_tiles_merge<256, 8>), dim3(nt), dim3(256), (2048 + 256) * 8, st, tile_start, keys, list, 0u, kp.cap);
         }
-        hipLaunchKernelGGL(k_sort_tiles_global, dim3(nt), dim3(S360_BLOCK), 0, st, tile_start, keys, list, 16384u, kp.cap);
+        hipLaunchKernelGGL(k_sort_tiles_global, dim3(nt), dim3(S360_BLOCK), 0, st, tile_start, keys, list, global_lo, kp.cap);
         S360_CHECK_LAUNCH();
     }
     {
