@@ -1,16 +1,18 @@
 // s360_forward.hip — forward kernels: fused multi-view preprocess, scans, tile binning,
-// per-tile depth sort in LDS, front-to-back composite.  gfx950 / wave64 only.
+// per-tile depth sort, front-to-back composite.  gfx950 / wave64 only.
 //
-// Pipeline (all asynchronous on one stream, no host sync):
-//   k_preprocess    1 thread / Gaussian, loops the V views in registers: cull, EWA cov2D, conic,
-//                   radius, tile rect; SH->RGB once per Gaussian when the views share campos;
-//                   SH coefficients staged through LDS with coalesced 16-byte loads.
-//   k_scan_*        inclusive scan of tiles_touched over the V*P (view, Gaussian) pairs
-//   k_tile_scan     exclusive scan of the per-tile instance counts  -> tile ranges
-//   k_emit          scatter (depth bits << 32 | pair) keys into their tile's bucket
-//   k_sort_tiles    bitonic sort of each tile's bucket inside LDS (unique 64-bit keys: the order
-//                   equals a stable radix sort by (tile, depth) with ascending-index emission)
-//   k_render        1 workgroup (4 waves) per 16x16 tile, LDS-staged batches of 256 splats
+// Pipeline (all asynchronous on the caller's stream + one internal side stream, no host sync):
+//   k_preprocess     1 thread / Gaussian, loops the V views in registers: cull, EWA cov2D, conic,
+//                    radius, tile rect; SH->RGB once per Gaussian when the views share campos
+//                    (each lane streams its own 300-byte slab with 16-byte loads).
+//   k_scan_lookback  single-pass inclusive scan of tiles_touched over the V*P (view, Gaussian) pairs
+//   k_tile_scan      exclusive scan of the per-tile instance counts -> tile ranges (+ sort-chunk table)
+//   k_emit           scatter (depth bits << 32 | pair) keys into their tile's bucket
+//   k_sort_tiles_merge / k_sort_chunks / k_merge_pass / k_sort_tiles_global
+//                    per-tile ascending sort of the unique 64-bit keys (== stable radix sort by
+//                    (tile, depth) with ascending-index emission): LDS merge sort per list or per
+//                    4096-key chunk, global merge-path passes for multi-chunk lists
+//   k_render         1 workgroup per 16x16 tile = 4 autonomous waves of 8x8 pixels (no LDS, no barriers)
 #include "s360_device.h"
 #include "s360_prof.h"
 
@@ -414,47 +416,6 @@ __global__ __launch_bounds__(S360_BLOCK) void k_emit(KParams kp, const uint32_t*
 }
 
 // ------------------------------------------------------------------------------ per-tile sort
-// One workgroup per tile whose list length n satisfies lo < n <= CAP: bitonic sort of the unique
-// 64-bit keys in LDS, then writes the sorted keys back and the pair list.
-template <int CAP, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_sort_tiles(const uint32_t* __restrict__ tile_start, uint64_t* __restrict__ keys,
-                                                          uint32_t* __restrict__ list, uint32_t lo, uint32_t cap, uint32_t* __restrict__ dbg) {
-#ifdef S360_DBG_TIMING
-    const long long t_begin = wall_clock64();
-#endif
-    extern __shared__ __attribute__((aligned(16))) uint64_t lds_k[];
-    const uint32_t s = min(tile_start[blockIdx.x], cap), e = min(tile_start[blockIdx.x + 1], cap);
-    const uint32_t n = e - s;
-    if (n <= lo || n > (uint32_t)CAP) return;
-    uint32_t npad = 1;
-    while (npad < n) npad <<= 1;
-    for (uint32_t i = threadIdx.x; i < npad; i += THREADS) lds_k[i] = i < n ? keys[s + i] : ~0ull;
-    __syncthreads();
-    for (uint32_t k = 2; k <= npad; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t t = threadIdx.x; t < (npad >> 1); t += THREADS) {
-                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // index with bit j clear
-                const uint32_t l = i | j;
-                const uint64_t a = lds_k[i], b = lds_k[l];
-                const bool up = (i & k) == 0;
-                if ((a > b) == up) {
-                    lds_k[i] = b;
-                    lds_k[l] = a;
-                }
-            }
-            __syncthreads();
-        }
-    }
-    for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
-        const uint64_t k = lds_k[i];
-        keys[s + i] = k;
-        list[s + i] = (uint32_t)k;
-    }
-#ifdef S360_DBG_TIMING
-    if (threadIdx.x == 0) dbg[blockIdx.x] = (uint32_t)(wall_clock64() - t_begin);
-#endif
-}
-
 // Merge sort of one tile's bucket in LDS: every thread sorts E keys in registers (odd-even transposition
 // network), then log2(THREADS) merge passes; in each pass a thread finds its slice of the two runs being
 // merged with a merge-path binary search and merges E outputs serially.  ~2 barriers and ~(2E + log n)
@@ -462,7 +423,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_tiles(const uint32_t* __restri
 // the bitonic network.  Keys are unique, so the result is the one ascending order (== stable radix sort
 // by (tile, depth), index-ordered emission).  Measured alternatives that were slower on this workload:
 // 4-ary merge-path search + in-register bitonic merge of 2E candidates (more instructions; the kernel is
-// issue-bound on 64-bit compares/selects, not LDS-latency-bound), and the LDS radix sort below.
+// issue-bound on 64-bit compares/selects, not LDS-latency-bound), and an LDS radix sort.
 template <int THREADS, int E>
 __device__ __forceinline__ void block_merge_sort(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
                                                  uint32_t* __restrict__ list, uint32_t n, uint64_t* lds_m) {
@@ -679,121 +640,7 @@ __global__ __launch_bounds__(512) void k_merge_pass(const uint32_t* __restrict__
 #undef S360_PHYS
 }
 
-// LDS radix sort of one tile's bucket: LSD, 4-bit digits over the 32 depth bits (passes whose digit is
-// constant over the tile are skipped), E contiguous keys per thread so every pass is stable.  ~6x less
-// LDS traffic than the bitonic network for the common 1-4 K lists.  The low 32 bits (pair index) only
-// matter for equal depths; if the tile contains any such tie the (rare) slow path re-sorts the full
-// 64-bit keys with the bitonic network, so the result is always the unique ascending key order.
-template <int THREADS, int E>
-__global__ __launch_bounds__(THREADS) void k_sort_tiles_radix(const uint32_t* __restrict__ tile_start, uint64_t* __restrict__ keys,
-                                                             uint32_t* __restrict__ list, uint32_t lo, uint32_t cap) {
-    constexpr int CAP = THREADS * E;
-    constexpr int WAVES = THREADS / 64;
-    extern __shared__ __attribute__((aligned(16))) uint64_t lds_r[];  // [CAP] A, [CAP] B, then uint16 cnt[16*THREADS], scratch
-    uint64_t* bufA = lds_r;
-    uint64_t* bufB = lds_r + CAP;
-    uint16_t* cnt = reinterpret_cast<uint16_t*>(lds_r + 2 * CAP);
-    uint32_t* wsum = reinterpret_cast<uint32_t*>(cnt + 16 * THREADS);  // [WAVES + 2]
-    const uint32_t s = min(tile_start[blockIdx.x], cap), e = min(tile_start[blockIdx.x + 1], cap);
-    const uint32_t n = e - s;
-    if (n <= lo || n > (uint32_t)CAP) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
-    // load (padding = all-ones keys) and find which depth bits vary inside the tile
-    uint32_t diff = 0;
-    const uint32_t ref_hi = (uint32_t)(keys[s] >> 32);
-    for (uint32_t i = tid; i < (uint32_t)CAP; i += THREADS) {
-        const uint64_t k = i < n ? keys[s + i] : ~0ull;
-        bufA[i] = k;
-        if (i < n) diff |= (uint32_t)(k >> 32) ^ ref_hi;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) diff |= (uint32_t)__shfl_xor((int)diff, o);
-    if (lane == 0) wsum[wave] = diff;
-    __syncthreads();
-    diff = 0;
-#pragma unroll
-    for (int w = 0; w < WAVES; ++w) diff |= wsum[w];
-    __syncthreads();
-
-    uint64_t* src = bufA;
-    uint64_t* dst = bufB;
-    for (int shift = 32; shift < 64; shift += 4) {
-        if (((diff >> (shift - 32)) & 15u) == 0u) continue;  // digit constant over the tile
-        uint64_t k[E];
-        uint64_t packed = 0;  // 16 x 4-bit counters (E <= 15)
-#pragma unroll
-        for (int q = 0; q < E; ++q) {
-            k[q] = src[tid * E + q];
-            packed += 1ull << (4 * (int)((k[q] >> shift) & 15ull));
-        }
-#pragma unroll
-        for (int b = 0; b < 16; ++b) cnt[b * THREADS + tid] = (uint16_t)((packed >> (4 * b)) & 15ull);
-        __syncthreads();
-        // exclusive scan of the 16*THREADS counters (bin-major): thread t owns entries [16t, 16t+16)
-        uint32_t v[16];
-        uint32_t tot = 0;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            v[q] = cnt[tid * 16 + q];
-            tot += v[q];
-        }
-        uint32_t inc = tot;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t2 = (uint32_t)__shfl_up((int)inc, o);
-            if (lane >= o) inc += t2;
-        }
-        if (lane == 63) wsum[wave] = inc;
-        __syncthreads();
-        uint32_t run = inc - tot;
-#pragma unroll
-        for (int w = 0; w < WAVES; ++w)
-            if (w < wave) run += wsum[w];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            cnt[tid * 16 + q] = (uint16_t)run;
-            run += v[q];
-        }
-        __syncthreads();
-        // stable scatter: a thread's keys go out in order, each to the next slot of its (digit, thread) counter
-#pragma unroll
-        for (int q = 0; q < E; ++q) {
-            const int d = (int)((k[q] >> shift) & 15ull);
-            const uint16_t pos = cnt[d * THREADS + tid];
-            cnt[d * THREADS + tid] = (uint16_t)(pos + 1);
-            dst[pos] = k[q];
-        }
-        __syncthreads();
-        uint64_t* tmp = src;
-        src = dst;
-        dst = tmp;
-    }
-    // equal depths (rare): fall back to the full 64-bit bitonic network on the padded buffer
-    int tie = 0;
-    for (uint32_t i = tid + 1; i < n; i += THREADS) tie |= (uint32_t)(src[i] >> 32) == (uint32_t)(src[i - 1] >> 32);
-    if (__syncthreads_or(tie)) {
-        for (uint32_t kk = 2; kk <= (uint32_t)CAP; kk <<= 1)
-            for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
-                for (uint32_t t = tid; t < (uint32_t)(CAP >> 1); t += THREADS) {
-                    const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
-                    const uint64_t a = src[i], c = src[l];
-                    if ((a > c) == ((i & kk) == 0)) {
-                        src[i] = c;
-                        src[l] = a;
-                    }
-                }
-                __syncthreads();
-            }
-    }
-    for (uint32_t i = tid; i < n; i += THREADS) {
-        const uint64_t kq = src[i];
-        keys[s + i] = kq;
-        list[s + i] = (uint32_t)kq;
-    }
-}
-
-// Fallback for tile lists that exceed the LDS capacity: one workgroup sorts directly in global memory with
+// Fallback for tile lists beyond the merge-pass budget (> SORT_CHUNK << MAX_PASSES keys): one workgroup sorts directly in global memory with
 // the ascending-only form of the bitonic network (first sub-step of every stage compares mirrored
 // positions), which tolerates VIRTUAL +inf padding at indices >= n: an ascending compare-exchange never
 // moves a padding key inwards, so nothing outside [0, n) is ever read or written.  Rare and slow.
@@ -1105,18 +952,6 @@ static SideStream* side_stream() {
     return state[dev] == 1 ? &ss[dev] : nullptr;
 }
 
-// Kernels that ask for more than 64 KiB of dynamic LDS need the attribute once per device.
-static void ensure_func_attributes() {
-    static bool done[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || done[dev]) return;
-    hipError_t e1 = hipFuncSetAttribute((const void*)k_sort_tiles<16384, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipError_t e2 = hipFuncSetAttribute((const void*)k_sort_tiles_merge<1024, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (getenv("S360_DEBUG")) fprintf(stderr, "s360: set attr %s / %s\n", hipGetErrorString(e1), hipGetErrorString(e2));
-    (void)hipGetLastError();
-    done[dev] = true;
-}
-
 extern "C" int s360_layout(const S360Params* prm, S360Layout* out) {
     if (!prm || !out) return S360_E_BADARG;
     if (prm->P < 0 || prm->V < 1 || prm->V > S360_MAX_VIEWS || prm->H < 1 || prm->W < 1) return S360_E_BADARG;
@@ -1267,26 +1102,8 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
         }
         S360_CHECK_LAUNCH();
         ProfScope ps(PS_SORT, st);
-        ensure_func_attributes();
-        // The few very long lists (polar tiles, > 4096 entries) take ~150 us each but occupy < 100 CUs:
-        // fork them onto a side stream so they overlap with the ~1.5 K short lists on the main stream.
         SideStream* ss = side_stream();
-        const bool bitonic = getenv("S360_SORT_BITONIC") != nullptr;
-        uint32_t global_lo = 16384u;  // lists longer than this go to the global-memory network
-        if (bitonic) {
-            if (ss) {
-                (void)hipEventRecord(ss->fork, st);
-                (void)hipStreamWaitEvent(ss->stream, ss->fork, 0);
-                hipLaunchKernelGGL((k_sort_tiles<16384, 1024>), dim3(nt), dim3(1024), 16384 * 8, ss->stream, tile_start, keys, list, 4096u, kp.cap, tile_cursor);
-                (void)hipEventRecord(ss->join, ss->stream);
-            }
-            hipLaunchKernelGGL((k_sort_tiles<1024, 256>), dim3(nt), dim3(256), 1024 * 8, st, tile_start, keys, list, 0u, kp.cap, tile_cursor);
-            hipLaunchKernelGGL((k_sort_tiles<4096, 512>), dim3(nt), dim3(512), 4096 * 8, st, tile_start, keys, list, 1024u, kp.cap, tile_cursor);
-            if (ss)
-                (void)hipStreamWaitEvent(st, ss->join, 0);
-            else
-                hipLaunchKernelGGL((k_sort_tiles<16384, 1024>), dim3(nt), dim3(1024), 16384 * 8, st, tile_start, keys, list, 4096u, kp.cap, tile_cursor);
-        } else {
+        {
             // Lists of up to 2 048 keys (the bulk) are sorted by one 256-thread workgroup each, on the side stream;
             // meanwhile the main stream takes the rest as 4 096-key chunks, one 512-thread workgroup each
             // (k_sort_chunks), followed for multi-chunk lists by `passes` global merge passes (k_merge_pass).  The
@@ -1295,7 +1112,7 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
             const size_t cap_keys = kp.cap < (uint32_t)kp.P ? kp.cap : (size_t)kp.P;   // a tile holds a Gaussian at most once
             uint32_t passes = 0;
             while (passes < MAX_PASSES && ((size_t)SORT_CHUNK << passes) < cap_keys) ++passes;
-            global_lo = SORT_CHUNK << passes;
+            const uint32_t global_lo = SORT_CHUNK << passes;  // lists longer than this go to the global-memory network
             // >= number of chunks: every chunk but the last of a tile is full, and a tile with chunks has > SORT_SHORT keys
             const unsigned cgrid = (unsigned)((size_t)kp.cap / SORT_CHUNK + (size_t)kp.cap / SORT_SHORT + 2);
             const size_t lds512 = (4096 + 512) * 8;
@@ -1314,8 +1131,9 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
                 (void)hipStreamWaitEvent(st, ss->join, 0);
             else
                 hipLaunchKernelGGL((k_sort_tiles_merge<256, 8>), dim3(nt), dim3(256), (2048 + 256) * 8, st, tile_start, keys, list, 0u, kp.cap);
+            if ((size_t)global_lo < cap_keys)  // otherwise no list can be that long
+                hipLaunchKernelGGL(k_sort_tiles_global, dim3(nt), dim3(S360_BLOCK), 0, st, tile_start, keys, list, global_lo, kp.cap);
         }
-        hipLaunchKernelGGL(k_sort_tiles_global, dim3(nt), dim3(S360_BLOCK), 0, st, tile_start, keys, list, global_lo, kp.cap);
         S360_CHECK_LAUNCH();
     }
     {
