@@ -362,6 +362,11 @@ __global__ __launch_bounds__(S360_BLOCK) void k_tile_scan(const uint32_t* __rest
 // grid (ceil(P/256), V).  LDS_BIN: block-local two-pass binning — count the block's instances per
 // tile in LDS, reserve one contiguous range per (block, tile) with a single returning global
 // atomic, then place.  (Order inside a tile's bucket is irrelevant: the bucket is sorted next.)
+#ifndef S360_EMIT_PPT
+#define S360_EMIT_PPT 4
+#endif
+constexpr int EMIT_PPT = S360_EMIT_PPT;  // pairs per thread: more instances per (block, tile) => fewer global atomics
+
 template <bool LDS_BIN>
 __global__ __launch_bounds__(S360_BLOCK) void k_emit(KParams kp, const uint32_t* __restrict__ tiles_touched,
                                                     const float4* __restrict__ recA, const float4* __restrict__ recC,
@@ -369,7 +374,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_emit(KParams kp, const uint32_t*
                                                     uint32_t* __restrict__ tile_cursor, uint64_t* __restrict__ keys) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_bin[];  // [T] counts/cursors, [T] bases
     const int v = blockIdx.y;
-    const int g = blockIdx.x * S360_BLOCK + threadIdx.x;
+    const int g0 = blockIdx.x * (S360_BLOCK * EMIT_PPT) + threadIdx.x;
     const size_t tb = (size_t)v * kp.T;
     uint32_t* cnt = lds_bin;
     uint32_t* base = lds_bin + kp.T;
@@ -377,19 +382,23 @@ __global__ __launch_bounds__(S360_BLOCK) void k_emit(KParams kp, const uint32_t*
         for (int i = threadIdx.x; i < kp.T; i += S360_BLOCK) cnt[i] = 0u;
         __syncthreads();
     }
-    const size_t p = (size_t)v * kp.P + g;
-    const bool act = g < kp.P && tiles_touched[p] != 0;
-    int minx = 0, miny = 0, maxx = 0, maxy = 0;
-    uint64_t key = 0;
-    if (act) {
-        const float4 rc = recA[3 * (size_t)(p) + 2];
-        const float4 ra = recA[3 * (size_t)(p)];
-        tile_rect(ra.x, ra.y, __float_as_int(rc.y), kp.gx, kp.gy, minx, miny, maxx, maxy);
-        key = ((uint64_t)__float_as_uint(depths[p]) << 32) | (uint64_t)(uint32_t)p;
+    // visible pairs of this thread (bit j: pair g0 + j*256); their rects are recomputed in the second phase
+    uint32_t vis = 0;
+#pragma unroll
+    for (int j = 0; j < EMIT_PPT; ++j) {
+        const int g = g0 + j * S360_BLOCK;
+        if (g < kp.P && tiles_touched[(size_t)v * kp.P + g] != 0) vis |= 1u << j;
     }
     if (LDS_BIN) {
-        for (int y = miny; y < maxy; ++y)
-            for (int x = minx; x < maxx; ++x) atomicAdd(&cnt[y * kp.gx + x], 1u);
+        for (uint32_t m = vis; m; m &= m - 1) {
+            const size_t p = (size_t)v * kp.P + g0 + __builtin_ctz(m) * S360_BLOCK;
+            const float4 rc = recA[3 * p + 2];
+            const float4 ra = recA[3 * p];
+            int minx, miny, maxx, maxy;
+            tile_rect(ra.x, ra.y, __float_as_int(rc.y), kp.gx, kp.gy, minx, miny, maxx, maxy);
+            for (int y = miny; y < maxy; ++y)
+                for (int x = minx; x < maxx; ++x) atomicAdd(&cnt[y * kp.gx + x], 1u);
+        }
         __syncthreads();
         for (int i = threadIdx.x; i < kp.T; i += S360_BLOCK) {
             const uint32_t c = cnt[i];
@@ -399,17 +408,19 @@ __global__ __launch_bounds__(S360_BLOCK) void k_emit(KParams kp, const uint32_t*
             }
         }
         __syncthreads();
+    }
+    for (uint32_t m = vis; m; m &= m - 1) {
+        const size_t p = (size_t)v * kp.P + g0 + __builtin_ctz(m) * S360_BLOCK;
+        const float4 rc = recA[3 * p + 2];
+        const float4 ra = recA[3 * p];
+        int minx, miny, maxx, maxy;
+        tile_rect(ra.x, ra.y, __float_as_int(rc.y), kp.gx, kp.gy, minx, miny, maxx, maxy);
+        const uint64_t key = ((uint64_t)__float_as_uint(depths[p]) << 32) | (uint64_t)(uint32_t)p;
         for (int y = miny; y < maxy; ++y)
             for (int x = minx; x < maxx; ++x) {
                 const int t = y * kp.gx + x;
-                const uint32_t pos = base[t] + atomicAdd(&cnt[t], 1u);
-                if (pos < kp.cap) keys[pos] = key;
-            }
-    } else {
-        for (int y = miny; y < maxy; ++y)
-            for (int x = minx; x < maxx; ++x) {
-                const size_t t = tb + y * kp.gx + x;
-                const uint32_t pos = tile_start[t] + atomicAdd(&tile_cursor[t], 1u);
+                const uint32_t pos = LDS_BIN ? base[t] + atomicAdd(&cnt[t], 1u)
+                                             : tile_start[tb + t] + atomicAdd(&tile_cursor[tb + t], 1u);
                 if (pos < kp.cap) keys[pos] = key;
             }
     }
@@ -1090,7 +1101,7 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
     }
     S360_CHECK_LAUNCH();
     if (kp.P > 0) {
-        const dim3 egrid((kp.P + S360_BLOCK - 1) / S360_BLOCK, kp.V);
+        const dim3 egrid((kp.P + S360_BLOCK * EMIT_PPT - 1) / (S360_BLOCK * EMIT_PPT), kp.V);
         {
         ProfScope ps(PS_EMIT, st);
         if ((size_t)kp.T * 8 <= 64 * 1024)
