@@ -196,11 +196,12 @@ def main():
     per_splat = BYTES_FWD if dom in FWD_KERNELS else BYTES_BWD
     dom_s = kernels[dom]["avg_us"] * 1e-6
     achieved = per_splat * G / dom_s / 1e9
-    traffic = None
+    traffic = valu_busy = valu_insts = None
     pmc = ROOT / "profiles" / "pmc_latest.json"
-    if pmc.exists():
+    if pmc.exists():   # PMC counters of the committed rocprofv3 passes (scripts/collect_profiles.sh), per launch
         try:
-            traffic = json.loads(pmc.read_text()).get(dom, {}).get("hbm_bytes_per_launch")
+            rec = json.loads(pmc.read_text()).get(dom, {})
+            traffic, valu_busy, valu_insts = rec.get("hbm_bytes_per_launch"), rec.get("valu_busy_frac"), rec.get("valu_insts_per_launch")
         except Exception:
             traffic = None
     bytes_step = (BYTES_FWD + (BYTES_BWD if a.mode == "fwdbwd" else 0.0)) * G * views_per_step
@@ -221,9 +222,11 @@ def main():
                    "num_rendered": L, "visible_pairs": visible_pairs},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "valu_busy_frac": valu_busy, "valu_insts_per_launch": valu_insts,
                      "note": f"{per_splat} B/splat (SURVEY §8d, {'fwd' if dom in FWD_KERNELS else 'bwd'} phase) x {G} splats / "
-                             f"avg launch {kernels[dom]['avg_us']:.1f} us of the dominant kernel; that kernel is VALU/LDS-bound "
-                             "(alpha-composite), see DESIGN.md"},
+                             f"avg launch {kernels[dom]['avg_us']:.1f} us of the dominant kernel; that kernel is VALU-issue-bound "
+                             "(alpha composite: valu_busy_frac = share of the kernel during which the SIMDs' VALU pipes issue, PMC), "
+                             "see DESIGN.md section 4"},
         "path_roofline": {"bytes_per_step": bytes_step, "achieved_GBps": bytes_step / (dt / a.steps) / 1e9 ,
                           "frac_of_8TBps": bytes_step / (dt / a.steps) / 1e9 / HBM_PEAK_GBPS},
         "kernels": kernels,

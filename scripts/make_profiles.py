@@ -28,4 +28,16 @@ with open(P / "r01_pmc_counters.csv", "w") as f:
     for k in sorted(acc):
         for c in sorted(acc[k]):
             w.writerow([k, c, round(sum(acc[k][c]) / len(acc[k][c])), len(acc[k][c])])
+# VALU-issue view of every kernel (SQ counters are per-SIMD quad-cycles; GRBM_GUI_ACTIVE sums the 8 XCDs):
+# a gfx950 SIMD issues one wave64 VALU instruction per 4 cycles, 1024 SIMDs on the chip.
+pm = json.load(open(P / "pmc_latest.json"))
+by_kernel = {v["kernel"]: v for v in pm.values()}
+for k, c in acc.items():
+    kk = k.replace("s360::", "")
+    if kk in by_kernel and "SQ_ACTIVE_INST_VALU" in c and "GRBM_GUI_ACTIVE" in c:
+        mean = lambda n: sum(c[n]) / len(c[n])
+        cycles = mean("GRBM_GUI_ACTIVE") / 8.0
+        by_kernel[kk]["valu_insts_per_launch"] = round(mean("SQ_INSTS_VALU")) if "SQ_INSTS_VALU" in c else None
+        by_kernel[kk]["valu_busy_frac"] = round(mean("SQ_ACTIVE_INST_VALU") * 4.0 / (cycles * 1024.0), 4)
+json.dump(pm, open(P / "pmc_latest.json", "w"), indent=1, sort_keys=True)
 print("profiles/ updated")

@@ -231,7 +231,8 @@ class CameraPrefetcher:
         self.stream.synchronize()
         try:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=self.stream):
+            # thread_local: other threads' HIP calls (RCCL watchdog, pin-memory workers) must not abort the capture
+            with torch.cuda.graph(graph, stream=self.stream, capture_error_mode="thread_local"):
                 out = pack_camera_views(*static_in)
             entry = (graph, static_in, out)
         except Exception as e:  # capture not possible in this environment: eager side-stream path still works
