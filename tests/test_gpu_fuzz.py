@@ -56,3 +56,61 @@ def test_fuzz_against_oracle(gpu, seed):
         e_hip = np.abs(hh["grads"][k].reshape(-1) - ref).max() / scale
         e_o32 = np.abs(np.asarray(og32[k], np.float64).reshape(-1) - ref).max() / scale
         assert e_hip <= max(5e-4, 2.0 * e_o32), (k, e_hip, e_o32)
+
+
+def _views_case(seed, shared):
+    rng = np.random.default_rng(5000 + seed)
+    n = int(rng.integers(50, 4000))
+    h, w = int(rng.integers(16, 100)), int(rng.integers(16, 100))
+    v = int(rng.integers(1, 9))
+    faces = [int(x) for x in rng.integers(0, 6, v)]
+    if shared:
+        pos = [tuple(rng.uniform(-0.5, 0.5, 3))] * v
+        nears = [float(rng.choice([0.1, 0.5]))] * v
+    else:
+        pos = [tuple(rng.uniform(-0.5, 0.5, 3)) for _ in range(v)]
+        nears = [float(rng.choice([0.1, 0.25, 0.5])) for _ in range(v)]
+    cloud = synthetic.uniform_cloud(n, seed=seed, extent=2.5, scale_range=(0.02, 0.3))
+    bg = rng.uniform(0, 1, 3).astype(np.float32)
+    gimg = rng.standard_normal((v, 3, h, w)).astype(np.float32)
+    return cloud, faces, pos, nears, bg, gimg, (n, h, w, v)
+
+
+@pytest.mark.parametrize("shared", [True, False])
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_multi_view_fused_call_against_per_view_oracle(gpu, seed, shared):
+    """render_views_fused (ONE call: V <= 8 views, the reference's [G,3,3] / [G,3,25] layouts read in place, 1/near
+    rescale inside the kernels, per-view or shared camera centre) against V independent oracle runs on the
+    reference-style rescaled boundary tensors, gradients chained back through the rescale."""
+    import torch
+    from splatter360_amd import cameras, decoder
+    cloud, faces, pos, nears, bg, gimg, (n, h, w, v) = _views_case(seed, shared)
+    ext = torch.stack([cameras.cube_face_extrinsics(torch.from_numpy(synthetic.target_pano_pose(pos[i]))[None])[0, faces[i]]
+                       for i in range(v)]).to(gpu)
+    K = cameras.cube_face_intrinsics(1)[0, :1].repeat(v, 1, 1).to(gpu)
+    near = torch.tensor(nears, device=gpu)
+    far = near * 100.0
+    ps = [torch.tensor(cloud[k], device=gpu, requires_grad=True) for k in ("means", "covariances", "harmonics", "opacities")]
+    imgs = decoder.render_views_fused(ext, K, near, far, (h, w), torch.tensor(bg, device=gpu), *ps, shared_campos=shared)
+    imgs.backward(torch.tensor(gimg, device=gpu))
+    want = [np.zeros((n, 3)), np.zeros((n, 3, 3)), np.zeros((n, 3, 25)), np.zeros((n,))]
+    want32 = [np.zeros_like(x) for x in want]
+    r, c = np.triu_indices(3)
+    for i in range(v):
+        S = face_settings(faces[i], h, w, near=nears[i], far=nears[i] * 100.0, position=pos[i], bg=bg)
+        means, cov6, shs, opac = boundary_tensors(cloud, S["scale"])
+        for dt, acc in ((np.float32, want32), (np.float64, want)):
+            o = oracle.rasterize(S, means3D=means, cov3D_precomp=cov6, opacities=opac, shs=shs, dtype=dt)
+            f = o.forward()
+            if dt == np.float32:
+                assert np.abs(imgs[i].detach().cpu().numpy() - f["image"]).mean() <= 1e-5
+            g = o.backward(gimg[i])
+            acc[0] += S["scale"] * np.asarray(g["means3D"], np.float64)
+            acc[1][:, r, c] += S["scale"] ** 2 * np.asarray(g["cov3D"], np.float64)
+            acc[2] += np.asarray(g["shs"], np.float64).transpose(0, 2, 1)
+            acc[3] += np.asarray(g["opacities"], np.float64).reshape(-1)
+    for p, ref, o32 in zip(ps, want, want32):
+        scale = np.abs(ref).max() + 1e-30
+        e_hip = np.abs(p.grad.cpu().numpy().astype(np.float64) - ref).max() / scale
+        e_o32 = np.abs(o32 - ref).max() / scale
+        assert e_hip <= max(5e-4, 2.0 * e_o32), (e_hip, e_o32)
