@@ -87,19 +87,28 @@ def sync_gradients_factored(means: Tensor, covariances: Tensor, harmonics: Tenso
     vis = rgb[:, 3].view(torch.int32) >= 0
     rgb[:, 3] = torch.where(vis, torch.full_like(rgb[:, 3].view(torch.int32), rank), torch.full_like(rgb[:, 3].view(torch.int32), -1)).view(torch.float32)
     rep = d.views[:1].contiguous()  # all views of the call share campos and scale
+    ar = []
     if world > 1:
-        works = [dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group, async_op=True)
-                 for g in (covariances.grad, means.grad, opacities.grad)]
+        # the communicator runs its work in issue order: the all-gathers first (the local SH pass waits for them),
+        # the three all-reduces behind them, overlapping with that pass
         rgb_all = torch.empty((world * rgb.shape[0], 4), dtype=rgb.dtype, device=dev)   # dim-0 concat: gloo-compatible
         rep_all = torch.empty((world * rep.shape[1],), dtype=rep.dtype, device=dev)
-        works.append(dist.all_gather_into_tensor(rgb_all, rgb, group=group, async_op=True))
-        works.append(dist.all_gather_into_tensor(rep_all, rep.reshape(-1), group=group, async_op=True))
-        for w in works:
+        ag = [dist.all_gather_into_tensor(rgb_all, rgb, group=group, async_op=True),
+              dist.all_gather_into_tensor(rep_all, rep.reshape(-1), group=group, async_op=True)]
+        ar = [dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group, async_op=True)
+              for g in (covariances.grad, means.grad, opacities.grad)]
+        for w in ag:
             w.wait()
     else:
         rgb_all, rep_all = rgb, rep
+    # the SH pass adds every rank's view-direction term of dL/dmean into a scratch buffer (means.grad is still
+    # being all-reduced); it is folded in once the all-reduce has landed
+    dm_extra = torch.zeros_like(means.grad)
     harmonics.grad = rasterizer.finish_deferred_sh(d.prm, rep_all.reshape(world, -1), d.means3D, d.shs,
-                                                   rgb_all.view(world, -1, 4), means.grad)
+                                                   rgb_all.view(world, -1, 4), dm_extra)
+    for w in ar:
+        w.wait()
+    means.grad += dm_extra
 
 
 def max_over_ranks(value: float, device) -> float:
