@@ -1,15 +1,17 @@
 // s360_backward.hip — backward kernels.  gfx950 / wave64 only.
 //
-//   k_zero_inst        zero the per-instance raster-gradient slots [0, num_instances)
-//   k_render_bwd       1 workgroup per tile, back-to-front replay from final_T / n_contrib.
-//                      Per splat the 9 raster gradients are reduced over the 64 pixels of a wave
-//                      with DPP adds (no LDS, no atomics), the 4 waves meet in LDS, and ONE
-//                      record per (tile, splat) instance is written — the slot index is the
-//                      instance's position in emission order (grouped by (view, Gaussian) pair).
-//   k_preprocess_bwd   1 thread per Gaussian: gathers its instances (contiguous, deterministic
-//                      order), chains conic -> cov2D -> cov3D / mean, projection -> mean,
-//                      SH -> dL/dSH + view-direction term, sums the V views in registers and
-//                      writes each 340-byte gradient exactly once (SH slab staged through LDS).
+//   k_order_units      work units (tile, quadrant) in descending order of their replay length; the same launch
+//                      clears the validity flags of the partial-record slots
+//   k_render_bwd       one autonomous wave per (tile, 8x8 quadrant): back-to-front replay from final_T /
+//                      n_contrib; per splat the 9 raster gradients are reduced over the wave's 64 pixels with
+//                      a transposing DPP butterfly (no LDS, no atomics) and ONE partial record per
+//                      (instance, quadrant) is written — the instance slot is the splat's position in emission
+//                      order (grouped by (view, Gaussian) pair)
+//   k_gather_pairs     1 thread per pair: sums its instances' quadrant partials in a fixed order
+//   k_preprocess_bwd   1 thread per Gaussian: chains conic -> cov2D -> cov3D / mean, projection -> mean, sums the
+//                      V views in registers; with per-view camera centres also SH -> dL/dSH (slab through LDS)
+//   k_sh_bwd           streaming SH backward for views sharing one camera centre (and for the N gathered
+//                      factors of the multi-GPU exchange): dL/dSH = Y (x) dRGB, view-direction term of dL/dmean
 // No float atomics anywhere: gradients are bit-reproducible run to run.
 #include "s360_device.h"
 #include "s360_prof.h"
@@ -21,18 +23,22 @@ namespace s360 {
 
 constexpr int GREC = 12;  // floats per partial record: gx gy gA gB | gC gop gr gg | gb - - -
 
-// valid[instance*4 + strip] = 1 when that strip's wave wrote a partial record for the instance
-__global__ __launch_bounds__(S360_BLOCK) void k_zero_valid(uint32_t* __restrict__ valid_words, const uint32_t* __restrict__ header,
-                                                          uint32_t cap) {
-    const size_t n = (size_t)min(header[0], cap);  // one 32-bit word (4 strip flags) per instance
-    for (size_t i = (size_t)blockIdx.x * S360_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * S360_BLOCK) valid_words[i] = 0u;
-}
-
 // Single workgroup: order[] = work-unit ids (tile*4 + strip) in descending order of their work estimate
 // (64-bucket counting sort on weight / max weight).  Units are dispatched in index order round-robin over
 // the CUs / SIMDs, so dealing them heavy-first gives every SIMD a similar mix (LPT-style balancing of
 // the sequential per-strip chains, which cannot be split).
-__global__ __launch_bounds__(1024) void k_order_units(const uint32_t* __restrict__ weight, uint32_t* __restrict__ order, int n) {
+// The same launch also clears the backward's validity words (valid[instance*4 + quadrant] = 1 when that
+// quadrant's wave wrote a partial record): block 0 orders, blocks 1.. zero (one 32-bit word = 4 flags per instance).
+__global__ __launch_bounds__(1024) void k_order_units(const uint32_t* __restrict__ weight, uint32_t* __restrict__ order, int n,
+                                                     uint32_t* __restrict__ valid_words, const uint32_t* __restrict__ header,
+                                                     uint32_t cap) {
+    if (blockIdx.x > 0) {
+        const size_t nv = (size_t)min(header[0], cap);
+        const size_t stride = (size_t)(gridDim.x - 1) * 1024;
+        for (size_t i = (size_t)(blockIdx.x - 1) * 1024 + threadIdx.x; i < nv; i += stride) valid_words[i] = 0u;
+        return;
+    }
+    if (!order) return;
     __shared__ uint32_t s_max;
     __shared__ uint32_t s_cnt[64];
     __shared__ uint32_t s_base[64];
@@ -713,16 +719,13 @@ static int backward_impl(const S360Params* prm, const S360View* views, const flo
     float4* part = (float4*)bwd_workspace;
     uint32_t* valid_words = (uint32_t*)((char*)bwd_workspace + (size_t)kp.cap * 4 * GREC * 4);
 
-    {
-        ProfScope ps(PS_ZERO_INST, st);
-        hipLaunchKernelGGL(k_zero_valid, dim3(1024), dim3(S360_BLOCK), 0, st, valid_words, header, kp.cap);
-    }
     uint32_t* order = valid_words + kp.cap;  // [nt*4] after the validity words
     const uint32_t* strip_last = (const uint32_t*)(ws + L.strip_last);
     const bool use_order = !getenv("S360_NO_ORDER");
     {
     ProfScope ps(PS_RENDER_BWD, st);
-    if (use_order) hipLaunchKernelGGL(k_order_units, dim3(1), dim3(1024), 0, st, strip_last, order, nt * 4);
+    hipLaunchKernelGGL(k_order_units, dim3(1 + 512), dim3(1024), 0, st, strip_last, use_order ? order : (uint32_t*)nullptr, nt * 4,
+                       valid_words, header, kp.cap);
     // Even spread of the single-wave work units: when all units fit on the chip at once (<= 32 per CU)
     // reserve just enough (unused) LDS per workgroup that every CU admits exactly ceil(units / 256) of
     // them — otherwise the dispatcher packs the first CUs to their register limit and starves the rest.

@@ -12,7 +12,6 @@ enum ProfSlot {
     PS_EMIT,
     PS_SORT,
     PS_RENDER,
-    PS_ZERO_INST,
     PS_RENDER_BWD,
     PS_PREPROCESS_BWD,
     PS_STITCH,
