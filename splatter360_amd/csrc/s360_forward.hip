@@ -18,6 +18,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 
 namespace s360 {
 
@@ -943,16 +944,22 @@ static size_t occupancy_cap_lds(const char* env, size_t dflt) {
     return e ? (size_t)atol(e) : dflt;
 }
 
-// One non-blocking side stream (+ fork/join events) per device, created on first use.
+// One non-blocking side stream (+ fork/join events) per device, created on first use.  The only process-wide
+// state of the library besides the optional profiler: callers on different host threads / streams of one device
+// share it, so the fork ... join enqueue sequence is serialised on the host by `mu` (enqueue only — nothing waits
+// on the GPU while the lock is held).
 struct SideStream {
     hipStream_t stream;
     hipEvent_t fork, join;
+    std::mutex mu;
 };
 static SideStream* side_stream() {
     static SideStream ss[64];
     static int state[64] = {};  // 0 = not created, 1 = ready, -1 = unavailable
+    static std::mutex create_mu;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || getenv("S360_NO_SIDE_STREAM")) return nullptr;
+    std::lock_guard<std::mutex> lk(create_mu);
     if (state[dev] == 0) {
         const bool ok = hipStreamCreateWithFlags(&ss[dev].stream, hipStreamNonBlocking) == hipSuccess &&
                         hipEventCreateWithFlags(&ss[dev].fork, hipEventDisableTiming) == hipSuccess &&
@@ -1115,6 +1122,8 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
         ProfScope ps(PS_SORT, st);
         SideStream* ss = side_stream();
         {
+            std::unique_lock<std::mutex> side_lock;
+            if (ss) side_lock = std::unique_lock<std::mutex>(ss->mu);
             // Lists of up to 2 048 keys (the bulk) are sorted by one 256-thread workgroup each, on the side stream;
             // meanwhile the main stream takes the rest as 4 096-key chunks, one 512-thread workgroup each
             // (k_sort_chunks), followed for multi-chunk lists by `passes` global merge passes (k_merge_pass).  The

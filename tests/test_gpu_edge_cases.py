@@ -146,3 +146,43 @@ def test_opacity_extremes_and_degree_below_four(gpu):
         check_forward(hh, f, 200, 48, 48)
         check_grads(hh["grads"], og, rtol=5e-4)
         assert np.abs(hh["grads"]["shs"][:, (deg + 1) ** 2:]).max() == 0.0
+
+
+def test_concurrent_calls_from_two_host_threads_on_two_streams(gpu):
+    """The library is re-entrant across host threads / streams of one device (the reference is called from the
+    Lightning main thread and from autograd's backward thread): two threads render + backpropagate different
+    clouds concurrently on their own streams; results equal the serial ones bit for bit."""
+    import threading
+    from splatter360_amd import decoder, synthetic
+    ext, K, near, far = decoder.cube_cameras(torch.eye(4, device=gpu), 0.1, 10.0)
+    bg = torch.zeros(3, device=gpu)
+    views = decoder.pack_camera_views(ext, K, near, far, bg)
+    clouds = [synthetic.uniform_cloud(30000 + 5000 * i, seed=40 + i, extent=2.5, scale_range=(0.02, 0.3)) for i in range(2)]
+
+    def run(i, out, stream=None):
+        ps = [torch.tensor(clouds[i][k], device=gpu, requires_grad=True) for k in ("means", "covariances", "harmonics", "opacities")]
+        ctx = torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.current_stream())
+        with ctx:
+            for _ in range(3):
+                for p in ps:
+                    p.grad = None
+                f = decoder.render_views_fused(ext, K, near, far, (64, 64), bg, *ps, views=views)
+                (f * f).sum().backward()
+            if stream is not None:
+                stream.synchronize()
+        out[i] = [f.detach().clone()] + [p.grad.clone() for p in ps]
+
+    serial, conc = {}, {}
+    for i in range(2):
+        run(i, serial)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=gpu) for _ in range(2)]
+    for s in streams:
+        s.wait_stream(torch.cuda.current_stream())
+    th = [threading.Thread(target=run, args=(i, conc, streams[i])) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    torch.cuda.synchronize()
+    for i in range(2):
+        for a, b in zip(serial[i], conc[i]):
+            assert torch.equal(a, b)
