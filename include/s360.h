@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define S360_ABI_VERSION 8
+#define S360_ABI_VERSION 9
 #define S360_MAX_VIEWS 8
 #define S360_TILE 16
 
@@ -101,6 +101,7 @@ typedef struct S360Layout {
     size_t tile_start;          /* uint32[V*T+1] exclusive scan (upstream ranges: [start[t], start[t+1])) */
     size_t tile_cursor;         /* uint32[V*T] */
     size_t chunk_start;         /* uint32[V*T+1] number of 4096-key sort chunks of long lists before tile t */
+    size_t tile_order;          /* uint32[V*T] tile ids, longest list first (dispatch order of the composite) */
     size_t keys;                /* uint64[max_instances]  (depth bits << 32 | pair index), sorted per tile */
     size_t keys_alt;            /* uint64[max_instances]  ping-pong buffer of the long-list merge passes */
     size_t list;                /* uint32[max_instances]  sorted pair indices p = v*P + g (upstream point_list) */

@@ -23,7 +23,7 @@ FLAG_SHARED_CAMPOS = 1
 FLAG_COV9 = 2
 FLAG_SH_CHANNEL_MAJOR = 4
 FLAG_FORWARD_ONLY = 8
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class S360Params(C.Structure):
@@ -35,7 +35,7 @@ class S360Params(C.Structure):
 class S360Layout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in (
         "total_bytes", "header", "tiles_touched", "offsets", "rec_a", "rec_b", "rec_c",
-        "clamped", "depths", "tile_count", "scan_scratch", "tile_start", "tile_cursor", "chunk_start", "keys", "keys_alt", "list", "final_T", "n_contrib",
+        "clamped", "depths", "tile_count", "scan_scratch", "tile_start", "tile_cursor", "chunk_start", "tile_order", "keys", "keys_alt", "list", "final_T", "n_contrib",
         "tile_max_contrib", "strip_last", "backward_bytes")]
 
 

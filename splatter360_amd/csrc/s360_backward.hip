@@ -23,50 +23,6 @@ namespace s360 {
 
 constexpr int GREC = 12;  // floats per partial record: gx gy gA gB | gC gop gr gg | gb - - -
 
-// Single workgroup: order[] = work-unit ids (tile*4 + strip) in descending order of their work estimate
-// (64-bucket counting sort on weight / max weight).  Units are dispatched in index order round-robin over
-// the CUs / SIMDs, so dealing them heavy-first gives every SIMD a similar mix (LPT-style balancing of
-// the sequential per-strip chains, which cannot be split).
-// The same launch also clears the backward's validity words (valid[instance*4 + quadrant] = 1 when that
-// quadrant's wave wrote a partial record): block 0 orders, blocks 1.. zero (one 32-bit word = 4 flags per instance).
-__global__ __launch_bounds__(1024) void k_order_units(const uint32_t* __restrict__ weight, uint32_t* __restrict__ order, int n,
-                                                     uint32_t* __restrict__ valid_words, const uint32_t* __restrict__ header,
-                                                     uint32_t cap) {
-    if (blockIdx.x > 0) {
-        const size_t nv = (size_t)min(header[0], cap);
-        const size_t stride = (size_t)(gridDim.x - 1) * 1024;
-        for (size_t i = (size_t)(blockIdx.x - 1) * 1024 + threadIdx.x; i < nv; i += stride) valid_words[i] = 0u;
-        return;
-    }
-    if (!order) return;
-    __shared__ uint32_t s_max;
-    __shared__ uint32_t s_cnt[64];
-    __shared__ uint32_t s_base[64];
-    if (threadIdx.x == 0) s_max = 1;
-    if (threadIdx.x < 64) s_cnt[threadIdx.x] = 0;
-    __syncthreads();
-    uint32_t mx = 0;
-    for (int i = threadIdx.x; i < n; i += 1024) mx = max(mx, weight[i]);
-    mx = wave_max_u32(mx);
-    if ((threadIdx.x & 63) == 0) atomicMax(&s_max, mx);
-    __syncthreads();
-    const uint32_t wmax = s_max;
-    for (int i = threadIdx.x; i < n; i += 1024) atomicAdd(&s_cnt[63 - (uint32_t)(((uint64_t)weight[i] * 63) / wmax)], 1u);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t run = 0;
-        for (int b = 0; b < 64; ++b) {
-            s_base[b] = run;
-            run += s_cnt[b];
-        }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < n; i += 1024) {
-        const uint32_t b = 63 - (uint32_t)(((uint64_t)weight[i] * 63) / wmax);
-        order[atomicAdd(&s_base[b], 1u)] = (uint32_t)i;
-    }
-}
-
 // Wave-autonomous like the forward composite: wave w replays strip w of the tile back to front from
 // final_T / n_contrib, 64 list entries at a time with lane l holding entry (hi - l) in registers.
 // Per surviving entry the 9 raster gradients are reduced over the strip's 64 pixels with DPP adds and
