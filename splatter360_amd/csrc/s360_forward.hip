@@ -929,7 +929,10 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
     }
 #ifdef S360_DBG_TIMING
     if (lane == 0) {
-        dbg[4 * t + wave] = (uint32_t)(wall_clock64() - t_begin);
+        dbg[4 * (4 * t + wave)] = (uint32_t)t_begin;
+        dbg[4 * (4 * t + wave) + 1] = (uint32_t)(wall_clock64() - t_begin);
+        dbg[4 * (4 * t + wave) + 2] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);   // HW_REG_HW_ID
+        dbg[4 * (4 * t + wave) + 3] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);  // HW_REG_XCC_ID
     }
 #endif
 }
@@ -1171,13 +1174,18 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
     {
         ProfScope ps(PS_RENDER, st);
         const dim3 rgrid(nt), rblock(S360_BLOCK);
+#ifdef S360_DBG_TIMING
+        uint32_t* dbg = (uint32_t*)keys_alt;  // [4 * nt * 4] per-wave (start, duration ticks, HW_ID, XCC_ID): the merge buffer is free by now
+#else
+        uint32_t* dbg = header + 8;           // S360_DBG_COUNT counters
+#endif
         if (depth_maps)
             hipLaunchKernelGGL(k_render<true>, rgrid, rblock, occupancy_cap_lds("S360_RENDER_LDS", 0), st, kp, views, tile_start,
-                               list, recA, recB, recC, images, final_T, n_contrib, tile_max_contrib, strip_last, header + 8,
+                               list, recA, recB, recC, images, final_T, n_contrib, tile_max_contrib, strip_last, dbg,
                                depths, depth_maps, depth_mode, ep, kp.P > 0 ? tile_order : (const uint32_t*)nullptr);
         else
             hipLaunchKernelGGL(k_render<false>, rgrid, rblock, occupancy_cap_lds("S360_RENDER_LDS", 0), st, kp, views, tile_start,
-                               list, recA, recB, recC, images, final_T, n_contrib, tile_max_contrib, strip_last, header + 8,
+                               list, recA, recB, recC, images, final_T, n_contrib, tile_max_contrib, strip_last, dbg,
                                depths, depth_maps, depth_mode, ep, kp.P > 0 ? tile_order : (const uint32_t*)nullptr);
     }
     S360_CHECK_LAUNCH();
