@@ -210,6 +210,28 @@ def main():
     sph = u.equi_2_spherical(coords, radius=1)
     cart = u.spherical_2_cartesian(sph)[0]
     np.savez_compressed(OUT / "erp_rays_8x16.npz", dirs=cart.numpy())
+
+    # ---- (5) cube-face loss / metric the fused epilogue replaces: LossMse (src/loss/loss_mse.py:30-31) and
+    # compute_psnr (src/evaluation/metrics.py:11-21).  metrics.py also imports lpips / skimage (absent here, only
+    # used by the other two metrics): empty stand-in modules let the real compute_psnr be imported and run.
+    lp = types.ModuleType("lpips"); lp.LPIPS = object
+    sk = types.ModuleType("skimage"); skm = types.ModuleType("skimage.metrics"); skm.structural_similarity = None
+    sys.modules.update({"lpips": lp, "skimage": sk, "skimage.metrics": skm})
+    for pkg in ("src.dataset", "src.loss", "src.evaluation"):   # skip their __init__ (torchvision, lpips-based losses)
+        m = types.ModuleType(pkg)
+        m.__path__ = [str(Path(REF) / pkg.replace(".", "/"))]
+        sys.modules[pkg] = m
+    sys.modules["src.dataset"].DatasetCfg = object   # decoder.py only names it in a type annotation
+    metrics = importlib.import_module("src.evaluation.metrics")
+    loss_mse = importlib.import_module("src.loss.loss_mse")
+    dec = importlib.import_module("src.model.decoder.decoder")
+    pred = torch.tensor(rng.uniform(-0.2, 1.3, (2, 6, 3, 8, 8)), dtype=torch.float32)      # [b, v*cubes, 3, h, w]
+    gt = torch.tensor(rng.uniform(-0.1, 1.2, (2, 1, 6, 3, 8, 8)), dtype=torch.float32)     # [b, v, cubes, 3, h, w]
+    loss = loss_mse.LossMse(loss_mse.LossMseCfgWrapper(loss_mse.LossMseCfg(weight=0.37)))
+    val = loss(dec.DecoderOutput(color=pred, depth=None), {"target": {"image_cubes_supervise": gt}}, None, 0)
+    psnr = metrics.compute_psnr(gt[0, 0], pred[0])
+    np.savez_compressed(OUT / "loss_mse_psnr.npz", pred=pred.numpy(), gt=gt.numpy(), weight=np.float32(0.37),
+                        loss=val.numpy(), psnr_b0=psnr.numpy())
     print("golden fixtures written to", OUT)
 
 

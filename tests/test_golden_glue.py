@@ -128,3 +128,21 @@ def test_cube_faces_and_stitch_are_geometrically_consistent():
     want = torch.from_numpy(synthetic.erp_ray_directions(eh, ew)).permute(2, 0, 1).float()
     ang = torch.rad2deg(torch.acos((erp * want).sum(0).clamp(-1, 1)))
     assert ang.max() < 0.8 and ang.mean() < 0.4  # pixel pitch at this size is 1.4 degrees
+
+
+def test_loss_mse_and_psnr_formulas_match_the_reference():
+    """Golden capture of the reference's LossMse.forward (src/loss/loss_mse.py:30-31) and compute_psnr
+    (src/evaluation/metrics.py:11-21): pins (a) the torch formulation the GPU test of the fused epilogue compares
+    against (tests/test_gpu_fused_loss.py) and (b) FusedMse.psnr(), which turns the epilogue's per-view clipped MSE
+    into the metric."""
+    from splatter360_amd.rasterizer import FusedMse
+    g = np.load(G / "loss_mse_psnr.npz")
+    pred, gt = torch.from_numpy(g["pred"]), torch.from_numpy(g["gt"])
+    w = float(g["weight"])
+    loss = w * ((pred - gt.reshape(pred.shape)) ** 2).mean()             # what the epilogue's `loss` is tested against
+    assert abs(loss.item() - float(g["loss"])) <= 1e-7 * abs(float(g["loss"]))
+    p0, g0 = pred[0], gt[0, 0]                                             # six faces of batch item 0
+    clipped_mse = ((g0.clip(0, 1) - p0.clip(0, 1)) ** 2).mean(dim=(1, 2, 3))   # what `clipped_mse` is tested against
+    fm = FusedMse(loss, clipped_mse)
+    torch.testing.assert_close(fm.psnr(), torch.from_numpy(g["psnr_b0"]), rtol=1e-6, atol=1e-6)
+    assert torch.equal(FusedMse(loss, torch.zeros(2)).psnr(), torch.full((2,), 100.0))   # mse == 0 -> 1e-10 -> 100 dB
