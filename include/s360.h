@@ -155,8 +155,8 @@ int s360_forward_depth(const S360Params* prm, const S360View* views, const float
  *   LossMse.forward       src/loss/loss_mse.py:30-31   weight * mean((color - target)^2)
  *   compute_psnr          src/evaluation/metrics.py:11-21   -10 log10(mean((clip01(gt) - clip01(pred))^2))
  * and the loss's autograd seed.  target[V,3,H,W]; d_images[V,3,H,W] = grad_scale * (image - target) (pass
- * grad_scale = 2*weight/N, N = elements averaged over); partials[V*tiles*4, 2] = per 16x4 strip (in tile
- * order, strips top to bottom) the sums of squared differences, plain and clipped — summed in a fixed order
+ * grad_scale = 2*weight/N, N = elements averaged over); partials[V*tiles*4, 2] = per 8x8 quadrant of every tile (in
+ * tile order) the sums of squared differences, plain and clipped — summed in a fixed order
  * by the caller (deterministic).  depth_maps may be null (no depth channel).
  */
 int s360_forward_mse(const S360Params* prm, const S360View* views, const float* means3D,

@@ -23,18 +23,18 @@ namespace s360 {
 
 constexpr int GREC = 12;  // floats per partial record: gx gy gA gB | gC gop gr gg | gb - - -
 
-// Wave-autonomous like the forward composite: wave w replays strip w of the tile back to front from
+// Wave-autonomous like the forward composite: wave w replays quadrant w of the tile back to front from
 // final_T / n_contrib, 64 list entries at a time with lane l holding entry (hi - l) in registers.
-// Per surviving entry the 9 raster gradients are reduced over the strip's 64 pixels with DPP adds and
-// lane 63 stores ONE partial record for (instance, strip); k_preprocess_bwd adds the (up to four)
-// strip partials of every instance in a fixed order.  No LDS, no barriers, no float atomics.
+// Per surviving entry the 9 raster gradients are reduced over the quadrant's 64 pixels with DPP adds and
+// lanes 0-7 / 63 store ONE partial record for (instance, quadrant); k_gather_pairs adds the (up to four)
+// quadrant partials of every instance in a fixed order.  No LDS, no barriers, no float atomics.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_render_bwd(
     KParams kp, const S360View* __restrict__ views, const uint32_t* __restrict__ tile_start,
     const uint32_t* __restrict__ list, const uint32_t* __restrict__ offsets, const float4* __restrict__ recA,
     const float4* __restrict__ recB, const float4* __restrict__ recC, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dimages, float4* __restrict__ part,
     uint8_t* __restrict__ valid, const uint32_t* __restrict__ order) {
-    const uint32_t unit = order ? order[blockIdx.x] : blockIdx.x;  // tile*4 + strip
+    const uint32_t unit = order ? order[blockIdx.x] : blockIdx.x;  // tile*4 + quadrant
     const int t = (int)(unit >> 2), wave = (int)(unit & 3u), lane = threadIdx.x;
     const int v = t / kp.T, rem = t - v * kp.T;
     const int ty = rem / kp.gx, tx = rem - ty * kp.gx;
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
         dp1 = dimg[hw + pix];
         dp2 = dimg[2 * hw + pix];
     }
-    const uint32_t wave_last = wave_max_u32(last);  // entries [0, wave_last) can matter to this strip
+    const uint32_t wave_last = wave_max_u32(last);  // entries [0, wave_last) can matter to this quadrant
     if (wave_last == 0) return;
     const float bg_dot = vw.bg[0] * dp0 + vw.bg[1] * dp1 + vw.bg[2] * dp2;
     float T = T_final;
@@ -175,8 +175,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
     }
 }
 
-// One thread per (view, Gaussian) pair: adds the strip partials of all its (tile) instances in a fixed
-// order (instance ascending, strip ascending) into one 48-byte raster-gradient record per pair.
+// One thread per (view, Gaussian) pair: adds the quadrant partials of all its (tile) instances in a fixed
+// order (instance ascending, quadrant ascending) into one 48-byte raster-gradient record per pair.
 // Light on registers => full occupancy, so the dependent offsets -> flags -> partials loads overlap
 // across waves instead of serialising inside the fat per-Gaussian kernel.
 __global__ __launch_bounds__(S360_BLOCK) void k_gather_pairs(KParams kp, const uint32_t* __restrict__ tiles_touched,
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_gather_pairs(KParams kp, const u
     const uint32_t i1 = min(offsets[p], kp.cap);
     float gx_ = 0.f, gy_ = 0.f, gA = 0.f, gB = 0.f, gC = 0.f, gop = 0.f, gr = 0.f, gg = 0.f, gb = 0.f;
     for (uint32_t i = i0; i < i1; ++i) {
-        const uint32_t vw4 = valid_words[i];  // byte s != 0: strip s wrote a partial
+        const uint32_t vw4 = valid_words[i];  // byte s != 0: quadrant s wrote a partial
 #pragma unroll
         for (int sidx = 0; sidx < 4; ++sidx) {
             if (!((vw4 >> (8 * sidx)) & 0xFFu)) continue;
@@ -671,7 +671,7 @@ static int backward_impl(const S360Params* prm, const S360View* views, const flo
     const uint32_t* list = (const uint32_t*)(ws + L.list);
     const float* final_T = (const float*)(ws + L.final_T);
     const uint32_t* n_contrib = (const uint32_t*)(ws + L.n_contrib);
-    // backward scratch: [cap] x 4 strip partial records of 48 B, then [cap] x 4 validity bytes
+    // backward scratch: [cap] x 4 quadrant partial records of 48 B, then [cap] x 4 validity bytes
     float4* part = (float4*)bwd_workspace;
     uint32_t* valid_words = (uint32_t*)((char*)bwd_workspace + (size_t)kp.cap * 4 * GREC * 4);
 

@@ -418,7 +418,7 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 // tile*4 + quadrant, weight = the forward's replay length; forward: unit = tile, weight = list length)
 // (64-bucket counting sort on weight / max weight).  Units are dispatched in index order round-robin over
 // the CUs / SIMDs, so dealing them heavy-first gives every SIMD a similar mix (LPT-style balancing of
-// the sequential per-strip chains, which cannot be split).
+// the sequential per-quadrant chains, which cannot be split).
 // The same launch also clears the backward's validity words (valid[instance*4 + quadrant] = 1 when that
 // quadrant's wave wrote a partial record): block 0 orders, blocks 1.. zero (one 32-bit word = 4 flags per instance).
 static __global__ __launch_bounds__(1024) void k_order_units(const uint32_t* __restrict__ weight, uint32_t* __restrict__ order, int n,

@@ -698,16 +698,16 @@ __global__ __launch_bounds__(S360_BLOCK) void k_sort_tiles_global(const uint32_t
 }
 
 // ------------------------------------------------------------------------------ composite
-// Wave-autonomous strips.  A workgroup is the four 16x4 pixel strips of one 16x16 tile, but the
+// Wave-autonomous quadrants.  A workgroup is the four 8x8 pixel quadrants of one 16x16 tile, but the
 // four waves never synchronise: each wave walks the tile's depth-sorted list on its own, 64 entries
 // at a time, with lane l fetching entry l straight into registers (list index prefetched two
 // chunks ahead, splat records one chunk ahead).  The wave's register file is the broadcast source:
-//   * cull   : every lane tests ITS entry against the strip with the conservative cull radius;
+//   * cull   : every lane tests ITS entry against the quadrant with the exact cull half-extents;
 //              the ballot is the work list (culled entries fail alpha >= 1/255 on every pixel of
-//              the strip, so skipping them changes nothing);
+//              the quadrant, so skipping them changes nothing);
 //   * dense  : surviving entries are broadcast one at a time with v_readlane (SGPR operands, no
 //              LDS, no exec-mask juggling) while the 64 pixels sit in the lanes;
-//   * sparse : once <= SPARSE_PIXELS pixels of the strip are still unsaturated the roles flip —
+//   * sparse : once <= SPARSE_PIXELS pixels of the quadrant are still unsaturated the roles flip —
 //              64 ENTRIES in the lanes, one live pixel per iteration, and only entries passing the
 //              tests are replayed in list order.  Same arithmetic per (pixel, entry) pair.
 // A wave retires as soon as its own 64 pixels are saturated (no tile-wide barrier to wait for).
@@ -721,7 +721,7 @@ constexpr int SPARSE_PIXELS = S360_SPARSE_PIXELS;
 struct MseEp {
     const float* target;  // [V,3,H,W] or null (epilogue off)
     float* d_images;      // [V,3,H,W]  grad_scale * (image - target)
-    float* partials;      // [V*T*4, 2] per 16x4 strip: sum (image-target)^2, sum (clip01(image)-clip01(target))^2
+    float* partials;      // [V*T*4, 2] per 8x8 quadrant: sum (image-target)^2, sum (clip01(image)-clip01(target))^2
     float grad_scale;
 };
 
@@ -1013,7 +1013,7 @@ extern "C" int s360_layout(const S360Params* prm, S360Layout* out) {
     out->tile_max_contrib = take(nt * 4);
     out->strip_last = take(nt * 4 * 4);
     out->total_bytes = o;
-    // backward scratch: 4 strip-partial raster-gradient records (12 floats) + 4 validity bytes per instance
+    // backward scratch: 4 quadrant-partial raster-gradient records (12 floats) + 4 validity bytes per instance
     // ... + tile order [V*T] + one gathered 48-byte record per (view, Gaussian) pair
     out->backward_bytes = align_up(cap * 4 * 12 * 4) + align_up(cap * 4) + align_up(nt * 4 * 4) + 512 + align_up(np * 48) +
                           align_up((size_t)(prm->P > 0 ? prm->P : 1) * 16) + 256;

@@ -133,8 +133,8 @@ def _forward_call(prm, views, means3D, cov6, opac, shs, colors, want_radii: bool
         if depth_mode is not None:
             depth = torch.empty((prm.V, prm.H, prm.W), dtype=torch.float32, device=dev)
         d_images = torch.empty_like(images)
-        nstrips = prm.V * ((prm.H + 15) // 16) * ((prm.W + 15) // 16) * 4
-        partials = torch.empty((nstrips, 2), dtype=torch.float32, device=dev)
+        nquads = prm.V * ((prm.H + 15) // 16) * ((prm.W + 15) // 16) * 4   # one partial per wave footprint (8x8 px)
+        partials = torch.empty((nquads, 2), dtype=torch.float32, device=dev)
         rc = _lib.lib().s360_forward_mse(C.byref(prm), _ptr(views), _ptr(means3D), _ptr(cov6), _ptr(opac), _ptr(shs),
                                          _ptr(colors), _ptr(images), _ptr(depth), DEPTH_MODES.get(depth_mode, 0), _ptr(radii),
                                          _ptr(target), C.c_float(grad_scale), _ptr(d_images), _ptr(partials),
