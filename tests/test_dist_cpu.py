@@ -80,3 +80,95 @@ def test_shard_views_partitions():
         for world in (1, 2, 4, 8):
             parts = [shard_views(n, r, world) for r in range(world)]
             assert sorted(sum(parts, [])) == list(range(n))
+
+
+POS = ((0.0, 0.0, 0.0), (0.3, -0.1, 0.2))
+
+
+def _rank_view(rank):
+    """One 32x32 face view per rank from that rank's panorama centre; oracle gradients and the factors the split
+    backward would export (d_rgb_sum = clamp-masked dL/dRGB, w = visibility)."""
+    from helpers import boundary_tensors, face_settings
+    from oracle import oracle
+    from splatter360_amd import synthetic
+    cloud = synthetic.uniform_cloud(300, seed=5, extent=2.0, scale_range=(0.05, 0.3))
+    S = face_settings(1, 32, 32, position=POS[rank])
+    means, cov6, shs, opac = boundary_tensors(cloud, S["scale"])
+    o = oracle.rasterize(S, means3D=means, cov3D_precomp=cov6, opacities=opac, shs=shs, dtype=np.float64)
+    f = o.forward()
+    g = o.backward(np.random.default_rng(30 + rank).standard_normal((3, 32, 32)))
+    vis = f["radii"] > 0
+    drgb = np.where(f["clamped"].astype(bool), 0.0, g["raster_rgb"]) * vis[:, None]
+    return cloud, S, g, drgb, vis
+
+
+def _sh_pass_restated(prm, views, means3D, shs, d_rgb_sums, d_means3D):
+    """torch restatement of what s360_sh_backward computes for dL/dSH (the view-direction term of dL/dmean is left
+    out: d_means3D is not touched) — stands in for the HIP kernel in this CPU test of the exchange logic."""
+    from oracle import torch_ref
+    out = torch.zeros_like(shs)                       # [P, 25, 3]
+    for j in range(d_rgb_sums.shape[0]):
+        w = d_rgb_sums[j, :, 3].contiguous().view(torch.int32)
+        assert bool(((w == j) | (w == -1)).all())     # .w was rewritten to the owning rank / group index
+        campos, scale = views[j, 32:35], views[j, 40]
+        d = means3D * scale - campos
+        y = torch_ref.sh_basis(4, d / d.norm(dim=1, keepdim=True))           # [P, 25]
+        out += (w >= 0).to(shs.dtype)[:, None, None] * y[:, :, None] * d_rgb_sums[j, :, None, :3]
+    return out
+
+
+def _factored_worker(rank, world, port, q):
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    sys.path[:0] = [str(root), str(root / "tests")]
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from splatter360_amd import distributed as D, rasterizer
+    D.init(backend="gloo")
+    rasterizer.finish_deferred_sh = _sh_pass_restated         # the HIP kernel's job, restated (no GPU here)
+    cloud, S, g, drgb, vis = _rank_view(rank)
+    t = lambda a: torch.tensor(np.asarray(a, np.float64))
+    means, cov, op = t(cloud["means"]), t(cloud["covariances"]), t(cloud["opacities"])
+    sh = torch.tensor(cloud["harmonics"], dtype=torch.float32).transpose(1, 2).contiguous()     # [P, 25, 3], f32 like the kernel's
+    r, c = np.triu_indices(3)
+    cov_grad = np.zeros((300, 3, 3)); cov_grad[:, r, c] = S["scale"] ** 2 * g["cov3D"]
+    means.grad, cov.grad, op.grad = t(S["scale"] * g["means3D"]), t(cov_grad), t(g["opacities"].reshape(-1))
+    sh.grad = None
+    d_rgb_sum = torch.zeros((300, 4), dtype=torch.float32)
+    d_rgb_sum[:, :3] = torch.tensor(drgb, dtype=torch.float32)
+    d_rgb_sum[:, 3] = torch.where(torch.tensor(vis), torch.tensor(0, dtype=torch.int32), torch.tensor(-1, dtype=torch.int32)).view(torch.float32)
+    views = torch.zeros((1, 44), dtype=torch.float32)
+    views[0, 32:35] = torch.tensor(np.asarray(S["campos"], np.float32))
+    views[0, 40] = S["scale"]
+    deferred = rasterizer.DeferredSH(None, views, means.float(), sh, d_rgb_sum)
+    D.sync_gradients_factored(means, cov, sh, op, deferred)
+    q.put((rank, [x.grad.double().numpy() for x in (means, cov, sh, op)]))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_factored_exchange_reconstructs_the_summed_sh_gradient():
+    """CPU (gloo, world size 2) test of distributed.sync_gradients_factored: the all-gathered (camera, dRGB) factors
+    rebuild the SUM over ranks of the oracle's dL/dSH (the rank-1 structure the exchange relies on), the other
+    gradients are all-reduced, and every rank ends with the same result."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_factored_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    outs = [q.get(timeout=240) for _ in range(world)]
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    want = [0.0, 0.0, 0.0, 0.0]
+    r, c = np.triu_indices(3)
+    for rank in range(world):
+        cloud, S, g, drgb, vis = _rank_view(rank)
+        cov_grad = np.zeros((300, 3, 3)); cov_grad[:, r, c] = S["scale"] ** 2 * g["cov3D"]
+        # oracle gradients are w.r.t. the rescaled boundary tensors; SH is not rescaled
+        want[0] = want[0] + S["scale"] * g["means3D"]
+        want[1] = want[1] + cov_grad
+        want[2] = want[2] + g["shs"]
+        want[3] = want[3] + g["opacities"].reshape(-1)
+    for rank, got in outs:
+        for a, b, tol in zip(got, want, (1e-12, 1e-12, 2e-5, 1e-12)):   # SH goes through float32 factors
+            scale = np.abs(b).max() + 1e-30
+            assert np.abs(a - b).max() / scale <= tol
