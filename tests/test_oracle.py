@@ -169,3 +169,73 @@ def test_empty_cloud():
                          colors_precomp=np.zeros((0, 3)), dtype=np.float32).forward()
     assert f["num_rendered"] == 0
     np.testing.assert_allclose(f["image"], np.broadcast_to(np.array([0.1, 0.2, 0.3], np.float32)[:, None, None], (3, 64, 64)))
+
+
+def _settings_from_camera(c2w, k, near, far, h, w, bg=(0.0, 0.0, 0.0)):
+    """GaussianRasterizationSettings fields built by the product's restatement of the reference glue
+    (cuda_splatting.py:64-112; pinned bit-for-bit by tests/test_golden_glue.py)."""
+    from splatter360_amd import cameras
+    vs = cameras.view_setup(c2w[None], k[None], torch.tensor([near]), torch.tensor([far]))
+    return dict(image_height=h, image_width=w, tanfovx=float(vs["tan_fov_x"][0]), tanfovy=float(vs["tan_fov_y"][0]),
+                bg=np.asarray(bg, np.float64), viewmatrix=vs["view_matrix"][0].numpy(), projmatrix=vs["full_projection"][0].numpy(),
+                sh_degree=4, campos=vs["campos"][0].numpy(), scale=float(vs["scale"][0]))
+
+
+def test_reference_smoke_scene_one_unit_gaussian_band2_sh():
+    """The scene of the reference's only rasteriser script (src/scripts/test_splatter.py:21-87): ONE Gaussian at the
+    origin with unit covariance, opacity 1, red SH band 2 = 10, camera 10 units away, 90-degree fov, near 0.1 /
+    far 20, 512x512 — rendered here from (0,0,-10) looking down +z (SH left unrotated).  Closed form after the
+    1/near rescale: depth 100, 2-D variance (256*10/100)^2 + 0.3, radius ceil(3 sigma), centre alpha capped at
+    0.99, red = 0.5 + 10*Y_6(0,0,1) = 0.5 + 10*0.31539*2 (unclamped above 1), green = blue = 0.5."""
+    c2w = torch.eye(4)
+    c2w[2, 3] = -10.0
+    k = torch.eye(3)
+    k[0, 0] = k[1, 1] = k[0, 2] = k[1, 2] = 0.5
+    S = _settings_from_camera(c2w, k, 0.1, 20.0, 512, 512)
+    assert S["scale"] == 10.0 and abs(S["tanfovx"] - 1.0) < 1e-6
+    sh = np.zeros((1, 25, 3))
+    sh[0, 4:9, 0] = 10.0
+    means = np.zeros((1, 3)) * S["scale"]
+    cov6 = np.array([[1.0, 0, 0, 1.0, 0, 1.0]]) * S["scale"] ** 2
+    f = oracle.rasterize(S, means3D=means, cov3D_precomp=cov6, opacities=np.ones((1, 1)), shs=sh, dtype=np.float64).forward()
+    var = (256.0 * 10.0 / 100.0) ** 2 + 0.3
+    assert f["radii"][0] == math.ceil(3.0 * math.sqrt(var)) == 77
+    np.testing.assert_allclose(f["xy"][0], [255.5, 255.5], atol=1e-4)
+    np.testing.assert_allclose(f["depth"][0], 100.0, rtol=1e-6)
+    red = 0.5 + 10.0 * 0.31539156525252005 * 2.0
+    np.testing.assert_allclose(f["rgb"][0], [red, 0.5, 0.5], rtol=1e-6)
+    a = min(0.99, math.exp(-0.5 * (0.5 ** 2 + 0.5 ** 2) / var))        # nearest pixel centres are half a pixel off
+    assert a == 0.99
+    np.testing.assert_allclose(f["image"][:, 255, 255], 0.99 * np.array([red, 0.5, 0.5]), rtol=1e-6)
+    # 40 px to the right of the centre the splat is still above the 1/255 cut; 100 px to the right it is below it
+    np.testing.assert_allclose(f["image"][1, 255, 295], 0.5 * math.exp(-0.5 * ((295 - 255.5) ** 2 + 0.25) / var), rtol=1e-5)
+    assert math.exp(-0.5 * ((355 - 255.5) ** 2 + 0.25) / var) < 1.0 / 255.0 and f["image"][1, 255, 355] == 0.0
+    assert f["tiles_touched"][0] == (int((255.5 + 77 + 15) // 16) - int((255.5 - 77) // 16)) ** 2
+
+
+def test_gaussian_on_a_cube_edge_is_rendered_on_both_faces():
+    """A splat whose centre lies in the plane bisecting two adjacent 90-degree faces projects onto the shared image
+    border of both (x_ndc = +1 in one, -1 in the other) and must be binned / rendered by both."""
+    from helpers import face_settings
+    from splatter360_amd import cameras, synthetic
+    ext = cameras.cube_face_extrinsics(torch.from_numpy(synthetic.target_pano_pose((0, 0, 0)))[None])[0]
+    fa, fb = 1, 2                                       # "front" and "left" of the rendered order
+    axis = lambda f: ext[f][:3, 2].numpy().astype(np.float64)   # camera +z (viewing direction) in world space
+    assert abs(float(axis(fa) @ axis(fb))) < 1e-6
+    p = (axis(fa) + axis(fb)) / math.sqrt(2.0) * 2.0    # 2 units away, on the bisecting plane
+    hits = []
+    for f in (fa, fb):
+        S = face_settings(f, 64, 64)
+        means = p[None] * S["scale"]
+        cov6 = np.array([[0.01, 0, 0, 0.01, 0, 0.01]]) * S["scale"] ** 2
+        o = oracle.rasterize(S, means3D=means, cov3D_precomp=cov6, opacities=np.full((1, 1), 0.9),
+                             colors_precomp=np.array([[1.0, 0.5, 0.25]]), dtype=np.float64)
+        r = o.forward()
+        assert r["radii"][0] > 0 and r["tiles_touched"][0] > 0
+        x = r["xy"][0][0]
+        assert min(abs(x - 63.5), abs(x + 0.5)) < 1e-3            # ((+-1 + 1) * 64 - 1) / 2: exactly on a vertical border
+        img = r["image"]
+        col = 63 if abs(x - 63.5) < 1e-3 else 0
+        assert img[0, :, col].max() > 0.3 and img[0, :, 63 - col].max() == 0.0   # visible at that border only
+        hits.append(col)
+    assert sorted(hits) == [0, 63]                                   # opposite borders in the two faces
