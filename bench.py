@@ -3,11 +3,15 @@
 
 Metric (BASELINE.json): Msplats/s forward+backward at 1 048 576 Gaussians, 1024x512 ERP
 (= six 256x256 cube faces + cube->ERP stitch), L2 pixel loss on the faces (the reference's loss,
-src/loss/loss_mse.py:30-31), 1/2/4/8 GPUs with one target view per GPU (weak scaling) and an RCCL
-all-reduce of the per-Gaussian gradients.
+src/loss/loss_mse.py:30-31), 1/2/4/8 GPUs with one target view per GPU (weak scaling) and one RCCL
+exchange of the per-Gaussian gradients per step (default: the factored form of DESIGN.md section 5 —
+all-reduce of the mean / covariance / opacity gradients + all-gather of the per-Gaussian dL/dRGB factors,
+SH gradient rebuilt locally; --grad-sync allreduce = one all-reduce of all 352 B/Gaussian).
 
-A "step" is one pass of the hot path per rank: fused six-face forward, stitch, loss, backward
-(+ gradient all-reduce when N > 1).  Inputs are resident in HBM before the timed region.
+A "step" is one pass of the hot path per rank: fused six-face forward (L2 loss and its gradient seed fused
+into the composite store unless --fused-loss 0), stitch, backward (+ the gradient exchange when N > 1; after
+it every rank holds the summed gradients of all four parameter tensors).  Inputs are resident in HBM before
+the timed region.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
