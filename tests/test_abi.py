@@ -59,3 +59,23 @@ def test_rasterizer_refuses_cpu_tensors():
                                    views=views, image_height=16, image_width=16)
     with pytest.raises(Exception):
         rasterizer.rasterize_views(torch.zeros(4, 3), torch.zeros(4, 6), torch.zeros(4), views=views, image_height=16, image_width=16)
+
+
+def test_header_is_plain_c_and_a_c_program_can_call_the_library(tmp_path):
+    """examples/c_abi_layout.c is compiled as C99 with -pedantic against include/s360.h, linked to libs360.so and
+    run: the boundary is a C ABI (no C++ / torch types), usable without Python, and the host-only entry points
+    need no GPU."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    _lib.lib()
+    root = Path(__file__).resolve().parent.parent
+    exe = tmp_path / "c_abi_layout"
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", f"-I{root / 'include'}", str(root / "examples" / "c_abi_layout.c"),
+           f"-L{root / 'splatter360_amd'}", "-ls360", f"-Wl,-rpath,{root / 'splatter360_amd'}", "-o", str(exe)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert f"abi {_lib.ABI_VERSION} " in r.stdout and "bad V -> -1" in r.stdout
