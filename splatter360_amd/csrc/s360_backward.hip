@@ -15,6 +15,13 @@
 // No float atomics anywhere: gradients are bit-reproducible run to run.
 #include "s360_device.h"
 #include "s360_prof.h"
+#include "s360_bwd_math.h"
+
+// formulation of the per-entry arithmetic: bwd_entry_packed (default) or bwd_entry_scalar — bit-identical results
+// (tests/test_bwd_math.py), the packed one needs 14 fewer VALU instructions per surviving entry
+#ifndef S360_BWD_ENTRY
+#define S360_BWD_ENTRY bwd_entry_packed
+#endif
 
 #include <cstdio>
 #include <cstdlib>
@@ -61,8 +68,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
     const uint32_t wave_last = wave_max_u32(last);  // entries [0, wave_last) can matter to this quadrant
     if (wave_last == 0) return;
     const float bg_dot = vw.bg[0] * dp0 + vw.bg[1] * dp1 + vw.bg[2] * dp2;
-    float T = T_final;
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_alpha = 0.f;
+    BwdPixel st = {T_final, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const BwdConst kc = {dp0, dp1, dp2, T_final, bg_dot};
 
     // chunk k holds list positions hi-63 .. hi (lane l <-> position hi - l), hi = wave_last-1-64k
     const int64_t hi0 = (int64_t)wave_last - 1;
@@ -121,31 +128,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
             const float om = 1.0f - a_eff;
             float rcp = __builtin_amdgcn_rcpf(om);
             rcp = __builtin_fmaf(__builtin_fmaf(-om, rcp, 1.0f), rcp, rcp);
-            T = T * rcp;
-            const float dchannel_dcolor = a_eff * T;
             const float c0 = rl(eb.z, bit), c1 = rl(eb.w, bit), c2 = rl(ec, bit);
-            acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
-            acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
-            acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2;
-            lc0 = c0; lc1 = c1; lc2 = c2;
-            float dL_dalpha = (c0 - acc0) * dp0 + (c1 - acc1) * dp1 + (c2 - acc2) * dp2;
-            float g_r = dchannel_dcolor * dp0;
-            float g_g = dchannel_dcolor * dp1;
-            float g_b = dchannel_dcolor * dp2;
-            dL_dalpha *= T;
-            last_alpha = a_eff;
-            dL_dalpha += (-T_final * rcp) * bg_dot;
-            const float dL_dG = op * dL_dalpha;
-            const float gdx = G_eff * dx, gdy = G_eff * dy;
-            // dG/d(delta) = -G (a dx + b dy) = ln2 * G (2 a' dx + b' dy)   (a' = -log2e/2 a, b' = -log2e b)
-            const float dG_ddelx = 0.6931471805599453f * (2.0f * gdx * cA + gdy * cB);
-            const float dG_ddely = 0.6931471805599453f * (2.0f * gdy * cC + gdx * cB);
-            float g_x = dL_dG * dG_ddelx;
-            float g_y = dL_dG * dG_ddely;
-            float g_A = -0.5f * gdx * dx * dL_dG;
-            float g_B = -gdx * dy * dL_dG;
-            float g_C = -0.5f * gdy * dy * dL_dG;
-            float g_op = G_eff * dL_dalpha;
+            BwdOut go;
+            S360_BWD_ENTRY(st, kc, a_eff, G_eff, rcp, cA, cB, cC, op, c0, c1, c2, dx, dy, go);
+            float g_x = go.g_x, g_y = go.g_y, g_A = go.g_A, g_B = go.g_B, g_C = go.g_C, g_op = go.g_op, g_r = go.g_r, g_g = go.g_g,
+                  g_b = go.g_b;
 #ifdef S360_PLAIN_REDUCE
             wave_sum9_lane63(g_x, g_y, g_A, g_B, g_C, g_op, g_r, g_g, g_b);
             const uint32_t inst = (uint32_t)__builtin_amdgcn_readlane((int)einst, bit);
