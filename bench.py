@@ -39,8 +39,6 @@ import torch  # noqa: E402
 from splatter360_amd import _lib, decoder, distributed, rasterizer, stitch, synthetic  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 measured-achievable
-# SURVEY.md §8(d) compulsory bytes per splat at G = 1 048 576, ERP 1024x512
-BYTES_FWD, BYTES_BWD = 350.5, 684.5
 FWD_KERNELS = ("preprocess", "scan", "tile_scan", "emit", "sort_tiles", "render", "cube2erp")
 
 
@@ -114,7 +112,7 @@ def main():
     ext, K, near, far = decoder.cube_cameras(pose, 0.1, 10.0)
     bg = torch.zeros(3, device=dev)
     gt = torch.full((6, 3, face_w, face_w), 0.5, device=dev)
-    c2e = stitch.Cube2Equirec(face_w, pano_h, pano_w).to(dev)
+    c2e = stitch.Cube2Equirec(face_w, 2 * face_w, 4 * face_w).to(dev)   # target ERP = (2 fw) x (4 fw)
     cams = decoder.CameraPrefetcher(dev)
     out = {}
 
@@ -124,7 +122,7 @@ def main():
     def step_eval():
         # evaluation_index_replica.json: 3 target views per scene -> 18 faces, colour + depth (test_step :336-345)
         for (e, k, n, f) in eval_poses:
-            col, dep = decoder.render_views_fused(e, k, n, f, (face_w, face_w), bg, *params, check="lazy", depth_mode="depth",
+            col, dep = decoder.render_views_fused(e, k, n, f, (face_w, face_w), bg, *params, check="lazy", shared_campos=True, depth_mode="depth",
                                                   views=cams.pack(e, k, n, f, bg))
             out["erp"] = c2e.stitch_rendered(col)
             out["faces"] = col
@@ -134,11 +132,11 @@ def main():
             p.grad = None
         views = cams.pack(ext, K, near, far, bg)  # camera glue of this step, overlapped on a side stream
         if a.mode == "fwdbwd" and a.fused_loss:   # LossMse fused into the composite store
-            faces, fm = decoder.render_views_fused(ext, K, near, far, (face_w, face_w), bg, *params, check="lazy", views=views,
+            faces, fm = decoder.render_views_fused(ext, K, near, far, (face_w, face_w), bg, *params, check="lazy", shared_campos=True, views=views,
                                                    defer_sh=factored, mse_target=gt)
             loss = fm.loss
         else:
-            faces = decoder.render_views_fused(ext, K, near, far, (face_w, face_w), bg, *params, check="lazy", views=views,
+            faces = decoder.render_views_fused(ext, K, near, far, (face_w, face_w), bg, *params, check="lazy", shared_campos=True, views=views,
                                                defer_sh=factored)
             loss = ((faces - gt) ** 2).mean() if a.mode == "fwdbwd" else None
         out["erp"] = c2e.stitch_rendered(faces.detach())
@@ -199,46 +197,66 @@ def main():
         emit=6 * G * 4 + visible_pairs * 32 + L * 8,
         render_bwd=L * (4 + 48 + 4) + hw * (12 + 8) + L * 48,
         preprocess_bwd=G * 340 + L * 48 + 6 * G * 8 + G * (340 + 12),
-        cube2erp=hw * 12 + pano_h * pano_w * (12 + 12),
+        cube2erp=hw * 12 + (2 * face_w) * (4 * face_w) * (12 + 12),
     )
     for k, v in kernels.items():
         if k in iface:
             v["interface_bytes"] = iface[k]
             v["interface_GBps"] = iface[k] / (v["avg_us"] * 1e-6) / 1e9
+    # SURVEY.md §8(d) compulsory bytes per splat, for THIS workload (350.5 / 684.5 at G = 1 048 576, 1024x512 ERP)
+    face_bytes, erp_bytes = hw * 12, (2 * face_w) * (4 * face_w) * 12
+    BYTES_FWD = 340.0 + (face_bytes + erp_bytes) / G
+    BYTES_BWD = 340.0 + face_bytes / G + 340.0
     per_splat = BYTES_FWD if dom in FWD_KERNELS else BYTES_BWD
     dom_s = kernels[dom]["avg_us"] * 1e-6
     achieved = per_splat * G / dom_s / 1e9
     traffic = valu_busy = valu_insts = None
+    pmc_note = "no committed PMC profile"
     pmc = ROOT / "profiles" / "pmc_latest.json"
     if pmc.exists():   # PMC counters of the committed rocprofv3 passes (scripts/collect_profiles.sh), per launch
         try:
-            rec = json.loads(pmc.read_text()).get(dom, {})
-            traffic, valu_busy, valu_insts = rec.get("hbm_bytes_per_launch"), rec.get("valu_busy_frac"), rec.get("valu_insts_per_launch")
+            blob = json.loads(pmc.read_text())
+            stamp = blob.get("_meta", {})
+            if stamp.get("source_hash") == _lib.source_hash() and stamp.get("gaussians") == G and stamp.get("face") == face_w:
+                rec = blob.get(dom, {})
+                traffic, valu_busy, valu_insts = rec.get("hbm_bytes_per_launch"), rec.get("valu_busy_frac"), rec.get("valu_insts_per_launch")
+                pmc_note = f"PMC counters from profiles/pmc_latest.json (same kernel sources {stamp.get('source_hash')}, same workload)"
+            else:   # never quote counters of other code or another workload: traffic stays null
+                pmc_note = (f"profiles/pmc_latest.json was collected from kernel sources {stamp.get('source_hash')} / G={stamp.get('gaussians')}"
+                            f" (now {_lib.source_hash()} / G={G}): traffic not quoted")
         except Exception:
             traffic = None
     bytes_step = (BYTES_FWD + (BYTES_BWD if a.mode == "fwdbwd" else 0.0)) * G * views_per_step
 
     value = G * views_per_step * world / (dt / a.steps) / 1e6
+    erp_w, erp_h = 4 * face_w, 2 * face_w          # the target ERP the six faces stitch into
+    gm = f"{G / 2**20:g}M" if G % 2**18 == 0 else str(G)
+    what = {"fwdbwd": "fwd+bwd", "fwd": "fwd", "eval": "fwd colour+depth, 3 ERP views"}[a.mode]
+    if G == 1 << 20 and face_w == 256:
+        cfg_name = {"fwdbwd": "BASELINE configs[2]", "fwd": "BASELINE configs[1]", "eval": "BASELINE configs[3] shape (synthetic cloud)"}[a.mode]
+    elif face_w == 512:
+        cfg_name = "BASELINE configs[4] single-rank shape" + (" (G = 2 context panoramas at 2048x1024)" if G == 1 << 22 else " (resolution-decoupled cloud)")
+    else:
+        cfg_name = "non-BASELINE size"
     res = {
-        "metric": {"fwdbwd": "Msplats/s fwd+bwd @1M Gaussians, 1024x512 ERP", "fwd": "Msplats/s fwd @1M Gaussians, 1024x512 ERP",
-                   "eval": "Msplats/s fwd colour+depth, 3 ERP views @1M Gaussians, 1024x512 ERP"}[a.mode],
+        "metric": f"Msplats/s {what} @{gm} Gaussians, {erp_w}x{erp_h} ERP",
         "value": value, "unit": "Msplats/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[2]: {G} encoder-like synthetic Gaussians (seed 0, deg-4 SH), "
-                               f"{pano_w}x{pano_h} ERP = 6 faces {face_w}x{face_w} + stitch, {a.mode}, L2 loss on faces"
-                               + (" (fused epilogue)" if a.mode == "fwdbwd" and a.fused_loss else ""),
-                   "gaussians": G, "erp": [pano_w, pano_h], "face": face_w, "views_per_gpu": 1,
+        "config": {"workload": f"{cfg_name}: {G} encoder-like synthetic Gaussians (seed 0, deg-4 SH, from {a.n_context if hasattr(a, 'n_context') else 2} "
+                               f"context panoramas {pano_w}x{pano_h}), {erp_w}x{erp_h} ERP = 6 faces {face_w}x{face_w} + stitch, {a.mode}"
+                               + (", L2 loss on faces" + (" (fused epilogue)" if a.fused_loss else "") if a.mode == "fwdbwd" else ""),
+                   "gaussians": G, "erp": [erp_w, erp_h], "face": face_w, "views_per_gpu": views_per_step,
                    "parallelism": f"view-sharded x{world}" + ((", RCCL factored grad exchange (all-reduce 52 B/G + all-gather dRGB 16 B/G/rank)" if factored else
                                                                   ", RCCL all-reduce of Gaussian grads") if world > 1 and a.mode == "fwdbwd" else ""),
                    "num_rendered": L, "visible_pairs": visible_pairs},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "valu_busy_frac": valu_busy, "valu_insts_per_launch": valu_insts,
-                     "note": f"{per_splat} B/splat (SURVEY §8d, {'fwd' if dom in FWD_KERNELS else 'bwd'} phase) x {G} splats / "
+                     "note": f"{per_splat:.1f} B/splat (SURVEY §8d, {'fwd' if dom in FWD_KERNELS else 'bwd'} phase) x {G} splats / "
                              f"avg launch {kernels[dom]['avg_us']:.1f} us of the dominant kernel; that kernel is VALU-issue-bound "
                              "(alpha composite: valu_busy_frac = share of the kernel during which the SIMDs' VALU pipes issue, PMC), "
-                             "see DESIGN.md section 4"},
+                             "see DESIGN.md section 4; " + pmc_note},
         "path_roofline": {"bytes_per_step": bytes_step, "achieved_GBps": bytes_step / (dt / a.steps) / 1e9 ,
                           "frac_of_8TBps": bytes_step / (dt / a.steps) / 1e9 / HBM_PEAK_GBPS},
         "kernels": kernels,

@@ -62,6 +62,12 @@ enum {
  * viewmatrix / projmatrix are the flat [4,4] tensors handed over at cuda_splatting.py:86-87
  * (row-vector convention: element [r][c] of the transposed matrix at index 4*r+c).
  */
+#define S360_FLAG_SH_DEG4_IGNORED 16u  /* treat sh_degree 4 as degree 3: coefficients 16..24 are ignored (zero gradient).
+                                         The reference always passes sh_degree = 4 (config/model/encoder/costvolume.yaml:16)
+                                         to a rasteriser fork whose degree-4 table cannot be verified here;
+                                         default (flag clear) = the standard real-SH degree-4 table, this flag = the
+                                         behaviour of a fork that stops at the upstream 3DGS degree 3. */
+
 typedef struct S360View {
     float viewmatrix[16];
     float projmatrix[16];

@@ -1,19 +1,20 @@
-"""Condense gpurun_out/r01/* (scripts/collect_profiles.sh) into the committed profiles/ directory."""
-import collections, csv, glob, json, shutil, subprocess, sys
+"""Condense gpurun_out/$ROUND/* (scripts/collect_profiles.sh) into the committed profiles/ directory."""
+import collections, csv, glob, json, os, shutil, subprocess, sys
 from pathlib import Path
 R = Path(__file__).resolve().parent.parent
-O = R / "gpurun_out" / "r01"
+ROUND = os.environ.get("ROUND", "r02")
+O = R / "gpurun_out" / ROUND
 P = R / "profiles"
 P.mkdir(exist_ok=True)
 rows = list(csv.DictReader(open(O / "stats" / "bench_kernel_stats.csv")))
-with open(P / "r01_bench_kernel_stats.csv", "w") as f:
+with open(P / f"{ROUND}_bench_kernel_stats.csv", "w") as f:
     w = csv.writer(f)
     w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
     for r in rows[:45]:
         w.writerow([r["Name"].split("(")[0][:90], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
 for n in ("bench_fwdbwd.json", "bench_fwd.json", "bench_under_rocprof.json"):
     txt = (O / n).read_text().strip().splitlines()
-    (P / ("r01_" + n)).write_text(json.dumps(json.loads(txt[-1]), indent=1) + "\n")
+    (P / (ROUND + "_" + n)).write_text(json.dumps(json.loads(txt[-1]), indent=1) + "\n")
 subprocess.run([sys.executable, str(R / "scripts" / "make_pmc_json.py"), str(P / "pmc_latest.json"),
                 str(O / "pmc_FETCH_SIZE" / "pmc_counter_collection.csv"), str(O / "pmc_WRITE_SIZE" / "pmc_counter_collection.csv")], check=True)
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -22,7 +23,7 @@ for f in glob.glob(str(O / "pmc_*" / "pmc_counter_collection.csv")):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         if "s360" in k:
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-with open(P / "r01_pmc_counters.csv", "w") as f:
+with open(P / f"{ROUND}_pmc_counters.csv", "w") as f:
     w = csv.writer(f)
     w.writerow(["kernel", "counter", "mean_per_launch", "launches"])
     for k in sorted(acc):
@@ -31,7 +32,7 @@ with open(P / "r01_pmc_counters.csv", "w") as f:
 # VALU-issue view of every kernel (SQ counters are per-SIMD quad-cycles; GRBM_GUI_ACTIVE sums the 8 XCDs):
 # a gfx950 SIMD issues one wave64 VALU instruction per 4 cycles, 1024 SIMDs on the chip.
 pm = json.load(open(P / "pmc_latest.json"))
-by_kernel = {v["kernel"]: v for v in pm.values()}
+by_kernel = {v["kernel"]: v for v in pm.values() if isinstance(v, dict) and "kernel" in v}
 for k, c in acc.items():
     kk = k.replace("s360::", "")
     if kk in by_kernel and "SQ_ACTIVE_INST_VALU" in c and "GRBM_GUI_ACTIVE" in c:
@@ -39,5 +40,7 @@ for k, c in acc.items():
         cycles = mean("GRBM_GUI_ACTIVE") / 8.0
         by_kernel[kk]["valu_insts_per_launch"] = round(mean("SQ_INSTS_VALU")) if "SQ_INSTS_VALU" in c else None
         by_kernel[kk]["valu_busy_frac"] = round(mean("SQ_ACTIVE_INST_VALU") * 4.0 / (cycles * 1024.0), 4)
+pm["_meta"] = json.loads((O / "meta.json").read_text())   # kernel-source hash + workload the counters belong to
+pm["_meta"]["round"] = ROUND
 json.dump(pm, open(P / "pmc_latest.json", "w"), indent=1, sort_keys=True)
 print("profiles/ updated")

@@ -23,6 +23,7 @@ FLAG_SHARED_CAMPOS = 1
 FLAG_COV9 = 2
 FLAG_SH_CHANNEL_MAJOR = 4
 FLAG_FORWARD_ONLY = 8
+FLAG_SH_DEG4_IGNORED = 16
 ABI_VERSION = 9
 
 
@@ -55,8 +56,23 @@ def needs_build() -> bool:
     if not LIB_PATH.exists():
         return True
     t = LIB_PATH.stat().st_mtime
-    deps = [_CSRC / s for s in SOURCES] + [_CSRC / "s360_device.h", _PKG.parent / "include" / "s360.h"]
-    return any(d.stat().st_mtime > t for d in deps)
+    return any(d.stat().st_mtime > t for d in _dep_files())
+
+
+def _dep_files():
+    """Every file the library is compiled from: csrc/*.hip, csrc/*.h, include/*.h."""
+    return sorted(list(_CSRC.glob("*.hip")) + list(_CSRC.glob("*.h")) + list((_PKG.parent / "include").glob("*.h")))
+
+
+def source_hash() -> str:
+    """sha256 (first 16 hex digits) over the kernel sources: stamps profiles/pmc_latest.json so that bench.py only
+    quotes counter traffic collected from THIS code."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in _dep_files():
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess_bwd(
     const int nb = min(S360_BLOCK, P - g0);
     const int nfl = nb * kp.M * 3;
     float* lds_drgb = lds_sh + S360_BLOCK * kp.M * 3;  // per-thread, per-view dRGB (non-shared campos)
-    const bool want_sh = USE_SH && SH_PASS && d_shs != nullptr;
+    const bool want_sh = USE_SH && SH_PASS;  // runs even when d_shs == NULL: dL/dmean needs the view-direction term
 
     if (want_sh) {
         const float* src = shs + (size_t)g0 * kp.M * 3;
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess_bwd(
             d_colors[3 * g + 2] = dcol_sum[2];
         }
     }
-    if (want_sh) {
+    if (want_sh && d_shs) {
         __syncthreads();
         float* dst = d_shs + (size_t)g0 * kp.M * 3;
         if ((((uintptr_t)dst) & 15) == 0) {
@@ -568,6 +568,7 @@ __global__ __launch_bounds__(64) void k_sh_bwd(KParams kp, const S360View* __res
             d_means3D[3 * g + 2] += dm2;
         }
     }
+    if (!d_shs) return;  // only the view-direction term of dL/dmean was wanted (harmonics frozen / detached)
     __syncthreads();  // single wave: orders the LDS writes above before the cooperative read below
     const int nb = min(64, kp.P - g0);
     const int nfl = nb * slab;
@@ -642,7 +643,7 @@ static int backward_impl(const S360Params* prm, const S360View* views, const flo
     const char* ws = (const char*)workspace;
 
     KParams kp;
-    kp.P = prm->P; kp.V = prm->V; kp.H = prm->H; kp.W = prm->W; kp.deg = prm->sh_degree; kp.M = prm->M;
+    kp.P = prm->P; kp.V = prm->V; kp.H = prm->H; kp.W = prm->W; kp.deg = s360_effective_degree(prm); kp.M = prm->M;
     kp.gx = (prm->W + 15) / 16; kp.gy = (prm->H + 15) / 16; kp.T = kp.gx * kp.gy;
     kp.flags = prm->flags; kp.cap = prm->max_instances;
     const int nt = kp.V * kp.T;
@@ -694,11 +695,13 @@ static int backward_impl(const S360Params* prm, const S360View* views, const flo
     if (shs) {
         const bool shared = (kp.flags & S360_FLAG_SHARED_CAMPOS) != 0;
         if (d_rgb_sum && !shared) return S360_E_UNSUPPORTED;  // the split form needs one camera centre per call
-        if (shared || !d_shs) {
+        if (shared) {
             hipLaunchKernelGGL((k_preprocess_bwd<true, false>), dim3(nblk), dim3(S360_BLOCK), 0, st, kp, views, means3D, cov6, shs,
                                tiles_touched, offsets, clamped, pairgrad, d_means3D, d_means2D, d_cov6, d_opacities, d_shs,
-                               d_colors, (d_shs || d_rgb_sum) ? drgb : (float4*)nullptr);
-            if (d_shs && !d_rgb_sum) {
+                               d_colors, drgb);
+            // the SH pass always runs: with d_shs == NULL (harmonics frozen) it still adds dRGB/ddir to dL/dmean,
+            // as upstream does
+            if (!d_rgb_sum) {
                 const int rc2 = launch_sh_bwd(kp, views, means3D, shs, drgb, 1, d_means3D, d_shs, st);
                 if (rc2) return rc2;
             }
@@ -756,7 +759,7 @@ extern "C" int s360_sh_backward(const S360Params* prm, int32_t n_groups, const S
         return S360_E_BADARG;
     if (prm->P == 0) return S360_OK;
     KParams kp;
-    kp.P = prm->P; kp.V = prm->V; kp.H = prm->H; kp.W = prm->W; kp.deg = prm->sh_degree; kp.M = prm->M;
+    kp.P = prm->P; kp.V = prm->V; kp.H = prm->H; kp.W = prm->W; kp.deg = s360_effective_degree(prm); kp.M = prm->M;
     kp.gx = kp.gy = kp.T = 0;
     kp.flags = prm->flags; kp.cap = prm->max_instances;
     const int rc = launch_sh_bwd(kp, views, means3D, shs, (const float4*)d_rgb_sums, n_groups, d_means3D_inout, d_shs,

@@ -20,6 +20,12 @@
 #define S360_SUB_W 8
 #endif
 
+// Active SH degree of a call: S360_FLAG_SH_DEG4_IGNORED turns a requested degree 4 into degree 3 (coefficients
+// 16..24 neither read nor given gradient) — the fallback if the reference's rasteriser fork has no degree-4 table.
+static inline int s360_effective_degree(const S360Params* prm) {
+    return (prm->sh_degree > 3 && (prm->flags & S360_FLAG_SH_DEG4_IGNORED)) ? 3 : prm->sh_degree;
+}
+
 namespace s360 {
 
 constexpr int SUB_W = S360_SUB_W, SUB_H = 64 / S360_SUB_W;

@@ -1048,7 +1048,7 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
     char* ws = (char*)workspace;
 
     KParams kp;
-    kp.P = prm->P; kp.V = prm->V; kp.H = prm->H; kp.W = prm->W; kp.deg = prm->sh_degree; kp.M = prm->M;
+    kp.P = prm->P; kp.V = prm->V; kp.H = prm->H; kp.W = prm->W; kp.deg = s360_effective_degree(prm); kp.M = prm->M;
     kp.gx = (prm->W + 15) / 16; kp.gy = (prm->H + 15) / 16; kp.T = kp.gx * kp.gy;
     kp.flags = prm->flags; kp.cap = prm->max_instances;
     const int nt = kp.V * kp.T;

@@ -180,20 +180,28 @@ def pack_camera_views(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far:
 
 def render_views_fused(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, image_shape: tuple,
                        background: Tensor, gaussian_means: Tensor, gaussian_covariances: Tensor,
-                       gaussian_sh_coefficients: Tensor, gaussian_opacities: Tensor, *, shared_campos: bool = True,
+                       gaussian_sh_coefficients: Tensor, gaussian_opacities: Tensor, *, shared_campos: Optional[bool] = None,
                        max_instances: Optional[int] = None, check: str = "sync", views: Optional[Tensor] = None,
                        depth_mode: Optional[DepthRenderingMode] = None, defer_sh: bool = False,
                        mse_target: Optional[Tensor] = None, mse_weight: float = 1.0, mse_count: Optional[int] = None):
     """V <= 8 views of ONE cloud in one fused rasteriser call: means[G,3], covariances[G,3,3],
     harmonics[G,3,d_sh] (the reference's Gaussians layout, src/model/types.py:7-12, read in place),
-    opacities[G] -> [V,3,h,w].  With the six face cameras of a panorama (shared_campos=True: one camera
-    centre) this is bit-for-bit the result of six reference-style render_cuda calls.  With depth_mode set,
+    opacities[G] -> [V,3,h,w].  With the six face cameras of a panorama (one camera centre) this is bit-for-bit the
+    result of six reference-style render_cuda calls.
+    shared_campos: True = all views share one camera centre and near plane (SH colours evaluated once per
+    Gaussian); False = per-view evaluation; None (default) = decided from `extrinsics` / `near`
+    (views_share_camera_centre: one small synchronising read when they live on the device).
+    Host synchronisation: check="sync" (default) reads the binning-overflow flag back after the forward, like
+    upstream's own scan read-back, and re-renders with the exact capacity if needed; check="lazy" together with an
+    explicit shared_campos never synchronises (validate later with rasterizer.last_state().overflowed()).  With depth_mode set,
     returns (colour, depth[V,h,w]): the depth maps of render_depth_cuda from the SAME pass (the reference
     rasterises every face a second time for them, decoder_splatting_cuda.py:72-97).
     With mse_target[V,3,h,w] (the supervising cube faces) the L2 loss / PSNR epilogue is fused into the render
     (rasterizer.FusedMse appended as the last result)."""
     if views is None:  # callers may pass pre-packed views (e.g. prepared on a side stream, see CameraPrefetcher)
         views = pack_camera_views(extrinsics, intrinsics, near, far, background)
+    if shared_campos is None:
+        shared_campos = views_share_camera_centre(extrinsics, near)
     n = gaussian_sh_coefficients.shape[-1]
     h, w = image_shape
     out = rasterizer.rasterize_views(
@@ -205,6 +213,18 @@ def render_views_fused(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far
     if mse_target is not None:
         res = res + (out[-1],)
     return res[0] if len(res) == 1 else res
+
+
+def views_share_camera_centre(extrinsics: Tensor, near: Tensor) -> bool:
+    """True when all views have one camera centre and one near plane (the six faces of a panorama): the
+    condition under which SH colours may be evaluated once per Gaussian (S360_FLAG_SHARED_CAMPOS).  The camera
+    tensors come from the data loader (host-resident or long materialised), so this comparison is made on the
+    host copy when there is one; for device tensors it costs one small synchronising read — pass
+    shared_campos explicitly on latency-critical paths (DecoderSplattingFused caches the answer per call shape)."""
+    if extrinsics.shape[0] <= 1:
+        return True
+    t = extrinsics[..., :3, 3]
+    return bool(((t == t[:1]).all() & (near == near.reshape(-1)[0]).all()).item())
 
 
 class CameraPrefetcher:
@@ -274,7 +294,8 @@ def render_cube_faces(pano_c2w: Tensor, near: Tensor, far: Tensor, face_w: int, 
     left, back, right, bottom)."""
     ext, k, n, f = cube_cameras(pano_c2w, near, far)
     return render_views_fused(ext, k, n, f, (face_w, face_w), background, gaussian_means, gaussian_covariances,
-                              gaussian_sh_coefficients, gaussian_opacities, max_instances=max_instances, check=check)
+                              gaussian_sh_coefficients, gaussian_opacities, max_instances=max_instances, check=check,
+                              shared_campos=True)   # six faces of one panorama: one camera centre by construction
 
 
 @dataclass
@@ -288,14 +309,18 @@ class DecoderSplattingFused(torch.nn.Module):
     every batch item are rendered `views_per_group` at a time (6 = the cube faces of one target panorama,
     which share a camera centre) in single rasteriser calls, colour and depth together."""
 
-    def __init__(self, background_color=(0.0, 0.0, 0.0), views_per_group: int = 6, shared_campos: bool = True,
-                 cameras_ready: bool = False, use_graph: bool = True):
-        """cameras_ready: the camera tensors were materialised before earlier work on the current stream was
+    def __init__(self, background_color=(0.0, 0.0, 0.0), views_per_group: int = 6, shared_campos: Optional[bool] = None,
+                 cameras_ready: bool = False, use_graph: bool = True, check: str = "sync"):
+        """shared_campos: None (default) = checked per group of views, with ONE small device->host read per
+        forward() call (groups whose views do not share a camera centre and near plane are rendered with per-view
+        SH evaluation instead of silently taking the first view's direction); True / False = trust the caller.
+        check: "sync" (overflow flag read back per rasteriser call, automatic re-render) or "lazy".
+        cameras_ready: the camera tensors were materialised before earlier work on the current stream was
         queued (data-loader output), so their glue may overlap with that work on the side stream."""
         super().__init__()
         self.register_buffer("background_color", torch.tensor(background_color, dtype=torch.float32), persistent=False)
         self.views_per_group, self.shared_campos = views_per_group, shared_campos
-        self.cameras_ready, self.use_graph = cameras_ready, use_graph
+        self.cameras_ready, self.use_graph, self.check = cameras_ready, use_graph, check
         self._cams: dict = {}
 
     def _prefetcher(self, device) -> "CameraPrefetcher":
@@ -309,6 +334,13 @@ class DecoderSplattingFused(torch.nn.Module):
         colors, depths = [], []
         cams = self._prefetcher(extrinsics.device)
         groups = [(i, slice(s, min(v, s + self.views_per_group))) for i in range(b) for s in range(0, v, self.views_per_group)]
+        if self.shared_campos is None:   # one comparison kernel chain + one read for all groups of the call
+            first = (torch.arange(v, device=extrinsics.device) // self.views_per_group) * self.views_per_group
+            t = extrinsics[..., :3, 3]
+            same = ((t == t[:, first]).all(-1) & (near == near[:, first])).cpu()
+            shared = {(i, e.start): bool(same[i, e].all()) for i, e in groups}
+        else:
+            shared = {(i, e.start): bool(self.shared_campos) for i, e in groups}
         # all camera records up front (one graph replay each), so the rasteriser calls queue back to back
         packed = {(i, e.start): cams.pack(extrinsics[i, e], intrinsics[i, e], near[i, e], far[i, e], self.background_color,
                                           inputs_ready=self.cameras_ready) for i, e in groups}
@@ -318,8 +350,8 @@ class DecoderSplattingFused(torch.nn.Module):
                 e = slice(s, min(v, s + self.views_per_group))
                 out = render_views_fused(extrinsics[i, e], intrinsics[i, e], near[i, e], far[i, e], image_shape,
                                          self.background_color, gaussians.means[i], gaussians.covariances[i],
-                                         gaussians.harmonics[i], gaussians.opacities[i], shared_campos=self.shared_campos,
-                                         depth_mode=depth_mode, views=packed[(i, s)])
+                                         gaussians.harmonics[i], gaussians.opacities[i], shared_campos=shared[(i, s)],
+                                         depth_mode=depth_mode, views=packed[(i, s)], check=self.check)
                 if depth_mode is None:
                     cs.append(out)
                 else:

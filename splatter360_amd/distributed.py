@@ -50,7 +50,11 @@ def allreduce_gradients(grads: Sequence[Optional[Tensor]], average: bool = False
                         async_op: bool = False):
     """Sum (or mean) the per-Gaussian gradient tensors over all ranks, in place.  The four buffers
     are issued back to back (largest first so the ring is busy while the small ones queue);
-    returns the work handles when async_op."""
+    returns the work handles when async_op (average together with async_op is rejected: the division
+    would have to run after handles the caller owns)."""
+    if average and async_op:
+        raise ValueError("allreduce_gradients: average=True cannot be combined with async_op=True "
+                         "(divide after waiting on the returned handles)")
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return []
     world = dist.get_world_size(group)
@@ -83,6 +87,12 @@ def sync_gradients_factored(means: Tensor, covariances: Tensor, harmonics: Tenso
     world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
     rank = dist.get_rank(group) if world > 1 else 0
     d = deferred
+    if d is None:
+        raise RuntimeError("sync_gradients_factored needs the DeferredSH of a backward run with defer_sh=True")
+    # every rank must issue the same collectives: a tensor that received no gradient on this rank contributes zeros
+    for t in (means, covariances, opacities):
+        if t.grad is None:
+            t.grad = torch.zeros_like(t)
     rgb = d.d_rgb_sum.clone()
     vis = rgb[:, 3].view(torch.int32) >= 0
     rgb[:, 3] = torch.where(vis, torch.full_like(rgb[:, 3].view(torch.int32), rank), torch.full_like(rgb[:, 3].view(torch.int32), -1)).view(torch.float32)

@@ -8,6 +8,7 @@ libs360.so through the C ABI of include/s360.h.  There is no eager / CPU fallbac
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import NamedTuple, Optional
 
 import torch
@@ -16,6 +17,11 @@ from torch import Tensor, nn
 from . import _lib
 
 VIEW_FLOATS = 44
+
+# Fallback switch for the one unverifiable constant table: the reference always calls its rasteriser
+# fork with sh_degree = 4; if that fork turns out to stop at the public 3DGS degree 3, set this (or the environment
+# variable S360_SH_DEG4_IGNORED=1) and coefficients 16..24 are ignored exactly as such a fork would ignore them.
+SH_DEG4_IGNORED = bool(int(os.environ.get("S360_SH_DEG4_IGNORED", "0")))
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -183,7 +189,8 @@ class _RasterizeViews(torch.autograd.Function):
             needs_bwd = any(ctx.needs_input_grad[:6])  # (grad mode is off inside Function.forward; this reflects apply-time)
             prm.flags = (_lib.FLAG_SHARED_CAMPOS if (shared_campos or v == 1) else 0) | (
                 _lib.FLAG_COV9 if cov9 else 0) | (_lib.FLAG_SH_CHANNEL_MAJOR if sh_channel_major else 0) | (
-                0 if (needs_bwd or keep_offsets) else _lib.FLAG_FORWARD_ONLY)
+                0 if (needs_bwd or keep_offsets) else _lib.FLAG_FORWARD_ONLY) | (
+                _lib.FLAG_SH_DEG4_IGNORED if SH_DEG4_IGNORED else 0)
             prm.max_instances = int(max_instances) if max_instances else default_capacity(p, v)
             mse = None
             if mse_target is not None:

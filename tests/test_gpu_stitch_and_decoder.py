@@ -161,3 +161,23 @@ def test_camera_prefetcher_graph_replay_is_bit_equal_to_eager_glue(gpu):
     dec = decoder.DecoderSplattingFused().to(gpu)
     for _ in range(2):
         assert torch.equal(dec(gs, ext, k, near, far, (32, 32)).color, ref.color)
+
+
+def test_fused_decoder_detects_views_with_different_camera_centres(gpu):
+    """a view list that is NOT six faces of one panorama (mixed camera centres inside a group) must not be
+    rendered with the first view's SH direction: the fused decoder checks the centres and falls back to per-view SH."""
+    from types import SimpleNamespace
+    cloud = synthetic.uniform_cloud(4000, seed=8, extent=3.0, scale_range=(0.02, 0.3))
+    gs = SimpleNamespace(**{k: torch.tensor(v, device=gpu)[None] for k, v in cloud.items()})
+    panos = torch.stack([torch.tensor(synthetic.target_pano_pose((0.3 * j, 0.1 * j, -0.2 * j))) for j in range(2)])
+    e12 = cameras.cube_face_extrinsics(panos)                      # [2,6,4,4]
+    ext = torch.cat([e12[0, :3], e12[1, :3], e12[1, 3:], e12[0, 3:]])[None].to(gpu)   # groups of 6 mix both centres
+    k = cameras.cube_face_intrinsics(2).reshape(1, 12, 3, 3).to(gpu)
+    near = torch.full((1, 12), 0.1, device=gpu)
+    far = torch.full((1, 12), 10.0, device=gpu)
+    ref = decoder.DecoderSplattingCUDA().to(gpu)(gs, ext, k, near, far, (32, 32))
+    auto = decoder.DecoderSplattingFused().to(gpu)(gs, ext, k, near, far, (32, 32))
+    assert torch.equal(auto.color, ref.color)
+    forced = decoder.DecoderSplattingFused(shared_campos=True).to(gpu)(gs, ext, k, near, far, (32, 32))
+    assert not torch.equal(forced.color, ref.color)                # what the unchecked flag would have produced
+    assert decoder.views_share_camera_centre(ext[0, :3], near[0, :3]) and not decoder.views_share_camera_centre(ext[0, :6], near[0, :6])
