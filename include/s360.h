@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define S360_ABI_VERSION 9
+#define S360_ABI_VERSION 10
 #define S360_MAX_VIEWS 8
 #define S360_TILE 16
 
@@ -144,7 +144,9 @@ int s360_forward(const S360Params* prm, const S360View* views, const float* mean
  * colour weights, background 0, not normalised) in ONE pass instead of a second full rasterisation
  * (decoder_splatting_cuda.py:72-97 renders every face twice when depth is wanted).
  *   depth_mode: S360_DEPTH_* (the reference's DepthRenderingMode); depth_maps[V,H,W].
- * The depth output carries no gradient (the reference only renders depth in evaluation / videos).
+ * The depth map is differentiable: pass dL_ddepth to s360_backward — the reference's
+ * training step can request depth (model_wrapper_erp.py:228, train_cfg.depth_mode) and LossDepth
+ * (src/loss/loss_depth.py:37-60) back-propagates through it into means, covariances and opacities.
  */
 #define S360_DEPTH_DEPTH 0
 #define S360_DEPTH_DISPARITY 1
@@ -175,17 +177,21 @@ int s360_forward_mse(const S360Params* prm, const S360View* views, const float* 
  * Backward: replaces upstream `rasterize_gaussians_backward(...)` (autograd backward of the
  * call above).  `workspace` is the forward workspace, unmodified since s360_forward.
  *   dL_dimages[V,3,H,W]
+ *   dL_ddepth[V,H,W] / depth_mode: gradient of the fused depth map of s360_forward_depth (same depth_mode as the
+ *   forward); NULL: no depth channel (e.g. the forward was s360_forward).
  * Outputs (all written, no accumulation into caller data):
  *   d_means3D[P,3]  d_means2D[V,P,3] (NDC-scaled screen-space gradient, z = 0)
  *   d_cov6[P,6]  d_opacities[P]  d_shs[P,M,3] or NULL  d_colors[P,3] or NULL  (d_cov6 / d_shs in the
- *   layouts selected by the flags; gradients are w.r.t. the UNSCALED inputs)
- * Gradients are summed over the V views with a fixed (deterministic) order.
+ *   layouts selected by the flags; gradients are w.r.t. the UNSCALED inputs).  d_shs == NULL (harmonics
+ *   frozen) still propagates dRGB/d(view direction) into d_means3D, as upstream does.
+ * Gradients are summed over the V views with a fixed (deterministic) order; no float atomics anywhere.
  */
 int s360_backward(const S360Params* prm, const S360View* views, const float* means3D,
                   const float* cov6, const float* opacities, const float* shs,
                   const float* colors_precomp, const void* workspace, size_t workspace_bytes,
-                  const float* dL_dimages, float* d_means3D, float* d_means2D, float* d_cov6,
-                  float* d_opacities, float* d_shs, float* d_colors, void* bwd_workspace,
+                  const float* dL_dimages,
+                  const float* dL_ddepth, int32_t depth_mode, float* d_means3D, float* d_means2D,
+                  float* d_cov6, float* d_opacities, float* d_shs, float* d_colors, void* bwd_workspace,
                   size_t bwd_workspace_bytes, void* stream);
 
 /*
@@ -201,9 +207,11 @@ int s360_backward(const S360Params* prm, const S360View* views, const float* mea
  */
 int s360_backward_split(const S360Params* prm, const S360View* views, const float* means3D,
                         const float* cov6, const float* opacities, const float* shs,
-                        const void* workspace, size_t workspace_bytes, const float* dL_dimages,
-                        float* d_means3D, float* d_means2D, float* d_cov6, float* d_opacities,
-                        float* d_rgb_sum, void* bwd_workspace, size_t bwd_workspace_bytes, void* stream);
+                        const void* workspace, size_t workspace_bytes,
+                        const float* dL_dimages, const float* dL_ddepth,
+                        int32_t depth_mode, float* d_means3D, float* d_means2D, float* d_cov6,
+                        float* d_opacities, float* d_rgb_sum, void* bwd_workspace,
+                        size_t bwd_workspace_bytes, void* stream);
 int s360_sh_backward(const S360Params* prm, int32_t n_groups, const S360View* views,
                      const float* means3D, const float* shs, const float* d_rgb_sums /* [n_groups,P,4] */,
                      float* d_means3D_inout, float* d_shs, void* stream);

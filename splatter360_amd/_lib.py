@@ -24,7 +24,7 @@ FLAG_COV9 = 2
 FLAG_SH_CHANNEL_MAJOR = 4
 FLAG_FORWARD_ONLY = 8
 FLAG_SH_DEG4_IGNORED = 16
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class S360Params(C.Structure):
@@ -116,9 +116,9 @@ def lib() -> C.CDLL:
     l.s360_forward_mse.restype = C.c_int
     l.s360_forward_mse.argtypes = [C.POINTER(S360Params)] + [vp] * 8 + [i32, vp, vp, C.c_float, vp, vp, vp, sz, vp]
     l.s360_backward.restype = C.c_int
-    l.s360_backward.argtypes = [C.POINTER(S360Params)] + [vp] * 7 + [sz] + [vp] * 8 + [sz, vp]
+    l.s360_backward.argtypes = [C.POINTER(S360Params)] + [vp] * 7 + [sz] + [vp] * 2 + [i32] + [vp] * 7 + [sz, vp]
     l.s360_backward_split.restype = C.c_int
-    l.s360_backward_split.argtypes = [C.POINTER(S360Params)] + [vp] * 6 + [sz] + [vp] * 7 + [sz, vp]
+    l.s360_backward_split.argtypes = [C.POINTER(S360Params)] + [vp] * 6 + [sz] + [vp] * 2 + [i32] + [vp] * 6 + [sz, vp]
     l.s360_sh_backward.restype = C.c_int
     l.s360_sh_backward.argtypes = [C.POINTER(S360Params), i32] + [vp] * 7
     l.s360_cube2erp_forward.restype = C.c_int

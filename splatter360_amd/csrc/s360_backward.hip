@@ -16,6 +16,7 @@
 #include "s360_device.h"
 #include "s360_prof.h"
 #include "s360_bwd_math.h"
+#include "s360_bwd_em.h"
 
 // formulation of the per-entry arithmetic: bwd_entry_packed (default) or bwd_entry_scalar — bit-identical results
 // (tests/test_bwd_math.py), the packed one needs 14 fewer VALU instructions per surviving entry
@@ -154,6 +155,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
                 if (lane < 8) o[lane ^ (lane >> 1)] = tot;  // Gray code: lane -> value index
                 if (lane == 63) {
                     o[8] = g_b;
+                    o[9] = 0.f;  // no depth channel in this formulation
                     valid[(size_t)inst * 4 + wave] = 1;
                 }
             }
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_gather_pairs(KParams kp, const u
     if (tiles_touched[p] == 0) return;
     const uint32_t i0 = p == 0 ? 0u : offsets[p - 1];
     const uint32_t i1 = min(offsets[p], kp.cap);
-    float gx_ = 0.f, gy_ = 0.f, gA = 0.f, gB = 0.f, gC = 0.f, gop = 0.f, gr = 0.f, gg = 0.f, gb = 0.f;
+    float gx_ = 0.f, gy_ = 0.f, gA = 0.f, gB = 0.f, gC = 0.f, gop = 0.f, gr = 0.f, gg = 0.f, gb = 0.f, gz = 0.f;
     for (uint32_t i = i0; i < i1; ++i) {
         const uint32_t vw4 = valid_words[i];  // byte s != 0: quadrant s wrote a partial
 #pragma unroll
@@ -185,11 +187,12 @@ __global__ __launch_bounds__(S360_BLOCK) void k_gather_pairs(KParams kp, const u
             gx_ += r0.x; gy_ += r0.y; gA += r0.z; gB += r0.w;
             gC += r1.x; gop += r1.y; gr += r1.z; gg += r1.w;
             gb += r2.x;
+            gz += r2.y;
         }
     }
     pairgrad[p * 3] = make_float4(gx_, gy_, gA, gB);
     pairgrad[p * 3 + 1] = make_float4(gC, gop, gr, gg);
-    pairgrad[p * 3 + 2] = make_float4(gb, 0.f, 0.f, 0.f);
+    pairgrad[p * 3 + 2] = make_float4(gb, gz, 0.f, 0.f);
 }
 
 // SH_PASS = true : SH backward inside this kernel (slab through LDS; required when the views have different
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess_bwd(
     const float* __restrict__ shs, const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ offsets,
     const uint8_t* __restrict__ clamped, const float4* __restrict__ pairgrad, float* __restrict__ d_means3D,
     float* __restrict__ d_means2D, float* __restrict__ d_cov6, float* __restrict__ d_opac, float* __restrict__ d_shs,
-    float* __restrict__ d_colors, float4* __restrict__ drgb_out) {
+    float* __restrict__ d_colors, float4* __restrict__ drgb_out, int depth_mode) {
     extern __shared__ __attribute__((aligned(16))) float lds_sh[];  // [256*M*3] SH slab, then [256*V*3] dRGB
     const int tid = threadIdx.x;
     const int g0 = blockIdx.x * S360_BLOCK;
@@ -264,6 +267,16 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess_bwd(
                 const float gA = r0.z, gB = r0.w, gC = r1.x, gop = r1.y, gr = r1.z, gg = r1.w, gb = r2.x;
                 dop += gop;
                 const S360View& vw = views[v];
+                if (depth_mode >= 0) {
+                    // fused depth channel: value = depth_value(z_u), z_u = camera z in UNSCALED units = R_row2 . mean + t_z / scale
+                    // (render_depth_cuda, cuda_splatting.py:239-251), so dz_u / dmean (unscaled) = third row of the rotation
+                    const float* Vm = vw.viewmatrix;
+                    const float tzs = Vm[2] * mx + Vm[6] * my + Vm[10] * mz + Vm[14];
+                    const float dzu = r2.y * depth_value_grad(tzs * (1.0f / sc), vw.near_plane, vw.far_plane, depth_mode);
+                    dm0 += Vm[2] * dzu;
+                    dm1 += Vm[6] * dzu;
+                    dm2 += Vm[10] * dzu;
+                }
                 const float* V = vw.viewmatrix;
                 Geo ge;
                 geo_compute(V, vw.tanfovx, vw.tanfovy, kp.W, kp.H, mx, my, mz, c6, ge);
@@ -626,7 +639,8 @@ static int launch_sh_bwd(const KParams& kp, const S360View* views, const float* 
 
 static int backward_impl(const S360Params* prm, const S360View* views, const float* means3D, const float* cov6,
                          const float* opacities, const float* shs, const float* colors_precomp,
-                         const void* workspace, size_t workspace_bytes, const float* dL_dimages, float* d_means3D,
+                         const void* workspace, size_t workspace_bytes, const float* dL_dimages,
+                         const float* dL_ddepth, int depth_mode, float* d_means3D,
                          float* d_means2D, float* d_cov6, float* d_opacities, float* d_shs, float* d_colors,
                          float* d_rgb_sum, void* bwd_workspace, size_t bwd_workspace_bytes, void* stream_) {
     (void)opacities;
@@ -634,6 +648,8 @@ static int backward_impl(const S360Params* prm, const S360View* views, const flo
     if (prm->flags & S360_FLAG_FORWARD_ONLY) return S360_E_BADARG;
     if (prm->P > 0 && (shs == nullptr) == (colors_precomp == nullptr)) return S360_E_BADARG;
     if (prm->P > 0 && (!means3D || !cov6 || !d_means3D || !d_cov6 || !d_opacities)) return S360_E_BADARG;
+    const bool with_depth = dL_ddepth != nullptr;
+    if (with_depth && (depth_mode < 0 || depth_mode > 3)) return S360_E_BADARG;
     S360Layout L;
     int rc = s360_layout(prm, &L);
     if (rc) return rc;
@@ -655,6 +671,7 @@ static int backward_impl(const S360Params* prm, const S360View* views, const flo
     const float4* recB = (const float4*)(ws + L.rec_b);
     const float4* recC = (const float4*)(ws + L.rec_c);
     const uint8_t* clamped = (const uint8_t*)(ws + L.clamped);
+    const float* depths = (const float*)(ws + L.depths);
     const uint32_t* tile_start = (const uint32_t*)(ws + L.tile_start);
     const uint32_t* list = (const uint32_t*)(ws + L.list);
     const float* final_T = (const float*)(ws + L.final_T);
@@ -666,24 +683,26 @@ static int backward_impl(const S360Params* prm, const S360View* views, const flo
     uint32_t* order = valid_words + kp.cap;  // [nt*4] after the validity words
     const uint32_t* strip_last = (const uint32_t*)(ws + L.strip_last);
     const bool use_order = !getenv("S360_NO_ORDER");
+    // S360_BWD_LEGACY=1: the round-1 pixel-major composite (kept for A/B timing; it has no depth channel)
+    const bool legacy = getenv("S360_BWD_LEGACY") != nullptr && !with_depth;
     {
     ProfScope ps(PS_RENDER_BWD, st);
     hipLaunchKernelGGL(k_order_units, dim3(1 + 512), dim3(1024), 0, st, strip_last, use_order ? order : (uint32_t*)nullptr, nt * 4,
                        valid_words, header, kp.cap);
-    // Even spread of the single-wave work units: when all units fit on the chip at once (<= 32 per CU)
-    // reserve just enough (unused) LDS per workgroup that every CU admits exactly ceil(units / 256) of
-    // them — otherwise the dispatcher packs the first CUs to their register limit and starves the rest.
-    size_t even_lds = 0;
-    {
-        const int per_cu = (nt * 4 + 255) / 256;
-        (void)per_cu;  // measured: forcing an even spread is slower (782 vs 748 us) -> knob only
-        if (getenv("S360_RBWD_LDS")) even_lds = (size_t)atol(getenv("S360_RBWD_LDS"));
-    }
-    hipLaunchKernelGGL(k_render_bwd, dim3(nt * 4), dim3(64), even_lds, st, kp, views, tile_start, list, offsets, recA, recB,
-                       recC, final_T, n_contrib, dL_dimages, part, (uint8_t*)valid_words, use_order ? order : (const uint32_t*)nullptr);
+    const uint32_t* ord = use_order ? order : (const uint32_t*)nullptr;
+    if (legacy)
+        hipLaunchKernelGGL(k_render_bwd, dim3(nt * 4), dim3(64), 0, st, kp, views, tile_start, list, offsets, recA, recB,
+                           recC, final_T, n_contrib, dL_dimages, part, (uint8_t*)valid_words, ord);
+    else if (with_depth)
+        hipLaunchKernelGGL(k_render_bwd_em<true>, dim3(nt * 4), dim3(64), 0, st, kp, views, tile_start, list, offsets, recA,
+                           depths, final_T, n_contrib, dL_dimages, dL_ddepth, part, (uint8_t*)valid_words, ord, depth_mode);
+    else
+        hipLaunchKernelGGL(k_render_bwd_em<false>, dim3(nt * 4), dim3(64), 0, st, kp, views, tile_start, list, offsets, recA,
+                           depths, final_T, n_contrib, dL_dimages, dL_ddepth, part, (uint8_t*)valid_words, ord, depth_mode);
     }
     S360_CHECK_LAUNCH();
     ProfScope ps(PS_PREPROCESS_BWD, st);
+    const int dmode = with_depth ? depth_mode : -1;
     float4* pairgrad = (float4*)((char*)(order + nt * 4) + 256 - ((uintptr_t)(order + nt * 4) & 255));
     {
         const size_t np = (size_t)kp.V * kp.P;
@@ -698,7 +717,7 @@ static int backward_impl(const S360Params* prm, const S360View* views, const flo
         if (shared) {
             hipLaunchKernelGGL((k_preprocess_bwd<true, false>), dim3(nblk), dim3(S360_BLOCK), 0, st, kp, views, means3D, cov6, shs,
                                tiles_touched, offsets, clamped, pairgrad, d_means3D, d_means2D, d_cov6, d_opacities, d_shs,
-                               d_colors, drgb);
+                               d_colors, drgb, dmode);
             // the SH pass always runs: with d_shs == NULL (harmonics frozen) it still adds dRGB/ddir to dL/dmean,
             // as upstream does
             if (!d_rgb_sum) {
@@ -719,12 +738,12 @@ static int backward_impl(const S360Params* prm, const S360View* views, const flo
             }
             hipLaunchKernelGGL((k_preprocess_bwd<true, true>), dim3(nblk), dim3(S360_BLOCK), lds, st, kp, views, means3D, cov6, shs,
                                tiles_touched, offsets, clamped, pairgrad, d_means3D, d_means2D, d_cov6, d_opacities, d_shs,
-                               d_colors, (float4*)nullptr);
+                               d_colors, (float4*)nullptr, dmode);
         }
     } else {
         hipLaunchKernelGGL((k_preprocess_bwd<false, false>), dim3(nblk), dim3(S360_BLOCK), 0, st, kp, views, means3D, cov6, shs,
                            tiles_touched, offsets, clamped, pairgrad, d_means3D, d_means2D, d_cov6, d_opacities, d_shs,
-                           d_colors, (float4*)nullptr);
+                           d_colors, (float4*)nullptr, dmode);
     }
     S360_CHECK_LAUNCH();
     return S360_OK;
@@ -732,23 +751,25 @@ static int backward_impl(const S360Params* prm, const S360View* views, const flo
 
 extern "C" int s360_backward(const S360Params* prm, const S360View* views, const float* means3D, const float* cov6,
                              const float* opacities, const float* shs, const float* colors_precomp,
-                             const void* workspace, size_t workspace_bytes, const float* dL_dimages, float* d_means3D,
+                             const void* workspace, size_t workspace_bytes, const float* dL_dimages,
+                             const float* dL_ddepth, int32_t depth_mode, float* d_means3D,
                              float* d_means2D, float* d_cov6, float* d_opacities, float* d_shs, float* d_colors,
                              void* bwd_workspace, size_t bwd_workspace_bytes, void* stream_) {
-    return backward_impl(prm, views, means3D, cov6, opacities, shs, colors_precomp, workspace, workspace_bytes, dL_dimages,
-                         d_means3D, d_means2D, d_cov6, d_opacities, d_shs, d_colors, nullptr, bwd_workspace,
-                         bwd_workspace_bytes, stream_);
+    return backward_impl(prm, views, means3D, cov6, opacities, shs, colors_precomp, workspace, workspace_bytes,
+                         dL_dimages, dL_ddepth, depth_mode, d_means3D, d_means2D, d_cov6, d_opacities, d_shs,
+                         d_colors, nullptr, bwd_workspace, bwd_workspace_bytes, stream_);
 }
 
 extern "C" int s360_backward_split(const S360Params* prm, const S360View* views, const float* means3D, const float* cov6,
                                    const float* opacities, const float* shs, const void* workspace, size_t workspace_bytes,
-                                   const float* dL_dimages, float* d_means3D, float* d_means2D, float* d_cov6,
-                                   float* d_opacities, float* d_rgb_sum, void* bwd_workspace, size_t bwd_workspace_bytes,
-                                   void* stream_) {
+                                   const float* dL_dimages,
+                                   const float* dL_ddepth, int32_t depth_mode, float* d_means3D, float* d_means2D,
+                                   float* d_cov6, float* d_opacities, float* d_rgb_sum, void* bwd_workspace,
+                                   size_t bwd_workspace_bytes, void* stream_) {
     if (!shs || !d_rgb_sum) return S360_E_BADARG;
-    return backward_impl(prm, views, means3D, cov6, opacities, shs, nullptr, workspace, workspace_bytes, dL_dimages, d_means3D,
-                         d_means2D, d_cov6, d_opacities, nullptr, nullptr, d_rgb_sum, bwd_workspace, bwd_workspace_bytes,
-                         stream_);
+    return backward_impl(prm, views, means3D, cov6, opacities, shs, nullptr, workspace, workspace_bytes, dL_dimages,
+                         dL_ddepth, depth_mode, d_means3D, d_means2D, d_cov6, d_opacities, nullptr, nullptr,
+                         d_rgb_sum, bwd_workspace, bwd_workspace_bytes, stream_);
 }
 
 extern "C" int s360_sh_backward(const S360Params* prm, int32_t n_groups, const S360View* views, const float* means3D,

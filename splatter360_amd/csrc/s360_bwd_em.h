@@ -1,0 +1,290 @@
+// s360_bwd_em.h — entry-major backward composite (k_render_bwd_em).  gfx950 / wave64 only.
+//
+// The round-1 kernel kept the forward's layout (64 PIXELS of an 8x8 quadrant in the lanes, one list entry at a time):
+// per surviving entry it paid ~50 cross-lane instructions to reduce nine gradients over the pixels, with 15.5 of 64
+// lanes contributing on average.  This kernel transposes the roles:
+//   * the wave walks its tile's depth-sorted list 64 entries at a time exactly like the forward, culls each chunk
+//     against its quadrant and COMPACTS the survivors into a 128-slot queue in LDS (48-byte records: centre, conic,
+//     opacity, colour, [depth value], list position, instance slot);
+//   * whenever 64 survivors are queued they are popped into the lanes — lane j holds ONE ENTRY — and the wave loops
+//     over the quadrant's 64 pixels, four at a time.  Per pixel the transmittance around every entry is a scanned
+//     PRODUCT of (1 - alpha) over the lanes and the colour behind it a scanned SUM: two
+//     six-step DPP scans (row_shr 1/2/4/8, row_bcast 15/31) replace the nine 64-lane reductions, and every lane
+//     accumulates its own entry's nine sums in registers.  The per-pixel constants (dL/dpixel, background term,
+//     n_contrib) and the running (T_run, R_run) live in LDS and are read as broadcasts;
+//   * back to front like upstream's backward: the walk starts at the quadrant's last contributor, the queue hands
+//     out entries in DEscending list position (lane 0 = backmost), so an inclusive scan over the lanes is a SUFFIX
+//     in list order: T in front of entry j = T_behind_group / prod_{i at or behind j}(1 - alpha_i), the colour
+//     behind it = R_behind_group + sum_{i behind j} alpha_i T_i (c_i . dL/dpixel).  Both start from exact values
+//     (final_T, 0) and every quantity keeps RELATIVE accuracy (a front-to-back variant that took R from
+//     "rendered pixel - prefix" measured 1.6x faster than round 1 too, but its absolute cancellation error of
+//     ~1e-7, amplified by 1 / (1 - alpha) <= 100, showed up as 2.4x the float32 oracle's own distance from the
+//     float64 oracle on ill-conditioned splats).
+// Accept / reject decisions per (pixel, entry) use the forward's own power2() / alpha expressions and its n_contrib,
+// so they are identical to the forward's.  Results are deterministic (fixed group composition, no atomics).
+// The optional depth channel (WITH_DEPTH) makes the fused depth map of s360_forward_depth differentiable: it is one more
+// "colour" channel for dL/dalpha plus a per-entry gradient with respect to the entry's depth value.
+#pragma once
+#include "s360_device.h"
+
+namespace s360 {
+
+constexpr int EM_QCAP = 128;  // survivor queue slots per wave (<= 63 left over + 64 appended)
+
+#define S360_SCAN4_STEP(op, ctrl)                                                                      \
+    op " %0, %0, %0 " ctrl "\n" op " %1, %1, %1 " ctrl "\n" op " %2, %2, %2 " ctrl "\n" op " %3, %3, %3 " ctrl "\n"
+// Four independent inclusive wave64 scans (lane j <- op over lanes 0..j), interleaved so that the three other chains
+// sit between two dependent DPP operations on one register (VALU write -> DPP read needs two wait states).
+// Kogge-Stone inside the 16-lane rows (a lane whose source falls outside its row is left unchanged: bound_ctrl off,
+// destination tied to the second operand), then lane 15 -> row 1 / 3 and lane 31 -> rows 2, 3.
+#define S360_SCAN4(op, a, b, c, d)                                                        \
+    asm volatile("s_nop 1\n"                                                              \
+                 S360_SCAN4_STEP(op, "row_shr:1 row_mask:0xf bank_mask:0xf")              \
+                 S360_SCAN4_STEP(op, "row_shr:2 row_mask:0xf bank_mask:0xf")              \
+                 S360_SCAN4_STEP(op, "row_shr:4 row_mask:0xf bank_mask:0xf")              \
+                 S360_SCAN4_STEP(op, "row_shr:8 row_mask:0xf bank_mask:0xf")              \
+                 S360_SCAN4_STEP(op, "row_bcast:15 row_mask:0xa bank_mask:0xf")           \
+                 S360_SCAN4_STEP(op, "row_bcast:31 row_mask:0xc bank_mask:0xf")           \
+                 "s_nop 1\n"                                                              \
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+
+// Four wave64 shifts by one lane (lane j <- lane j-1, lane 0 <- fill): turns an inclusive scan into an exclusive one.
+__device__ __forceinline__ void wave_shr1x4(float& a, float& b, float& c, float& d, float fill) {
+    float oa = fill, ob = fill, oc = fill, od = fill;
+    asm volatile("s_nop 1\n"
+                 "v_mov_b32_dpp %0, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+                 "v_mov_b32_dpp %1, %5 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+                 "v_mov_b32_dpp %2, %6 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+                 "v_mov_b32_dpp %3, %7 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+                 : "+v"(oa), "+v"(ob), "+v"(oc), "+v"(od)
+                 : "v"(a), "v"(b), "v"(c), "v"(d));
+    a = oa; b = ob; c = oc; d = od;
+}
+
+__device__ __forceinline__ void wave_scan4_mul(float& a, float& b, float& c, float& d) { S360_SCAN4("v_mul_f32_dpp", a, b, c, d); }
+__device__ __forceinline__ void wave_scan4_add(float& a, float& b, float& c, float& d) { S360_SCAN4("v_add_f32_dpp", a, b, c, d); }
+
+// d(depth_value)/dz for the fused depth channel (s360_device.h depth_value; the "log" mode keeps the reference's
+// swapped clamp, whose result does not depend on z whenever near < far).
+__device__ __forceinline__ float depth_value_grad(float z, float nearp, float farp, int mode) {
+    if (mode == 1) return -1.0f / (z * z);
+    if (mode == 2) {
+        const float eps = 1e-10f;
+        const float disp_near = 1.0f / (nearp + eps), disp_far = 1.0f / (farp + eps), disp = 1.0f / (z + eps);
+        return (disp * disp) / (disp_near - disp_far + eps);
+    }
+    if (mode == 3) return (z < nearp && z > farp) ? 1.0f / z : 0.0f;
+    return 1.0f;
+}
+
+template <bool WITH_DEPTH>
+__global__ __launch_bounds__(64) void k_render_bwd_em(
+    KParams kp, const S360View* __restrict__ views, const uint32_t* __restrict__ tile_start,
+    const uint32_t* __restrict__ list, const uint32_t* __restrict__ offsets, const float4* __restrict__ recA,
+    const float* __restrict__ depths, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+    const float* __restrict__ dL_dimages, const float* __restrict__ dL_ddepth, float4* __restrict__ part,
+    uint8_t* __restrict__ valid, const uint32_t* __restrict__ order, int depth_mode) {
+    static_assert(SUB_W == 8, "entry-major backward assumes 8x8 quadrants");
+    __shared__ float4 s_q[EM_QCAP * 3];
+    __shared__ float4 s_pa[64];  // dL/dpixel (r, g, b, depth)
+    __shared__ float4 s_pb[64];  // T_run, R_run (behind the entries processed so far), T_final * (bg . dL/dpixel), n_contrib bits
+
+    const uint32_t unit = order ? order[blockIdx.x] : blockIdx.x;  // tile*4 + quadrant
+    const int t = (int)(unit >> 2), wave = (int)(unit & 3u), lane = threadIdx.x;
+    const int v = t / kp.T, rem = t - v * kp.T;
+    const int ty = rem / kp.gx, tx = rem - ty * kp.gx;
+    const int qx = tx * 16 + sub_ox(wave), qy = ty * 16 + sub_oy(wave);
+    const float x0 = (float)qx, ys0 = (float)qy;
+    const uint32_t start = min(tile_start[t], kp.cap);
+    const S360View& vw = views[v];
+
+    // ---- per-pixel constants (lane = pixel of the quadrant) ----
+    uint32_t last = 0;
+    {
+        const int px = qx + (lane & 7), py = qy + (lane >> 3);
+        const size_t hw = (size_t)kp.H * kp.W;
+        float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = make_float4(1.0f, 0.f, 0.f, 0.f);
+        if (px < kp.W && py < kp.H) {
+            const size_t pix = (size_t)py * kp.W + px;
+            const float T_final = final_T[(size_t)v * hw + pix];
+            last = n_contrib[(size_t)v * hw + pix];
+            const float* dimg = dL_dimages + (size_t)v * 3 * hw;
+            pa.x = dimg[pix];
+            pa.y = dimg[hw + pix];
+            pa.z = dimg[2 * hw + pix];
+            if (WITH_DEPTH) pa.w = dL_ddepth[(size_t)v * hw + pix];  // depth background is 0: no background term
+            pb.x = T_final;
+            pb.z = T_final * (vw.bg[0] * pa.x + vw.bg[1] * pa.y + vw.bg[2] * pa.z);
+        }
+        pb.w = __uint_as_float(last);
+        s_pa[lane] = pa;
+        s_pb[lane] = pb;
+    }
+    const uint32_t wave_last = wave_max_u32(last);  // entries [0, wave_last) can matter to this quadrant
+    if (wave_last == 0) return;
+    float pxc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) pxc[c] = (float)(qx + c);
+    const float inv_scale = WITH_DEPTH ? 1.0f / vw.scale : 0.f;
+    const float v_near = WITH_DEPTH ? vw.near_plane : 0.f, v_far = WITH_DEPTH ? vw.far_plane : 0.f;
+
+    // ---- one group: up to 64 queued survivors in the lanes (descending list position), loop over the 64 pixels ----
+    auto process_group = [&](uint32_t head, uint32_t n) __attribute__((always_inline)) {
+        const uint32_t idx = (head + (uint32_t)lane) & (EM_QCAP - 1);
+        const float4 qa = s_q[3 * idx], qb = s_q[3 * idx + 1], qc = s_q[3 * idx + 2];
+        const bool lane_ok = (uint32_t)lane < n;
+        const float ex = qa.x, ey = qa.y, cA = qa.z, cB = qa.w, cC = qb.x, op = qb.y, c0 = qb.z, c1 = qb.w, c2 = qc.x,
+                    zv = qc.y;
+        const uint32_t pos = lane_ok ? __float_as_uint(qc.z) : 0xFFFFFFFFu;  // list position; idle lanes never contribute
+        const uint32_t inst = __float_as_uint(qc.w);
+        // positions descend with the lane: the group's frontmost entry sits in lane n - 1
+        const uint32_t pos_min = (uint32_t)__builtin_amdgcn_readlane((int)pos, (int)n - 1);
+        float g_op = 0.f, X = 0.f, Y = 0.f, XX = 0.f, XY = 0.f, YY = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f, g_z = 0.f;
+        bool anyc = false;
+#pragma unroll 1
+        for (int row = 0; row < 8; ++row) {
+            const float pyf = (float)(qy + row);
+            const float dy = ey - pyf;
+            const float cdy2 = (cC * dy) * dy;  // shared by the row's pixels: power2() = fma(fma(b,dy,a*dx), dx, (c*dy)*dy)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int p0 = row * 8 + half * 4;
+                float4 pa[4], pb[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    pa[k] = s_pa[p0 + k];
+                    pb[k] = s_pb[p0 + k];
+                }
+                const uint32_t lmax = max(max(__float_as_uint(pb[0].w), __float_as_uint(pb[1].w)),
+                                          max(__float_as_uint(pb[2].w), __float_as_uint(pb[3].w)));
+                // none of the four pixels reaches as far back as this group's frontmost entry (wave-uniform)
+                if ((uint32_t)__builtin_amdgcn_readfirstlane((int)lmax) <= pos_min) continue;
+                float dx[4], a[4], Gm[4], om[4], Qx[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    dx[k] = ex - pxc[half * 4 + k];
+                    const float tq = __builtin_fmaf(cB, dy, cA * dx[k]);
+                    const float pw = __builtin_fmaf(tq, dx[k], cdy2);
+                    const float G = __builtin_amdgcn_exp2f(pw);
+                    const float al = fminf(0.99f, op * G);
+                    const bool act = pos < __float_as_uint(pb[k].w) && !(pw > 0.0f) && !(al < 1.0f / 255.0f);
+                    anyc = anyc || act;
+                    a[k] = act ? al : 0.0f;
+                    Gm[k] = act ? G : 0.0f;
+                    om[k] = 1.0f - a[k];
+                    Qx[k] = om[k];
+                }
+                // Qx_j = prod of (1 - alpha) over the entries strictly BEHIND j (lanes below j), Q_j includes j
+                wave_shr1x4(Qx[0], Qx[1], Qx[2], Qx[3], 1.0f);
+                wave_scan4_mul(Qx[0], Qx[1], Qx[2], Qx[3]);
+                float rc[4], Tj[4], cdp[4], w[4], S[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float Q = Qx[k] * om[k];
+                    float r = __builtin_amdgcn_rcpf(Q);
+                    r = __builtin_fmaf(__builtin_fmaf(-Q, r, 1.0f), r, r);
+                    Tj[k] = pb[k].x * r;   // transmittance in front of entry j = T behind the group / Q_j
+                    rc[k] = Qx[k] * r;     // 1 / (1 - alpha_j)
+                    float d = __builtin_fmaf(c2, pa[k].z, __builtin_fmaf(c1, pa[k].y, c0 * pa[k].x));
+                    if (WITH_DEPTH) d = __builtin_fmaf(zv, pa[k].w, d);
+                    cdp[k] = d;
+                    w[k] = a[k] * Tj[k];
+                    S[k] = w[k] * d;
+                }
+                wave_scan4_add(S[0], S[1], S[2], S[3]);  // sum over the entries at or behind j of alpha_i T_i (c_i . dL/dpixel)
+                float Sx[4] = {S[0], S[1], S[2], S[3]};
+                wave_shr1x4(Sx[0], Sx[1], Sx[2], Sx[3], 0.0f);  // ... strictly behind j
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float Rj = pb[k].y + Sx[k];  // colour (. dL/dpixel) behind entry j
+                    const float dLda = __builtin_fmaf(Tj[k], cdp[k], -((Rj + pb[k].z) * rc[k]));
+                    g_op = __builtin_fmaf(Gm[k], dLda, g_op);
+                    const float h = (op * dLda) * Gm[k];  // dL/dG * G
+                    const float hx = h * dx[k], hy = h * dy;
+                    X += hx;
+                    Y += hy;
+                    XX = __builtin_fmaf(hx, dx[k], XX);
+                    XY = __builtin_fmaf(hx, dy, XY);
+                    YY = __builtin_fmaf(hy, dy, YY);
+                    g_r = __builtin_fmaf(w[k], pa[k].x, g_r);
+                    g_g = __builtin_fmaf(w[k], pa[k].y, g_g);
+                    g_b = __builtin_fmaf(w[k], pa[k].z, g_b);
+                    if (WITH_DEPTH) g_z = __builtin_fmaf(w[k], pa[k].w, g_z);
+                }
+                if (lane == 63) {  // lane 63 sees the whole group: the pixels' running state for the next (nearer) group
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) *reinterpret_cast<float2*>(&s_pb[p0 + k]) = make_float2(Tj[k], pb[k].y + S[k]);
+                }
+            }
+        }
+        if (lane_ok && anyc && inst < kp.cap) {
+            const float ln2 = 0.6931471805599453f;
+            // dG/d(centre) = ln2 G (2 a' dx + b' dy) with the pre-scaled conic; dG/d(conic a) = -G dx^2 / 2 ...
+            float4* o = part + ((size_t)inst * 4 + wave) * 3;
+            o[0] = make_float4(ln2 * (2.0f * cA * X + cB * Y), ln2 * (2.0f * cC * Y + cB * X), -0.5f * XX, -XY);
+            o[1] = make_float4(-0.5f * YY, g_op, g_r, g_g);
+            o[2] = make_float4(g_b, g_z, 0.f, 0.f);
+            valid[(size_t)inst * 4 + wave] = 1;
+        }
+    };
+
+    // ---- walk the list back to front, 64 entries per chunk (lane l <-> list position hi - l); survivors go to the queue ----
+    uint32_t qhead = 0, qcount = 0;
+    const int64_t hi0 = (int64_t)wave_last - 1;
+    uint32_t p_n1 = 0, p_n2 = 0;
+    if (hi0 - lane >= 0) p_n1 = list[start + (uint32_t)(hi0 - lane)];
+    if (hi0 - 64 - lane >= 0) p_n2 = list[start + (uint32_t)(hi0 - 64 - lane)];
+    float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na, nc = na;
+    uint32_t nbase = 0;
+    float nz = 0.f;
+    if (hi0 - lane >= 0) {
+        na = recA[3 * (size_t)p_n1];
+        nb = recA[3 * (size_t)p_n1 + 1];
+        nc = recA[3 * (size_t)p_n1 + 2];
+        nbase = p_n1 == 0 ? 0u : offsets[p_n1 - 1];
+        if (WITH_DEPTH) nz = depths[p_n1];
+    }
+    for (int64_t hi = hi0; hi >= 0; hi -= 64) {
+        const float4 ea = na, eb = nb;
+        const float ec = nc.x, ewx = nc.z, ewy = nc.w;
+        const int erad = __float_as_int(nc.y);
+        const uint32_t ebase = nbase;
+        float ez = 0.f;
+        if (WITH_DEPTH) ez = depth_value(nz * inv_scale, v_near, v_far, depth_mode);
+        const bool ev = hi - lane >= 0;
+        p_n1 = p_n2;
+        if (hi - 64 - lane >= 0) {
+            na = recA[3 * (size_t)p_n1];
+            nb = recA[3 * (size_t)p_n1 + 1];
+            nc = recA[3 * (size_t)p_n1 + 2];
+            nbase = p_n1 == 0 ? 0u : offsets[p_n1 - 1];
+            if (WITH_DEPTH) nz = depths[p_n1];
+        }
+        if (hi - 128 - lane >= 0) p_n2 = list[start + (uint32_t)(hi - 128 - lane)];
+
+        const bool hit = ev && !(ea.x + ewx < x0 || ea.x - ewx > x0 + (float)(SUB_W - 1) || ea.y + ewy < ys0 ||
+                                 ea.y - ewy > ys0 + (float)(SUB_H - 1));
+        const unsigned long long m = __ballot(hit);
+        if (m == 0ull) continue;
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (hit) {
+            // slot of this entry: position of tile (tx,ty) inside the splat's tile rectangle, in emission order
+            int minx, miny, maxx, maxy;
+            tile_rect(ea.x, ea.y, erad, kp.gx, kp.gy, minx, miny, maxx, maxy);
+            const uint32_t einst = ebase + (uint32_t)((ty - miny) * (maxx - minx) + (tx - minx));
+            const uint32_t idx = (qhead + qcount + rank) & (EM_QCAP - 1);
+            s_q[3 * idx] = ea;
+            s_q[3 * idx + 1] = eb;
+            s_q[3 * idx + 2] = make_float4(ec, ez, __uint_as_float((uint32_t)(hi - lane)), __uint_as_float(einst));
+        }
+        qcount += (uint32_t)__popcll(m);
+        while (qcount >= 64) {
+            process_group(qhead, 64);
+            qhead = (qhead + 64) & (EM_QCAP - 1);
+            qcount -= 64;
+        }
+    }
+    if (qcount) process_group(qhead, qcount);
+}
+
+}  // namespace s360

@@ -214,17 +214,20 @@ class _RasterizeViews(torch.autograd.Function):
         ctx.state = state
         ctx.defer_sh = bool(defer_sh) and sh is not None
         ctx.has_means2D = means2D is not None
-        ctx.save_for_backward(m3, c6, op, sh, col, vw)
+        ctx.depth_mode = depth_mode if depth is not None else None
         _RasterizeViews.last_state = state
         if radii is None:
             radii = torch.empty(0, dtype=torch.int32, device=images.device)
         if depth is None:
             depth = torch.empty(0, dtype=torch.float32, device=images.device)
-        ctx.mark_non_differentiable(radii, depth, clipped_mse)
+            ctx.mark_non_differentiable(radii, depth, clipped_mse)
+        else:   # the fused depth map is differentiable (LossDepth back-propagates through it, loss_depth.py:37-60)
+            ctx.mark_non_differentiable(radii, clipped_mse)
+        ctx.save_for_backward(m3, c6, op, sh, col, vw)
         return images, radii, depth, loss, clipped_mse
 
     @staticmethod
-    def backward(ctx, grad_images, _grad_radii, _grad_depth, grad_loss, _grad_clipped):
+    def backward(ctx, grad_images, _grad_radii, grad_depth, grad_loss, _grad_clipped):
         m3, c6, op, sh, col, vw = ctx.saved_tensors
         state: RasterState = ctx.state
         prm, lay = state.prm, state.layout
@@ -237,6 +240,9 @@ class _RasterizeViews(torch.autograd.Function):
             if g is None:
                 g = torch.zeros((prm.V, 3, prm.H, prm.W), dtype=torch.float32, device=dev)
             g = g.contiguous()
+            gd, dm = None, 0
+            if grad_depth is not None and ctx.depth_mode is not None:
+                gd, dm = grad_depth.detach().float().contiguous(), DEPTH_MODES[ctx.depth_mode]
             p, v = prm.P, prm.V
             d_m3 = torch.empty((p, 3), dtype=torch.float32, device=dev)
             d_c6 = torch.empty_like(c6)
@@ -253,7 +259,8 @@ class _RasterizeViews(torch.autograd.Function):
                 d_rgb = torch.empty((p, 4), dtype=torch.float32, device=dev)
                 rc = _lib.lib().s360_backward_split(
                     C.byref(prm), _ptr(vw), _ptr(m3), _ptr(c6), _ptr(op), _ptr(sh), _ptr(state.workspace), lay.total_bytes,
-                    _ptr(g), _ptr(d_m3), _ptr(d_m2), _ptr(d_c6), _ptr(d_op), _ptr(d_rgb), _ptr(bws), lay.backward_bytes, stream)
+                    _ptr(g), _ptr(gd), dm, _ptr(d_m3), _ptr(d_m2), _ptr(d_c6), _ptr(d_op), _ptr(d_rgb),
+                    _ptr(bws), lay.backward_bytes, stream)
                 _lib.check(rc, "s360_backward_split")
                 _RasterizeViews.last_deferred = DeferredSH(prm, vw, m3, sh, d_rgb)
                 if d_m2 is not None:
@@ -261,8 +268,8 @@ class _RasterizeViews(torch.autograd.Function):
                 return d_m3, d_m2, None, None, d_op.view(-1, 1), d_c6, None, None, None
             rc = _lib.lib().s360_backward(
                 C.byref(prm), _ptr(vw), _ptr(m3), _ptr(c6), _ptr(op), _ptr(sh), _ptr(col), _ptr(state.workspace),
-                lay.total_bytes, _ptr(g), _ptr(d_m3), _ptr(d_m2), _ptr(d_c6), _ptr(d_op), _ptr(d_sh), _ptr(d_col),
-                _ptr(bws), lay.backward_bytes, stream)
+                lay.total_bytes, _ptr(g), _ptr(gd), dm, _ptr(d_m3), _ptr(d_m2), _ptr(d_c6),
+                _ptr(d_op), _ptr(d_sh), _ptr(d_col), _ptr(bws), lay.backward_bytes, stream)
             _lib.check(rc, "s360_backward")
         if d_m2 is not None:
             d_m2 = d_m2.sum(0) if v > 1 else d_m2[0]
@@ -322,7 +329,7 @@ def rasterize_views(means3D: Tensor, cov6: Tensor, opacities: Tensor, shs: Optio
     sh_channel_major: shs is [P,3,M] (the reference's Gaussians layouts, consumed without copies).
     When no input requires grad the per-pair offsets scan (backward-only state) is skipped unless
     keep_offsets=True.  depth_mode ("depth" | "disparity" | "relative_disparity" | "log"): also return the
-    fused depth map [V,H,W] of render_depth_cuda as a third result (no gradient; needs near / far in `views`).
+    fused depth map [V,H,W] of render_depth_cuda as a third result (differentiable; needs near / far in `views`).
     defer_sh=True (views sharing one camera centre): the backward skips the SH pass, returns no gradient for
     `shs` and leaves a DeferredSH (last_deferred()) for distributed.sync_gradients_factored.  Returns (images[V,3,H,W],
     radii[V,P] int32).  opacities may be [P] or [P,1]; its gradient has the same shape.

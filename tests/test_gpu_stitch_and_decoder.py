@@ -181,3 +181,35 @@ def test_fused_decoder_detects_views_with_different_camera_centres(gpu):
     forced = decoder.DecoderSplattingFused(shared_campos=True).to(gpu)(gs, ext, k, near, far, (32, 32))
     assert not torch.equal(forced.color, ref.color)                # what the unchecked flag would have produced
     assert decoder.views_share_camera_centre(ext[0, :3], near[0, :3]) and not decoder.views_share_camera_centre(ext[0, :6], near[0, :6])
+
+
+@pytest.mark.parametrize("mode", ["depth", "disparity", "relative_disparity", "log"])
+def test_fused_depth_map_is_differentiable_like_the_second_pass(gpu, mode):
+    """the reference's training step may request depth (model_wrapper_erp.py:228) and LossDepth
+    (loss_depth.py:37-60) back-propagates through it.  Gradients of (colour loss + depth loss) through the fused
+    one-pass decoder must equal those through the reference-style decoder (separate depth rasterisation with
+    colours_precomp = per-Gaussian depth value, gradient reaching the means through the einsum at cuda_splatting.py:239-242)."""
+    from types import SimpleNamespace
+    cloud = synthetic.uniform_cloud(6000, seed=31, extent=3.0, scale_range=(0.03, 0.3))
+    fw = 48
+    ext = cameras.cube_face_extrinsics(torch.tensor(synthetic.target_pano_pose((0.1, -0.1, 0.2)))[None]).to(gpu)
+    k = cameras.cube_face_intrinsics(1).to(gpu)
+    near = torch.full((1, 6), 0.1, device=gpu)
+    far = torch.full((1, 6), 10.0, device=gpu)
+    wc = torch.randn(1, 6, 3, fw, fw, device=gpu)
+    wd = torch.randn(1, 6, fw, fw, device=gpu)
+    grads = []
+    for dec in (decoder.DecoderSplattingCUDA().to(gpu), decoder.DecoderSplattingFused().to(gpu)):
+        gs = SimpleNamespace(**{key: torch.tensor(v, device=gpu)[None].requires_grad_(True) for key, v in cloud.items()})
+        out = dec(gs, ext, k, near, far, (fw, fw), depth_mode=mode)
+        ((out.color * wc).sum() + (out.depth * wd).sum()).backward()
+        grads.append({key: getattr(gs, key).grad for key in cloud})
+    for key in cloud:
+        a, b = grads[0][key], grads[1][key]
+        scale = a.abs().max().item() + 1e-20
+        assert (a - b).abs().max().item() / scale <= 2e-4, (mode, key, (a - b).abs().max().item() / scale)
+    if mode != "log":   # "log" keeps the reference's swapped clamp: its value does not depend on the Gaussian at all
+        gs = SimpleNamespace(**{key: torch.tensor(v, device=gpu)[None].requires_grad_(True) for key, v in cloud.items()})
+        out = decoder.DecoderSplattingFused().to(gpu)(gs, ext, k, near, far, (fw, fw), depth_mode=mode)
+        (out.depth * wd).sum().backward()       # depth-only loss: used to raise / give zero gradient
+        assert gs.means.grad.abs().max().item() > 0 and gs.harmonics.grad.abs().max().item() == 0
