@@ -14,9 +14,10 @@ from pathlib import Path
 _PKG = Path(__file__).resolve().parent
 _CSRC = _PKG / "csrc"
 LIB_PATH = _PKG / "libs360.so"
-SOURCES = ("s360_forward.hip", "s360_backward.hip", "s360_stitch.hip")
-HIPCC_FLAGS = ("--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-               "-Wno-unused-result")
+SOURCES = ("s360_forward.hip", "s360_backward.hip", "s360_backward_em.hip", "s360_stitch.hip")
+# per-source extra flags (s360_backward_em.hip: see the launcher comment in csrc/s360_bwd_em.h)
+SOURCE_FLAGS = {"s360_backward_em.hip": ("-fno-slp-vectorize",)}
+HIPCC_FLAGS = ("--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-unused-result")
 
 S360_MAX_VIEWS = 8
 FLAG_SHARED_CAMPOS = 1
@@ -80,13 +81,31 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     if not force and not needs_build():
         return LIB_PATH
     extra = os.environ.get("S360_HIPCC_EXTRA", "").split()
-    cmd = [_hipcc(), *HIPCC_FLAGS, *extra, *[str(_CSRC / s) for s in SOURCES], "-o", str(LIB_PATH)]
+    from concurrent.futures import ThreadPoolExecutor
+    objdir = _PKG / "build"
+    objdir.mkdir(exist_ok=True)
+
+    def compile_one(src: str):
+        obj = objdir / (src + ".o")
+        cmd = [_hipcc(), *HIPCC_FLAGS, *SOURCE_FLAGS.get(src, ()), *extra, "-c", str(_CSRC / src), "-o", str(obj)]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        return obj, cmd, r
+
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:
+        results = list(pool.map(compile_one, SOURCES))
+    for obj, cmd, r in results:
+        if verbose or r.returncode:
+            print(" ".join(cmd))
+            print(r.stdout, r.stderr)
+        if r.returncode:
+            raise RuntimeError("hipcc failed building libs360.so:\n" + r.stderr[-4000:])
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *[str(o) for o, _, _ in results], "-o", str(LIB_PATH)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or r.returncode:
         print(" ".join(cmd))
         print(r.stdout, r.stderr)
     if r.returncode:
-        raise RuntimeError("hipcc failed building libs360.so:\n" + r.stderr[-4000:])
+        raise RuntimeError("hipcc failed linking libs360.so:\n" + r.stderr[-4000:])
     return LIB_PATH
 
 

@@ -693,12 +693,9 @@ static int backward_impl(const S360Params* prm, const S360View* views, const flo
     if (legacy)
         hipLaunchKernelGGL(k_render_bwd, dim3(nt * 4), dim3(64), 0, st, kp, views, tile_start, list, offsets, recA, recB,
                            recC, final_T, n_contrib, dL_dimages, part, (uint8_t*)valid_words, ord);
-    else if (with_depth)
-        hipLaunchKernelGGL(k_render_bwd_em<true>, dim3(nt * 4), dim3(64), 0, st, kp, views, tile_start, list, offsets, recA,
-                           depths, final_T, n_contrib, dL_dimages, dL_ddepth, part, (uint8_t*)valid_words, ord, depth_mode);
     else
-        hipLaunchKernelGGL(k_render_bwd_em<false>, dim3(nt * 4), dim3(64), 0, st, kp, views, tile_start, list, offsets, recA,
-                           depths, final_T, n_contrib, dL_dimages, dL_ddepth, part, (uint8_t*)valid_words, ord, depth_mode);
+        launch_render_bwd_em(with_depth, nt * 4, st, kp, views, tile_start, list, offsets, recA, depths, final_T, n_contrib,
+                             dL_dimages, dL_ddepth, part, (uint8_t*)valid_words, ord, depth_mode);
     }
     S360_CHECK_LAUNCH();
     ProfScope ps(PS_PREPROCESS_BWD, st);

@@ -48,17 +48,30 @@ constexpr int EM_QCAP = 128;  // survivor queue slots per wave (<= 63 left over 
                  "s_nop 1\n"                                                              \
                  : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
 
-// Four wave64 shifts by one lane (lane j <- lane j-1, lane 0 <- fill): turns an inclusive scan into an exclusive one.
-__device__ __forceinline__ void wave_shr1x4(float& a, float& b, float& c, float& d, float fill) {
-    float oa = fill, ob = fill, oc = fill, od = fill;
+// Four wave64 shifts by one lane (lane j <- lane j-1, lane 0 <- 0: bound_ctrl zero-fill): turns an inclusive scan into
+// an exclusive one.
+__device__ __forceinline__ void wave_shr1x4_zero(float& a, float& b, float& c, float& d) {
+    float oa, ob, oc, od;
     asm volatile("s_nop 1\n"
-                 "v_mov_b32_dpp %0, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
-                 "v_mov_b32_dpp %1, %5 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
-                 "v_mov_b32_dpp %2, %6 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
-                 "v_mov_b32_dpp %3, %7 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
-                 : "+v"(oa), "+v"(ob), "+v"(oc), "+v"(od)
+                 "v_mov_b32_dpp %0, %4 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
+                 "v_mov_b32_dpp %1, %5 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
+                 "v_mov_b32_dpp %2, %6 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
+                 "v_mov_b32_dpp %3, %7 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
+                 : "=&v"(oa), "=&v"(ob), "=&v"(oc), "=&v"(od)
                  : "v"(a), "v"(b), "v"(c), "v"(d));
     a = oa; b = ob; c = oc; d = od;
+}
+// out_j = 1 - in_{j-1} (lane 0: 1 - 0): the shifted (1 - alpha) factors in one instruction each.
+__device__ __forceinline__ void wave_one_minus_shr1x4(float a, float b, float c, float d, float& oa, float& ob, float& oc,
+                                                      float& od) {
+    const float one = 1.0f;
+    asm volatile("s_nop 1\n"
+                 "v_subrev_f32_dpp %0, %4, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
+                 "v_subrev_f32_dpp %1, %5, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
+                 "v_subrev_f32_dpp %2, %6, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
+                 "v_subrev_f32_dpp %3, %7, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
+                 : "=&v"(oa), "=&v"(ob), "=&v"(oc), "=&v"(od)
+                 : "v"(a), "v"(b), "v"(c), "v"(d), "v"(one));
 }
 
 __device__ __forceinline__ void wave_scan4_mul(float& a, float& b, float& c, float& d) { S360_SCAN4("v_mul_f32_dpp", a, b, c, d); }
@@ -77,6 +90,7 @@ __device__ __forceinline__ float depth_value_grad(float z, float nearp, float fa
     return 1.0f;
 }
 
+#ifdef S360_EM_KERNEL_TU
 template <bool WITH_DEPTH>
 __global__ __launch_bounds__(64) void k_render_bwd_em(
     KParams kp, const S360View* __restrict__ views, const uint32_t* __restrict__ tile_start,
@@ -172,17 +186,19 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
                     a[k] = act ? al : 0.0f;
                     Gm[k] = act ? G : 0.0f;
                     om[k] = 1.0f - a[k];
-                    Qx[k] = om[k];
                 }
                 // Qx_j = prod of (1 - alpha) over the entries strictly BEHIND j (lanes below j), Q_j includes j
-                wave_shr1x4(Qx[0], Qx[1], Qx[2], Qx[3], 1.0f);
+                wave_one_minus_shr1x4(a[0], a[1], a[2], a[3], Qx[0], Qx[1], Qx[2], Qx[3]);
                 wave_scan4_mul(Qx[0], Qx[1], Qx[2], Qx[3]);
                 float rc[4], Tj[4], cdp[4], w[4], S[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float Q = Qx[k] * om[k];
                     float r = __builtin_amdgcn_rcpf(Q);
-                    r = __builtin_fmaf(__builtin_fmaf(-Q, r, 1.0f), r, r);
+                    r = __builtin_fmaf(__builtin_fmaf(-Q, r, 1.0f), r, r);  // Newton step: dL/dalpha below is a difference of two
+                                                                             // nearly equal terms whenever an entry's colour is close to
+                                                                             // the colour behind it; without it the fuzz suite measures
+                                                                             // 2.7x the float32 oracle's distance from the float64 one
                     Tj[k] = pb[k].x * r;   // transmittance in front of entry j = T behind the group / Q_j
                     rc[k] = Qx[k] * r;     // 1 / (1 - alpha_j)
                     float d = __builtin_fmaf(c2, pa[k].z, __builtin_fmaf(c1, pa[k].y, c0 * pa[k].x));
@@ -193,7 +209,7 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
                 }
                 wave_scan4_add(S[0], S[1], S[2], S[3]);  // sum over the entries at or behind j of alpha_i T_i (c_i . dL/dpixel)
                 float Sx[4] = {S[0], S[1], S[2], S[3]};
-                wave_shr1x4(Sx[0], Sx[1], Sx[2], Sx[3], 0.0f);  // ... strictly behind j
+                wave_shr1x4_zero(Sx[0], Sx[1], Sx[2], Sx[3]);  // ... strictly behind j
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float Rj = pb[k].y + Sx[k];  // colour (. dL/dpixel) behind entry j
@@ -286,5 +302,14 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
     }
     if (qcount) process_group(qhead, qcount);
 }
+#endif  // S360_EM_KERNEL_TU
+
+// Launcher (this kernel lives in its own translation unit, s360_backward_em.hip, which is compiled with
+// -fno-slp-vectorize: the SLP vectoriser packs pairs of the four pixel chains into v_pk_* instructions but pays for it
+// with 23 register moves per half row and 14 more VGPRs — 138 instead of 125, i.e. 3 instead of 4 waves per SIMD).
+void launch_render_bwd_em(bool with_depth, int n_units, hipStream_t st, const KParams& kp, const S360View* views,
+                          const uint32_t* tile_start, const uint32_t* list, const uint32_t* offsets, const float4* recA,
+                          const float* depths, const float* final_T, const uint32_t* n_contrib, const float* dL_dimages,
+                          const float* dL_ddepth, float4* part, uint8_t* valid, const uint32_t* order, int depth_mode);
 
 }  // namespace s360
