@@ -113,7 +113,6 @@ def main():
     bg = torch.zeros(3, device=dev)
     gt = torch.full((6, 3, face_w, face_w), 0.5, device=dev)
     c2e = stitch.Cube2Equirec(face_w, 2 * face_w, 4 * face_w).to(dev)   # target ERP = (2 fw) x (4 fw)
-    cams = decoder.CameraPrefetcher(dev)
     out = {}
 
     eval_poses = [decoder.cube_cameras(torch.tensor(synthetic.target_pano_pose((0.1 * i, 0.0, -0.05 * i)), device=dev), 0.1, 10.0)
@@ -123,14 +122,14 @@ def main():
         # evaluation_index_replica.json: 3 target views per scene -> 18 faces, colour + depth (test_step :336-345)
         for (e, k, n, f) in eval_poses:
             col, dep = decoder.render_views_fused(e, k, n, f, (face_w, face_w), bg, *params, check="lazy", shared_campos=True, depth_mode="depth",
-                                                  views=cams.pack(e, k, n, f, bg))
+                                                  views=decoder.pack_camera_views(e, k, n, f, bg))
             out["erp"] = c2e.stitch_rendered(col)
             out["faces"] = col
 
     def step_train():
         for p in params:
             p.grad = None
-        views = cams.pack(ext, K, near, far, bg)  # camera glue of this step, overlapped on a side stream
+        views = decoder.pack_camera_views(ext, K, near, far, bg)  # camera glue of this step: one kernel (s360_pack_views)
         if a.mode == "fwdbwd" and a.fused_loss:   # LossMse fused into the composite store
             faces, fm = decoder.render_views_fused(ext, K, near, far, (face_w, face_w), bg, *params, check="lazy", shared_campos=True, views=views,
                                                    defer_sh=factored, mse_target=gt)

@@ -217,6 +217,20 @@ int s360_sh_backward(const S360Params* prm, int32_t n_groups, const S360View* vi
                      float* d_means3D_inout, float* d_shs, void* stream);
 
 /*
+ * Camera records of a call in one launch: replaces the reference's per-call camera glue
+ * (cuda_splatting.py:64-71 scale-invariant rescale, :80-84 get_fov / get_projection_matrix, :85-87 the two
+ * transposed matrices; src/geometry/projection.py:233-247) — ~60 tiny torch / rocSOLVER launches for six cameras.
+ *   extrinsics[N,4,4] camera-to-world (OpenCV), intrinsics[N,3,3] normalised, near / far[N],
+ *   background[3] (background_per_view = 0) or [N,3] (1), scale_invariant as in render_cuda.
+ *   views_out[N]: S360View records (near_plane / far_plane = the UNSCALED planes).
+ * Same formulas in the same order as the reference; the two matrix inverses are Gauss-Jordan eliminations
+ * with partial pivoting, so the records agree with the torch glue to a few ulp, not bit for bit.
+ */
+int s360_pack_views(const float* extrinsics, const float* intrinsics, const float* near_planes,
+                    const float* far_planes, const float* background, int32_t background_per_view,
+                    int32_t n_views, int32_t scale_invariant, S360View* views_out, void* stream);
+
+/*
  * Cube -> equirectangular stitch: replaces Cube2Equirec.forward
  * (/root/reference/src/geometry/layers.py:108-116, F.grid_sample trilinear / border /
  * align_corners=True over the [C,6,fw,fw] face stack).

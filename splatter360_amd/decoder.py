@@ -167,21 +167,32 @@ def cube_cameras(pano_c2w: Tensor, near, far):
     return ext, k, n, f
 
 
-def pack_camera_views(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, background: Tensor,
-                      scale_invariant: bool = True) -> Tensor:
-    """V cameras (extrinsics[V,4,4] c2w, normalised intrinsics[V,3,3], near/far[V], background [3] or
-    [V,3]) -> views[V,44] for one rasteriser call: the camera half of render_cuda
-    (cuda_splatting.py:64-71,80-87) for all V views at once; the cloud half of the scale-invariant
-    rescale happens inside the kernels (S360View.scale).  Device math only, no host sync."""
+def pack_camera_views_torch(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, background: Tensor,
+                            scale_invariant: bool = True) -> Tensor:
+    """The reference's camera glue as torch ops (cameras.view_setup: two LU inverses, fov, projection, one bmm —
+    ~60 tiny launches for six cameras), packed into views[V,44].  This is what the drop-in render_cuda uses and
+    what the golden captures pin on CPU; the fused path uses the one-kernel form below."""
     vs = cameras.view_setup(extrinsics, intrinsics, near, far, scale_invariant)
     return rasterizer.pack_views(vs["view_matrix"], vs["full_projection"], vs["campos"], vs["tan_fov_x"],
                                  vs["tan_fov_y"], background, scale=vs["scale"], near=near, far=far)
 
 
+def pack_camera_views(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, background: Tensor,
+                      scale_invariant: bool = True, glue: str = "native") -> Tensor:
+    """V cameras (extrinsics[V,4,4] c2w, normalised intrinsics[V,3,3], near/far[V], background [3] or
+    [V,3]) -> views[V,44] for one rasteriser call: the camera half of render_cuda
+    (cuda_splatting.py:64-71,80-87) for all V views at once; the cloud half of the scale-invariant
+    rescale happens inside the kernels (S360View.scale).  glue="native": ONE kernel launch (s360_pack_views);
+    glue="torch": the reference's own torch ops (a few ulp apart: LU vs Gauss-Jordan inverses).  No host sync."""
+    if glue == "torch":
+        return pack_camera_views_torch(extrinsics, intrinsics, near, far, background, scale_invariant)
+    return rasterizer.pack_views_native(extrinsics, intrinsics, near, far, background, scale_invariant)
+
+
 def render_views_fused(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, image_shape: tuple,
                        background: Tensor, gaussian_means: Tensor, gaussian_covariances: Tensor,
                        gaussian_sh_coefficients: Tensor, gaussian_opacities: Tensor, *, shared_campos: Optional[bool] = None,
-                       max_instances: Optional[int] = None, check: str = "sync", views: Optional[Tensor] = None,
+                       max_instances: Optional[int] = None, check: str = "sync", views: Optional[Tensor] = None, glue: str = "native",
                        depth_mode: Optional[DepthRenderingMode] = None, defer_sh: bool = False,
                        mse_target: Optional[Tensor] = None, mse_weight: float = 1.0, mse_count: Optional[int] = None):
     """V <= 8 views of ONE cloud in one fused rasteriser call: means[G,3], covariances[G,3,3],
@@ -198,8 +209,8 @@ def render_views_fused(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far
     rasterises every face a second time for them, decoder_splatting_cuda.py:72-97).
     With mse_target[V,3,h,w] (the supervising cube faces) the L2 loss / PSNR epilogue is fused into the render
     (rasterizer.FusedMse appended as the last result)."""
-    if views is None:  # callers may pass pre-packed views (e.g. prepared on a side stream, see CameraPrefetcher)
-        views = pack_camera_views(extrinsics, intrinsics, near, far, background)
+    if views is None:  # callers may pass pre-packed views
+        views = pack_camera_views(extrinsics, intrinsics, near, far, background, glue=glue)
     if shared_campos is None:
         shared_campos = views_share_camera_centre(extrinsics, near)
     n = gaussian_sh_coefficients.shape[-1]
@@ -228,73 +239,26 @@ def views_share_camera_centre(extrinsics: Tensor, near: Tensor) -> bool:
 
 
 class CameraPrefetcher:
-    """Packs the V camera records of the NEXT rasteriser call on a side stream.  The ~60 tiny torch
-    kernels of the camera glue (inverse, fov, projection, matmul: O(V) work, independent of the cloud)
-    then overlap with the previous call's heavy kernels instead of serialising in front of them; the
-    main stream only waits on an event.  Results are identical to pack_camera_views."""
+    """Round-1 helper kept for its interface: it used to replay the ~60-launch torch camera glue as a captured HIP
+    graph on a side stream.  With s360_pack_views the glue is one 5-us kernel on the current stream, so there is
+    nothing left to prefetch: pack() simply calls pack_camera_views (no side stream, no graph, no process-wide state)."""
 
-    def __init__(self, device, use_graph: bool = True):
-        """use_graph: replay the glue as ONE captured HIP graph per call instead of ~60 eager launches.  The
-        kernels and therefore the results are the same; what disappears is ~0.7 ms of host-side launch cost per
-        call, which otherwise makes a forward-only step (0.6 ms of GPU work at 1 M Gaussians) host-bound."""
-        self.stream = torch.cuda.Stream(device=device)
-        self.event = torch.cuda.Event()
-        self.use_graph = use_graph
-        self._graphs: dict = {}
-
-    def _capture(self, key, args):
-        static_in = [torch.empty(tuple(a.shape), dtype=torch.float32, device=self.stream.device) for a in args]
-        with torch.cuda.stream(self.stream):
-            torch._foreach_copy_(static_in, [a.detach() for a in args])
-            for _ in range(2):      # warm-up: library handles, cached constants, allocator pools
-                pack_camera_views(*static_in)
-        self.stream.synchronize()
-        try:
-            graph = torch.cuda.CUDAGraph()
-            # thread_local: other threads' HIP calls (RCCL watchdog, pin-memory workers) must not abort the capture
-            with torch.cuda.graph(graph, stream=self.stream, capture_error_mode="thread_local"):
-                out = pack_camera_views(*static_in)
-            entry = (graph, static_in, out)
-        except Exception as e:  # capture not possible in this environment: eager side-stream path still works
-            import warnings
-            warnings.warn(f"CameraPrefetcher: HIP graph capture failed ({e!r}); using eager launches")
-            entry = None
-        self._graphs[key] = entry
-        return entry
+    def __init__(self, device=None, use_graph: bool = False, glue: str = "native"):
+        self.glue = glue
 
     def pack(self, extrinsics, intrinsics, near, far, background, inputs_ready: bool = True) -> Tensor:
-        """inputs_ready=True: the camera tensors come from the data loader / an earlier step and are
-        already materialised (the normal case: poses do not depend on the model).  Pass False when they
-        were just produced on the current stream; the side stream then waits for it (no overlap)."""
-        args = (extrinsics, intrinsics, near, far, background)
-        entry = None
-        if self.use_graph:
-            key = tuple(tuple(a.shape) for a in args)
-            entry = self._graphs[key] if key in self._graphs else self._capture(key, args)
-        if not inputs_ready:
-            self.stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.stream):
-            if entry is not None:
-                graph, static_in, out = entry
-                torch._foreach_copy_(static_in, [a.detach() for a in args])
-                graph.replay()
-                views = out.clone()     # the static output is overwritten by the next replay
-            else:
-                views = pack_camera_views(*args)
-            self.event.record(self.stream)
-        torch.cuda.current_stream().wait_event(self.event)
-        views.record_stream(torch.cuda.current_stream())
-        return views
+        return pack_camera_views(extrinsics, intrinsics, near, far, background, glue=self.glue)
 
 
 def render_cube_faces(pano_c2w: Tensor, near: Tensor, far: Tensor, face_w: int, background: Tensor,
                       gaussian_means: Tensor, gaussian_covariances: Tensor, gaussian_sh_coefficients: Tensor,
-                      gaussian_opacities: Tensor, *, max_instances: Optional[int] = None, check: str = "sync") -> Tensor:
+                      gaussian_opacities: Tensor, *, max_instances: Optional[int] = None, check: str = "sync",
+                      glue: str = "native") -> Tensor:
     """Convenience: panorama pose -> faces[6,3,fw,fw] in the reference's rendered order (top, front,
     left, back, right, bottom)."""
     ext, k, n, f = cube_cameras(pano_c2w, near, far)
     return render_views_fused(ext, k, n, f, (face_w, face_w), background, gaussian_means, gaussian_covariances,
-                              gaussian_sh_coefficients, gaussian_opacities, max_instances=max_instances, check=check,
+                              gaussian_sh_coefficients, gaussian_opacities, max_instances=max_instances, check=check, glue=glue,
                               shared_campos=True)   # six faces of one panorama: one camera centre by construction
 
 
@@ -310,7 +274,7 @@ class DecoderSplattingFused(torch.nn.Module):
     which share a camera centre) in single rasteriser calls, colour and depth together."""
 
     def __init__(self, background_color=(0.0, 0.0, 0.0), views_per_group: int = 6, shared_campos: Optional[bool] = None,
-                 cameras_ready: bool = False, use_graph: bool = True, check: str = "sync"):
+                 cameras_ready: bool = False, use_graph: bool = False, check: str = "sync", glue: str = "native"):
         """shared_campos: None (default) = checked per group of views, with ONE small device->host read per
         forward() call (groups whose views do not share a camera centre and near plane are rendered with per-view
         SH evaluation instead of silently taking the first view's direction); True / False = trust the caller.
@@ -320,19 +284,11 @@ class DecoderSplattingFused(torch.nn.Module):
         super().__init__()
         self.register_buffer("background_color", torch.tensor(background_color, dtype=torch.float32), persistent=False)
         self.views_per_group, self.shared_campos = views_per_group, shared_campos
-        self.cameras_ready, self.use_graph, self.check = cameras_ready, use_graph, check
-        self._cams: dict = {}
-
-    def _prefetcher(self, device) -> "CameraPrefetcher":
-        c = self._cams.get(device)
-        if c is None:
-            c = self._cams[device] = CameraPrefetcher(device, use_graph=self.use_graph)
-        return c
+        self.check, self.glue = check, glue   # cameras_ready / use_graph: accepted for compatibility, unused
 
     def forward(self, gaussians, extrinsics, intrinsics, near, far, image_shape, depth_mode=None) -> "DecoderOutput":
         b, v = extrinsics.shape[:2]
         colors, depths = [], []
-        cams = self._prefetcher(extrinsics.device)
         groups = [(i, slice(s, min(v, s + self.views_per_group))) for i in range(b) for s in range(0, v, self.views_per_group)]
         if self.shared_campos is None:   # one comparison kernel chain + one read for all groups of the call
             first = (torch.arange(v, device=extrinsics.device) // self.views_per_group) * self.views_per_group
@@ -341,9 +297,11 @@ class DecoderSplattingFused(torch.nn.Module):
             shared = {(i, e.start): bool(same[i, e].all()) for i, e in groups}
         else:
             shared = {(i, e.start): bool(self.shared_campos) for i, e in groups}
-        # all camera records up front (one graph replay each), so the rasteriser calls queue back to back
-        packed = {(i, e.start): cams.pack(extrinsics[i, e], intrinsics[i, e], near[i, e], far[i, e], self.background_color,
-                                          inputs_ready=self.cameras_ready) for i, e in groups}
+        # all camera records of the call in ONE launch
+        bgv = self.background_color
+        allv = pack_camera_views(extrinsics.reshape(b * v, 4, 4), intrinsics.reshape(b * v, 3, 3), near.reshape(-1),
+                                 far.reshape(-1), bgv, glue=self.glue).view(b, v, -1)
+        packed = {(i, e.start): allv[i, e] for i, e in groups}
         for i in range(b):
             cs, ds = [], []
             for s in range(0, v, self.views_per_group):

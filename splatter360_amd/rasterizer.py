@@ -65,6 +65,30 @@ def pack_views(viewmatrix: Tensor, projmatrix: Tensor, campos: Tensor, tanfovx, 
                      dim=1).contiguous()
 
 
+def pack_views_native(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, background: Tensor,
+                      scale_invariant: bool = True) -> Tensor:
+    """s360_pack_views: N cameras -> views[N,44] in one kernel launch on the current stream (no host sync)."""
+    ext = _f32c(extrinsics, "extrinsics").reshape(-1, 4, 4)
+    n = int(ext.shape[0])
+    dev = ext.device
+    k = _f32c(intrinsics, "intrinsics").reshape(-1, 3, 3)
+    nr = _f32c(near, "near").reshape(-1).expand(n).contiguous()
+    fr = _f32c(far, "far").reshape(-1).expand(n).contiguous()
+    bg = background.detach().float().to(dev).contiguous()
+    per_view = bg.dim() == 2 and int(bg.shape[0]) == n
+    if not per_view and bg.numel() != 3:
+        raise RuntimeError(f"background must be [3] or [{n},3], got {tuple(bg.shape)}")
+    if int(k.shape[0]) != n:
+        raise RuntimeError("extrinsics / intrinsics view counts differ")
+    out = torch.empty((n, VIEW_FLOATS), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        rc = _lib.lib().s360_pack_views(_ptr(ext), _ptr(k), _ptr(nr), _ptr(fr), _ptr(bg), int(bool(per_view)), n,
+                                        int(bool(scale_invariant)), _ptr(out), stream)
+    _lib.check(rc, "s360_pack_views")
+    return out
+
+
 def default_capacity(p: int, v: int) -> int:
     """Initial capacity (instances = (Gaussian, tile) pairs) of the binning buffers."""
     return int(min(2**32 - 1, max(1 << 16, (3 * p * v) // 2 + (1 << 18))))

@@ -20,6 +20,16 @@ def face_settings(face: int, h: int, w: int, near=0.1, far=10.0, position=(0.0, 
                 sh_degree=4, campos=vs["campos"][0].numpy(), scale=float(vs["scale"][0]))
 
 
+def settings_from_views(views, i: int, h: int, w: int, sh_degree: int = 4):
+    """The same GaussianRasterizationSettings fields, read back from row i of a packed S360View tensor [V,44] — so
+    that the oracle sees bit-identical camera records to the HIP path whichever glue (torch ops or the one-kernel
+    s360_pack_views) produced them."""
+    r = views[i].detach().cpu().numpy().astype(np.float32)
+    return dict(image_height=h, image_width=w, tanfovx=float(r[35]), tanfovy=float(r[36]), bg=r[37:40].copy(),
+                viewmatrix=r[0:16].reshape(4, 4).copy(), projmatrix=r[16:32].reshape(4, 4).copy(), sh_degree=sh_degree,
+                campos=r[32:35].copy(), scale=float(r[40]))
+
+
 def boundary_tensors(cloud: dict, scale: float):
     """means3D, cov6, shs[G,n,3], opacities[G,1] exactly as render_cuda hands them over
     (cuda_splatting.py:68-75,115-123)."""

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import boundary_tensors, face_settings
+from helpers import boundary_tensors, face_settings, settings_from_views
 from oracle import oracle
 from splatter360_amd import cameras, decoder, rasterizer, stitch, synthetic
 
@@ -79,8 +79,9 @@ def test_fullsize_pixels_match_oracle_on_one_face(gpu, big):
     """Face 2 of the 1M cloud against the CPU oracle (the oracle only needs the Gaussians that can
     reach the face; it culls the rest itself)."""
     cloud, params, (ext, K, near, far) = big
-    faces = decoder.render_views_fused(ext, K, near, far, (256, 256), torch.zeros(3, device=gpu), *params)
-    S = face_settings(2, 256, 256)
+    views = decoder.pack_camera_views(ext, K, near, far, torch.zeros(3, device=gpu))
+    faces = decoder.render_views_fused(ext, K, near, far, (256, 256), torch.zeros(3, device=gpu), *params, views=views)
+    S = settings_from_views(views, 2, 256, 256)
     means, cov6, shs, opac = boundary_tensors(cloud, S["scale"])
     f = oracle.rasterize(S, means3D=means, cov3D_precomp=cov6, opacities=opac, shs=shs).forward()
     st = rasterizer.last_state().tensors()

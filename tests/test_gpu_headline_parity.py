@@ -18,7 +18,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import boundary_tensors, face_settings
+from helpers import boundary_tensors, face_settings, settings_from_views
 from oracle import oracle
 from splatter360_amd import cameras, decoder, rasterizer, synthetic
 
@@ -104,9 +104,11 @@ def _single_face_call(params, face, fw, dev, grad_image=None, position=(0.0, 0.0
     pose = torch.tensor(synthetic.target_pano_pose(position), device=dev)
     ext, K, near, far = decoder.cube_cameras(pose, 0.1, 10.0)
     s = slice(face, face + 1)
+    views = decoder.pack_camera_views(ext[s], K[s], near[s], far[s], torch.zeros(3, device=dev))
     out = decoder.render_views_fused(ext[s], K[s], near[s], far[s], (fw, fw), torch.zeros(3, device=dev), *ps,
-                                     depth_mode=depth_mode)
+                                     depth_mode=depth_mode, views=views)
     st = rasterizer.last_state()
+    st.views = views      # the camera records the kernels saw: the oracle is given exactly these
     if grad_image is not None:
         (out if depth_mode is None else out[0]).backward(torch.tensor(grad_image, device=dev)[None])
     return out, st, ps
@@ -114,12 +116,13 @@ def _single_face_call(params, face, fw, dev, grad_image=None, position=(0.0, 0.0
 
 def test_1m_all_six_faces_forward_vs_oracle(gpu, cloud1m, params1m):
     ext, K, near, far = decoder.cube_cameras(torch.eye(4, device=gpu), 0.1, 10.0)
-    faces = decoder.render_views_fused(ext, K, near, far, (256, 256), torch.zeros(3, device=gpu), *params1m)
+    views = decoder.pack_camera_views(ext, K, near, far, torch.zeros(3, device=gpu))
+    faces = decoder.render_views_fused(ext, K, near, far, (256, 256), torch.zeros(3, device=gpu), *params1m, views=views)
     t = rasterizer.last_state().tensors()
     faces = faces.cpu().numpy()
     P = cloud1m["means"].shape[0]
     for face in range(6):
-        S = face_settings(face, 256, 256)
+        S = settings_from_views(views, face, 256, 256)
         means, cov6, shs, opac = boundary_tensors(cloud1m, S["scale"])
         f = oracle.rasterize(S, means3D=means, cov3D_precomp=cov6, opacities=opac, shs=shs).forward()
         _check_face_forward(_face_state(t, face, P, 256), faces[face], f, f"1m_face{face}_fwd", 256)
@@ -130,7 +133,7 @@ def test_1m_backward_vs_oracle(gpu, cloud1m, params1m, face):
     rng = np.random.default_rng(100 + face)
     gimg = rng.standard_normal((3, 256, 256)).astype(np.float32)
     out, st, ps = _single_face_call(params1m, face, 256, gpu, grad_image=gimg)
-    S = face_settings(face, 256, 256)
+    S = settings_from_views(st.views, 0, 256, 256)
     means, cov6, shs, opac = boundary_tensors(cloud1m, S["scale"])
     o32 = oracle.rasterize(S, means3D=means, cov3D_precomp=cov6, opacities=opac, shs=shs)
     o32.forward()
@@ -158,14 +161,15 @@ def test_1m_fused_six_face_gradient_equals_sum_of_oracle_backwards(gpu, cloud1m,
     float64 oracle backwards seeded with the same per-face pixel gradients."""
     ps = [p.clone().requires_grad_(True) for p in params1m]
     ext, K, near, far = decoder.cube_cameras(torch.eye(4, device=gpu), 0.1, 10.0)
-    faces = decoder.render_views_fused(ext, K, near, far, (256, 256), torch.zeros(3, device=gpu), *ps)
+    views = decoder.pack_camera_views(ext, K, near, far, torch.zeros(3, device=gpu))
+    faces = decoder.render_views_fused(ext, K, near, far, (256, 256), torch.zeros(3, device=gpu), *ps, views=views)
     gt = torch.full_like(faces, 0.5)
     ((faces - gt) ** 2).mean().backward()
     seed = (2.0 / faces.numel() * (faces.detach() - gt)).cpu().numpy()
     P = cloud1m["means"].shape[0]
     tot = dict(means3D=np.zeros((P, 3)), cov3D=np.zeros((P, 6)), shs=np.zeros((P, 25, 3)), opacities=np.zeros((P, 1)))
     for face in range(6):
-        S = face_settings(face, 256, 256)
+        S = settings_from_views(views, face, 256, 256)
         means, cov6, shs, opac = boundary_tensors(cloud1m, S["scale"])
         o = oracle.rasterize(S, means3D=means, cov3D_precomp=cov6, opacities=opac, shs=shs, dtype=np.float64)
         o.forward()
@@ -196,7 +200,7 @@ def test_4m_512_face_forward_backward_vs_oracle(gpu):
     gimg = rng.standard_normal((3, 512, 512)).astype(np.float32)
     out, st, ps = _single_face_call(params, face, 512, gpu, grad_image=gimg)
     assert not st.overflowed()
-    S = face_settings(face, 512, 512)
+    S = settings_from_views(st.views, 0, 512, 512)
     means, cov6, shs, opac = boundary_tensors(cloud, S["scale"])
     o = oracle.rasterize(S, means3D=means, cov3D_precomp=cov6, opacities=opac, shs=shs)
     f = o.forward()
@@ -226,13 +230,14 @@ def test_eval_shape_colour_and_depth_vs_oracle(gpu, cloud1m, params1m, mode):
     for pos in positions:
         pose = torch.tensor(synthetic.target_pano_pose(pos), device=gpu)
         ext, K, near, far = decoder.cube_cameras(pose, 0.1, 10.0)
+        views = decoder.pack_camera_views(ext, K, near, far, torch.zeros(3, device=gpu))
         col, dep = decoder.render_views_fused(ext, K, near, far, (256, 256), torch.zeros(3, device=gpu), *params1m,
-                                              depth_mode=mode)
+                                              depth_mode=mode, views=views)
         assert col.shape == (6, 3, 256, 256) and dep.shape == (6, 256, 256)
-        outs.append((col, dep, ext, near, far))
+        outs.append((col, dep, ext, near, far, views))
     pi, face = pick
-    col, dep, ext, near, far = outs[pi]
-    S = face_settings(face, 256, 256, position=positions[pi])
+    col, dep, ext, near, far, views = outs[pi]
+    S = settings_from_views(views, face, 256, 256)
     means, cov6, shs, opac = boundary_tensors(cloud1m, S["scale"])
     f = oracle.rasterize(S, means3D=means, cov3D_precomp=cov6, opacities=opac, shs=shs).forward()
     st = _pixel_stats(col[face].cpu().numpy(), f["image"])

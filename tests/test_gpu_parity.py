@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import boundary_tensors, face_settings, small_front_scene
+from helpers import boundary_tensors, face_settings, settings_from_views, small_front_scene
 from oracle import oracle
 from splatter360_amd import rasterizer, synthetic
 
@@ -145,7 +145,7 @@ def test_fused_cube6_equals_six_dropin_calls(gpu):
     gimg = torch.tensor(rng.standard_normal((6, 3, fw, fw)).astype(np.float32), device=gpu)
 
     ins_f = _cloud_tensors(cloud, gpu, True)
-    faces = decoder.render_cube_faces(pose, near, far, fw, bg, *ins_f)
+    faces = decoder.render_cube_faces(pose, near, far, fw, bg, *ins_f, glue="torch")   # same camera records as the drop-in calls
     faces.backward(gimg)
 
     ins_d = _cloud_tensors(cloud, gpu, True)
@@ -173,9 +173,11 @@ def test_fused_cube6_vs_oracle(gpu):
     pose = torch.tensor(synthetic.target_pano_pose(), device=gpu)
     near, far = torch.tensor(0.1, device=gpu), torch.tensor(10.0, device=gpu)
     bg = torch.zeros(3, device=gpu)
-    faces = decoder.render_cube_faces(pose, near, far, fw, bg, *_cloud_tensors(cloud, gpu)).cpu().numpy()
+    ext, K, nr, fr = decoder.cube_cameras(pose, near, far)
+    views = decoder.pack_camera_views(ext, K, nr, fr, bg)
+    faces = decoder.render_views_fused(ext, K, nr, fr, (fw, fw), bg, *_cloud_tensors(cloud, gpu), views=views, shared_campos=True).cpu().numpy()
     for face in range(6):
-        S = face_settings(face, fw, fw)
+        S = settings_from_views(views, face, fw, fw)
         means, cov6, shs, opac = boundary_tensors(cloud, S["scale"])
         f = oracle.rasterize(S, means3D=means, cov3D_precomp=cov6, opacities=opac, shs=shs).forward()
         assert np.abs(faces[face] - f["image"]).mean() <= 1e-5

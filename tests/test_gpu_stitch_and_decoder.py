@@ -83,7 +83,7 @@ def test_decoder_module_forward_shapes_and_values(gpu):
     out = dec(gs, ext, k, near, far, (fw, fw), depth_mode="depth")
     assert out.color.shape == (1, 6, 3, fw, fw) and out.depth.shape == (1, 6, fw, fw)
     fused = decoder.render_views_fused(ext[0], k[0], near[0], far[0], (fw, fw), torch.zeros(3, device=gpu), gs.means[0],
-                                       gs.covariances[0], gs.harmonics[0], gs.opacities[0])
+                                       gs.covariances[0], gs.harmonics[0], gs.opacities[0], glue="torch")
     assert torch.equal(out.color[0], fused)
 
 
@@ -122,33 +122,17 @@ def test_fused_depth_equals_second_pass_depth_render(gpu, mode):
     near = torch.full((1, 6), 0.1, device=gpu)
     far = torch.full((1, 6), 10.0, device=gpu)
     ref = decoder.DecoderSplattingCUDA().to(gpu)(gs, ext, k, near, far, (fw, fw), depth_mode=mode)
-    fused = decoder.DecoderSplattingFused().to(gpu)(gs, ext, k, near, far, (fw, fw), depth_mode=mode)
+    fused = decoder.DecoderSplattingFused(glue="torch").to(gpu)(gs, ext, k, near, far, (fw, fw), depth_mode=mode)
     assert torch.equal(fused.color, ref.color)
     scale = ref.depth.abs().max().item() + 1e-12
     assert (fused.depth - ref.depth).abs().max().item() <= 2e-5 * scale
     assert (fused.depth - ref.depth).abs().mean().item() <= 2e-6 * scale
 
 
-def test_camera_prefetcher_graph_replay_is_bit_equal_to_eager_glue(gpu):
-    """CameraPrefetcher (one captured HIP graph per call shape, side stream) == pack_camera_views for a
-    sequence of different cameras, batched 18-view decoder shape included."""
-    cams = decoder.CameraPrefetcher(gpu)
-    eager = decoder.CameraPrefetcher(gpu, use_graph=False)
-    bg3 = torch.tensor([0.2, 0.4, 0.6], device=gpu)
-    bgv = torch.rand(6, 3, device=gpu)
-    outs = []
-    for i in range(5):
-        pose = torch.tensor(synthetic.target_pano_pose((0.1 * i, -0.05 * i, 0.02 * i)), device=gpu)
-        ext, K, near, far = decoder.cube_cameras(pose, 0.1 + 0.01 * i, 10.0 + i)
-        bg = bg3 if i % 2 == 0 else bgv
-        want = decoder.pack_camera_views(ext, K, near, far, bg)
-        got = cams.pack(ext, K, near, far, bg, inputs_ready=False)
-        outs.append((got, want))
-        assert torch.equal(eager.pack(ext, K, near, far, bg, inputs_ready=False), want)
-    for got, want in outs:            # earlier results stay valid after later replays
-        assert torch.equal(got, want)
-    assert all(e is not None for e in cams._graphs.values()), "HIP graph capture fell back to eager"
-    # 3 panoramas x 6 faces through the decoder module (eval shape), twice (second call = pure replays)
+def test_fused_decoder_eval_shape_equals_dropin_decoder(gpu):
+    """3 panoramas x 6 faces through the decoder modules (evaluation shape): with the reference's torch camera glue the
+    fused decoder is bit-identical to the per-face drop-in decoder; with the one-kernel native glue (default) the camera
+    records differ by a few ulp (Gauss-Jordan vs LU inverses), the images by <= 1e-6."""
     from types import SimpleNamespace
     cloud = synthetic.uniform_cloud(4000, seed=5, extent=3.0, scale_range=(0.02, 0.3))
     gs = SimpleNamespace(**{k: torch.tensor(v, device=gpu)[None] for k, v in cloud.items()})
@@ -158,9 +142,9 @@ def test_camera_prefetcher_graph_replay_is_bit_equal_to_eager_glue(gpu):
     near = torch.full((1, 18), 0.1, device=gpu)
     far = torch.full((1, 18), 10.0, device=gpu)
     ref = decoder.DecoderSplattingCUDA().to(gpu)(gs, ext, k, near, far, (32, 32))
-    dec = decoder.DecoderSplattingFused().to(gpu)
-    for _ in range(2):
-        assert torch.equal(dec(gs, ext, k, near, far, (32, 32)).color, ref.color)
+    assert torch.equal(decoder.DecoderSplattingFused(glue="torch").to(gpu)(gs, ext, k, near, far, (32, 32)).color, ref.color)
+    nat = decoder.DecoderSplattingFused().to(gpu)(gs, ext, k, near, far, (32, 32)).color
+    assert (nat - ref.color).abs().max().item() <= 1e-6
 
 
 def test_fused_decoder_detects_views_with_different_camera_centres(gpu):
@@ -176,9 +160,9 @@ def test_fused_decoder_detects_views_with_different_camera_centres(gpu):
     near = torch.full((1, 12), 0.1, device=gpu)
     far = torch.full((1, 12), 10.0, device=gpu)
     ref = decoder.DecoderSplattingCUDA().to(gpu)(gs, ext, k, near, far, (32, 32))
-    auto = decoder.DecoderSplattingFused().to(gpu)(gs, ext, k, near, far, (32, 32))
+    auto = decoder.DecoderSplattingFused(glue="torch").to(gpu)(gs, ext, k, near, far, (32, 32))
     assert torch.equal(auto.color, ref.color)
-    forced = decoder.DecoderSplattingFused(shared_campos=True).to(gpu)(gs, ext, k, near, far, (32, 32))
+    forced = decoder.DecoderSplattingFused(shared_campos=True, glue="torch").to(gpu)(gs, ext, k, near, far, (32, 32))
     assert not torch.equal(forced.color, ref.color)                # what the unchecked flag would have produced
     assert decoder.views_share_camera_centre(ext[0, :3], near[0, :3]) and not decoder.views_share_camera_centre(ext[0, :6], near[0, :6])
 
