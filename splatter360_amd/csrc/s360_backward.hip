@@ -2,11 +2,10 @@
 //
 //   k_order_units      work units (tile, quadrant) in descending order of their replay length; the same launch
 //                      clears the validity flags of the partial-record slots
-//   k_render_bwd       one autonomous wave per (tile, 8x8 quadrant): back-to-front replay from final_T /
-//                      n_contrib; per splat the 9 raster gradients are reduced over the wave's 64 pixels with
-//                      a transposing DPP butterfly (no LDS, no atomics) and ONE partial record per
-//                      (instance, quadrant) is written — the instance slot is the splat's position in emission
-//                      order (grouped by (view, Gaussian) pair)
+//   k_render_bwd_em    (s360_bwd_em.h / s360_backward_em.hip) one autonomous wave per (tile, 8x8 quadrant): entry-major
+//                      back-to-front replay from final_T / n_contrib — 64 culled list entries in the lanes, the
+//                      pixels looped, two DPP scans per pixel; ONE partial record per (instance, quadrant) is written —
+//                      the instance slot is the splat's position in emission order (grouped by (view, Gaussian) pair)
 //   k_gather_pairs     1 thread per pair: sums its instances' quadrant partials in a fixed order
 //   k_preprocess_bwd   1 thread per Gaussian: chains conic -> cov2D -> cov3D / mean, projection -> mean, sums the
 //                      V views in registers; with per-view camera centres also SH -> dL/dSH (slab through LDS)
@@ -15,154 +14,14 @@
 // No float atomics anywhere: gradients are bit-reproducible run to run.
 #include "s360_device.h"
 #include "s360_prof.h"
-#include "s360_bwd_math.h"
 #include "s360_bwd_em.h"
-
-// formulation of the per-entry arithmetic: bwd_entry_packed (default) or bwd_entry_scalar — bit-identical results
-// (tests/test_bwd_math.py), the packed one needs 14 fewer VALU instructions per surviving entry
-#ifndef S360_BWD_ENTRY
-#define S360_BWD_ENTRY bwd_entry_packed
-#endif
 
 #include <cstdio>
 #include <cstdlib>
 
 namespace s360 {
 
-constexpr int GREC = 12;  // floats per partial record: gx gy gA gB | gC gop gr gg | gb - - -
-
-// Wave-autonomous like the forward composite: wave w replays quadrant w of the tile back to front from
-// final_T / n_contrib, 64 list entries at a time with lane l holding entry (hi - l) in registers.
-// Per surviving entry the 9 raster gradients are reduced over the quadrant's 64 pixels with DPP adds and
-// lanes 0-7 / 63 store ONE partial record for (instance, quadrant); k_gather_pairs adds the (up to four)
-// quadrant partials of every instance in a fixed order.  No LDS, no barriers, no float atomics.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_render_bwd(
-    KParams kp, const S360View* __restrict__ views, const uint32_t* __restrict__ tile_start,
-    const uint32_t* __restrict__ list, const uint32_t* __restrict__ offsets, const float4* __restrict__ recA,
-    const float4* __restrict__ recB, const float4* __restrict__ recC, const float* __restrict__ final_T,
-    const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dimages, float4* __restrict__ part,
-    uint8_t* __restrict__ valid, const uint32_t* __restrict__ order) {
-    const uint32_t unit = order ? order[blockIdx.x] : blockIdx.x;  // tile*4 + quadrant
-    const int t = (int)(unit >> 2), wave = (int)(unit & 3u), lane = threadIdx.x;
-    const int v = t / kp.T, rem = t - v * kp.T;
-    const int ty = rem / kp.gx, tx = rem - ty * kp.gx;
-    const int lx = sub_ox(wave) + lane % SUB_W, ly = sub_oy(wave) + lane / SUB_W;
-    const int px = tx * 16 + lx, py = ty * 16 + ly;
-    const bool inside = px < kp.W && py < kp.H;
-    const float pxf = (float)px, pyf = (float)py;
-    const float x0 = (float)(tx * 16 + sub_ox(wave)), ys0 = (float)(ty * 16 + sub_oy(wave));
-
-    const uint32_t start = min(tile_start[t], kp.cap);
-    const size_t hw = (size_t)kp.H * kp.W;
-    const size_t pix = (size_t)py * kp.W + px;
-    const S360View& vw = views[v];
-    float T_final = 0.f, dp0 = 0.f, dp1 = 0.f, dp2 = 0.f;
-    uint32_t last = 0;
-    if (inside) {
-        T_final = final_T[(size_t)v * hw + pix];
-        last = n_contrib[(size_t)v * hw + pix];
-        const float* dimg = dL_dimages + (size_t)v * 3 * hw;
-        dp0 = dimg[pix];
-        dp1 = dimg[hw + pix];
-        dp2 = dimg[2 * hw + pix];
-    }
-    const uint32_t wave_last = wave_max_u32(last);  // entries [0, wave_last) can matter to this quadrant
-    if (wave_last == 0) return;
-    const float bg_dot = vw.bg[0] * dp0 + vw.bg[1] * dp1 + vw.bg[2] * dp2;
-    BwdPixel st = {T_final, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const BwdConst kc = {dp0, dp1, dp2, T_final, bg_dot};
-
-    // chunk k holds list positions hi-63 .. hi (lane l <-> position hi - l), hi = wave_last-1-64k
-    const int64_t hi0 = (int64_t)wave_last - 1;
-    uint32_t p_n1 = 0, p_n2 = 0;
-    if (hi0 - lane >= 0) p_n1 = list[start + (uint32_t)(hi0 - lane)];
-    if (hi0 - 64 - lane >= 0) p_n2 = list[start + (uint32_t)(hi0 - 64 - lane)];
-    float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na, nc = na;
-    uint32_t nbase = 0;
-    if (hi0 - lane >= 0) {
-        na = recA[3 * (size_t)(p_n1)];
-        nb = recA[3 * (size_t)(p_n1) + 1];
-        nc = recA[3 * (size_t)(p_n1) + 2];
-        nbase = p_n1 == 0 ? 0u : offsets[p_n1 - 1];
-    }
-    for (int64_t hi = hi0; hi >= 0; hi -= 64) {
-        const float4 ea = na, eb = nb;
-        const float ec = nc.x, ewx = nc.z, ewy = nc.w;
-        const int erad = __float_as_int(nc.y);
-        const uint32_t ebase = nbase;
-        const bool ev = hi - lane >= 0;
-        p_n1 = p_n2;
-        if (hi - 64 - lane >= 0) {
-            na = recA[3 * (size_t)(p_n1)];
-            nb = recA[3 * (size_t)(p_n1) + 1];
-            nc = recA[3 * (size_t)(p_n1) + 2];
-            nbase = p_n1 == 0 ? 0u : offsets[p_n1 - 1];
-        }
-        if (hi - 128 - lane >= 0) p_n2 = list[start + (uint32_t)(hi - 128 - lane)];
-
-        const bool hit = ev && !(ea.x + ewx < x0 || ea.x - ewx > x0 + (float)(SUB_W - 1) || ea.y + ewy < ys0 ||
-                                 ea.y - ewy > ys0 + (float)(SUB_H - 1));
-        unsigned long long m = __ballot(hit);
-        if (m == 0ull) continue;
-        // slot of this lane's entry: position of tile (tx,ty) inside the splat's tile rectangle,
-        // in emission order, after the splat's first instance
-        int minx, miny, maxx, maxy;
-        tile_rect(ea.x, ea.y, erad, kp.gx, kp.gy, minx, miny, maxx, maxy);
-        const uint32_t einst = ebase + (uint32_t)((ty - miny) * (maxx - minx) + (tx - minx));
-        while (m) {
-            const int bit = __builtin_ctzll(m);
-            m &= m - 1;
-            const uint32_t contributor = (uint32_t)(hi - bit);  // 0-based list position
-            const float gx_ = rl(ea.x, bit), gy_ = rl(ea.y, bit);
-            const float cA = rl(ea.z, bit), cB = rl(ea.w, bit), cC = rl(eb.x, bit), op = rl(eb.y, bit);
-            const float dx = gx_ - pxf, dy = gy_ - pyf;
-            const float power = power2(cA, cB, cC, dx, dy);  // log2 G; cA, cB, cC are the pre-scaled conic
-            const float G = __builtin_amdgcn_exp2f(power);
-            const float alpha = fminf(0.99f, op * G);
-            const bool active = contributor < last && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-            if (__ballot(active) == 0ull) continue;  // wave-uniform: nothing to reduce
-            // Branch-free: a lane that is not a contributor runs the same arithmetic with alpha = G = 0, which
-            // leaves its T / accumulated-colour state unchanged bit for bit (T*1; acc' = 0*c + 1*acc) and makes
-            // all nine products exactly zero — no exec-mask juggling, no zero-fill of the reduction inputs.
-            const float a_eff = active ? alpha : 0.0f, G_eff = active ? G : 0.0f;
-            // 1/(1-alpha): hardware reciprocal + one Newton step (<= 1 ulp), shared by both quotients
-            const float om = 1.0f - a_eff;
-            float rcp = __builtin_amdgcn_rcpf(om);
-            rcp = __builtin_fmaf(__builtin_fmaf(-om, rcp, 1.0f), rcp, rcp);
-            const float c0 = rl(eb.z, bit), c1 = rl(eb.w, bit), c2 = rl(ec, bit);
-            BwdOut go;
-            S360_BWD_ENTRY(st, kc, a_eff, G_eff, rcp, cA, cB, cC, op, c0, c1, c2, dx, dy, go);
-            float g_x = go.g_x, g_y = go.g_y, g_A = go.g_A, g_B = go.g_B, g_C = go.g_C, g_op = go.g_op, g_r = go.g_r, g_g = go.g_g,
-                  g_b = go.g_b;
-#ifdef S360_PLAIN_REDUCE
-            wave_sum9_lane63(g_x, g_y, g_A, g_B, g_C, g_op, g_r, g_g, g_b);
-            const uint32_t inst = (uint32_t)__builtin_amdgcn_readlane((int)einst, bit);
-            if (lane == 63 && inst < kp.cap) {
-                float4* o = part + ((size_t)inst * 4 + wave) * (GREC / 4);
-                o[0] = make_float4(g_x, g_y, g_A, g_B);
-                o[1] = make_float4(g_C, g_op, g_r, g_g);
-                o[2] = make_float4(g_b, 0.f, 0.f, 0.f);
-                valid[(size_t)inst * 4 + wave] = 1;
-            }
-#else
-            // 8 sums through the transposing butterfly (lanes 0..7 end up with values 0,1,3,2,6,7,5,4 of
-            // the record), the ninth (g_b) through a plain DPP chain into lane 63
-            const float tot = wave_sum8_transposed(g_x, g_y, g_A, g_B, g_C, g_op, g_r, g_g);
-            g_b = wave_sum1_lane63(g_b);
-            const uint32_t inst = (uint32_t)__builtin_amdgcn_readlane((int)einst, bit);
-            if (inst < kp.cap) {
-                float* o = reinterpret_cast<float*>(part + ((size_t)inst * 4 + wave) * (GREC / 4));
-                if (lane < 8) o[lane ^ (lane >> 1)] = tot;  // Gray code: lane -> value index
-                if (lane == 63) {
-                    o[8] = g_b;
-                    o[9] = 0.f;  // no depth channel in this formulation
-                    valid[(size_t)inst * 4 + wave] = 1;
-                }
-            }
-#endif
-        }
-    }
-}
+constexpr int GREC = 12;  // floats per partial record: gx gy gA gB | gC gop gr gg | gb gz - -
 
 // One thread per (view, Gaussian) pair: adds the quadrant partials of all its (tile) instances in a fixed
 // order (instance ascending, quadrant ascending) into one 48-byte raster-gradient record per pair.
@@ -683,19 +542,13 @@ static int backward_impl(const S360Params* prm, const S360View* views, const flo
     uint32_t* order = valid_words + kp.cap;  // [nt*4] after the validity words
     const uint32_t* strip_last = (const uint32_t*)(ws + L.strip_last);
     const bool use_order = !getenv("S360_NO_ORDER");
-    // S360_BWD_LEGACY=1: the round-1 pixel-major composite (kept for A/B timing; it has no depth channel)
-    const bool legacy = getenv("S360_BWD_LEGACY") != nullptr && !with_depth;
     {
     ProfScope ps(PS_RENDER_BWD, st);
     hipLaunchKernelGGL(k_order_units, dim3(1 + 512), dim3(1024), 0, st, strip_last, use_order ? order : (uint32_t*)nullptr, nt * 4,
                        valid_words, header, kp.cap);
     const uint32_t* ord = use_order ? order : (const uint32_t*)nullptr;
-    if (legacy)
-        hipLaunchKernelGGL(k_render_bwd, dim3(nt * 4), dim3(64), 0, st, kp, views, tile_start, list, offsets, recA, recB,
-                           recC, final_T, n_contrib, dL_dimages, part, (uint8_t*)valid_words, ord);
-    else
-        launch_render_bwd_em(with_depth, nt * 4, st, kp, views, tile_start, list, offsets, recA, depths, final_T, n_contrib,
-                             dL_dimages, dL_ddepth, part, (uint8_t*)valid_words, ord, depth_mode);
+    launch_render_bwd_em(with_depth, nt * 4, st, kp, views, tile_start, list, offsets, recA, depths, final_T, n_contrib,
+                         dL_dimages, dL_ddepth, part, (uint8_t*)valid_words, ord, depth_mode);
     }
     S360_CHECK_LAUNCH();
     ProfScope ps(PS_PREPROCESS_BWD, st);

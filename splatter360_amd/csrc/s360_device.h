@@ -255,6 +255,26 @@ __device__ __forceinline__ float power2(float a, float b, float c, float dx, flo
     return __builtin_fmaf(t, dx, (c * dy) * dy);
 }
 
+// Exact quadrant cull shared by the forward and backward composites.  A splat contributes to a pixel only if
+// alpha = opacity * 2^power >= 1/255, i.e. power >= -log2(255 opacity).  power(dx, dy) = a dx^2 + b dx dy + c dy^2 is a
+// concave quadratic (maximum 0 at the centre), so its maximum over the box spanned by the quadrant's 8x8 pixel centres
+// lies either at the centre (inside the box) or on one of the two box edges facing the centre; each edge maximum is a
+// clamped 1-D parabola vertex (ka = -b/(2a), kb = -b/(2c) are stored in the splat record by k_preprocess).
+// The test is conservative (continuous box instead of the pixel lattice, +0.02 in log2 units against float rounding of
+// ~1e-5): a culled entry fails alpha >= 1/255 on every pixel of the quadrant, so skipping it changes nothing.
+// Round 1 tested the ellipse's axis-aligned bounding box instead: 18 % of its survivors contributed to no pixel.
+__device__ __forceinline__ bool quadrant_hit(float x, float y, float a, float b, float c, float op, float ka, float kb,
+                                             float x0, float y0) {
+    const float dh = x - x0, dl = dh - (float)(SUB_W - 1);   // range of dx = x - px over the quadrant's columns
+    const float eh = y - y0, el = eh - (float)(SUB_H - 1);   // range of dy = y - py over its rows
+    const float dx1 = __builtin_amdgcn_fmed3f(0.0f, dl, dh);  // column closest to the centre
+    const float dy1 = __builtin_amdgcn_fmed3f(0.0f, el, eh);
+    const float dys = __builtin_amdgcn_fmed3f(kb * dx1, el, eh);  // best row on that column
+    const float dxs = __builtin_amdgcn_fmed3f(ka * dy1, dl, dh);  // best column on that row
+    const float pmax = fmaxf(power2(a, b, c, dx1, dys), power2(a, b, c, dxs, dy1));
+    return pmax + __builtin_amdgcn_logf(op) + (7.994353436858858f + 0.02f) >= 0.0f;  // log2(255) = 7.9943...
+}
+
 // Per-Gaussian "colour" of the fused depth map for the reference's DepthRenderingMode
 // (cuda_splatting.py:244-251; z = camera-space depth in unscaled units).  The "log" mode reproduces the
 // reference's swapped clamp (z.minimum(near).maximum(far)) as is.
@@ -281,114 +301,12 @@ __device__ __forceinline__ void tile_rect(float px, float py, int radius, int gx
 }
 
 // ---- wave64 primitives -------------------------------------------------------------------
-template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF, bool BOUND = true>
-__device__ __forceinline__ float dpp_f(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, BOUND));
-}
-
-// Sum over the 64 lanes of a wave with DPP only (no LDS traffic); result valid in lane 63.
-__device__ __forceinline__ float wave_sum_lane63(float v) {
-    v += dpp_f<0xB1>(v);   // quad_perm [1,0,3,2]
-    v += dpp_f<0x4E>(v);   // quad_perm [2,3,0,1]
-    v += dpp_f<0x141>(v);  // row_half_mirror
-    v += dpp_f<0x140>(v);  // row_mirror  -> every lane of a 16-lane row holds the row sum
-    v += dpp_f<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
-    v += dpp_f<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3
-    return v;
-}
-
 // broadcast lane `l` (wave-uniform) of a VGPR into an SGPR
 __device__ __forceinline__ float rl(float v, int l) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 
-// Nine independent wave64 sums in one hand-scheduled block: 9 x 6 v_add_f32 with DPP source
-// modifiers (hipcc lowers update_dpp + add to v_mov_dpp + v_pk_add + moves, ~2.2x the instructions).
-// The nine chains are interleaved step by step, so between two dependent DPP ops on one register
-// there are always eight other VALU ops (the VALU-write -> DPP-read hazard needs two wait states);
-// the leading s_nop covers the producers of the inputs.  Totals end up in lane 63.
-__device__ __forceinline__ void wave_sum9_lane63(float& a, float& b, float& c, float& d, float& e, float& f,
-                                                 float& g, float& h, float& i) {
-#define S360_DPP_STEP(ctrl)                              \
-    "v_add_f32_dpp %0, %0, %0 " ctrl "\n"                \
-    "v_add_f32_dpp %1, %1, %1 " ctrl "\n"                \
-    "v_add_f32_dpp %2, %2, %2 " ctrl "\n"                \
-    "v_add_f32_dpp %3, %3, %3 " ctrl "\n"                \
-    "v_add_f32_dpp %4, %4, %4 " ctrl "\n"                \
-    "v_add_f32_dpp %5, %5, %5 " ctrl "\n"                \
-    "v_add_f32_dpp %6, %6, %6 " ctrl "\n"                \
-    "v_add_f32_dpp %7, %7, %7 " ctrl "\n"                \
-    "v_add_f32_dpp %8, %8, %8 " ctrl "\n"
-    asm volatile(
-        "s_nop 1\n"
-        S360_DPP_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
-        S360_DPP_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
-        S360_DPP_STEP("row_half_mirror row_mask:0xf bank_mask:0xf")
-        S360_DPP_STEP("row_mirror row_mask:0xf bank_mask:0xf")
-        S360_DPP_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
-        S360_DPP_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
-        "s_nop 1\n"
-        : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(i));
-#undef S360_DPP_STEP
-}
-
-// Eight wave64 sums for the price of ~3: "transposing" butterfly.  At level k (k = 1, 2, 3) a lane and
-// its mirror partner inside the 2^k-lane group each hold two registers (X, Y); the lane whose role bit
-// t_k = bit_{k-1}(lane) ^ bit_k(lane) is 0 keeps X and adds the partner's X, the other keeps Y — so the
-// register count halves per level (8 -> 4 -> 2 -> 1) instead of every register paying all six steps.
-// Mirror partners (quad_perm [1,0,3,2] / [3,2,1,0], row_half_mirror, row_mirror) flip all lower lane bits,
-// which leaves every earlier role bit unchanged (adjacent-bit XOR), so the partial sums line up.
-// Levels 4-6 (row mirror, xor 16, xor 32) are plain adds on the single remaining register.
-// Result: EVERY lane holds the wave total of value idx = t1 + 2 t2 + 4 t3, i.e. lanes 0..7 hold values
-// 0,1,3,2,6,7,5,4.  26 VALU/LDS-crossbar ops instead of 48.
-__device__ __forceinline__ float wave_sum8_transposed(float v0, float v1, float v2, float v3, float v4, float v5,
-                                                      float v6, float v7) {
-    const unsigned long long m1 = 0x6666666666666666ull;  // lanes with bit0 != bit1
-    const unsigned long long m2 = 0x3C3C3C3C3C3C3C3Cull;  // lanes with bit1 != bit2
-    const unsigned long long m3 = 0x0FF00FF00FF00FF0ull;  // lanes with bit2 != bit3
-    float s0, s1, s2, s3, k0, k1, k2, k3, r0, r1, r2, r3;
-    asm volatile(
-        "s_nop 1\n"
-        // level 1: (v0,v1) (v2,v3) (v4,v5) (v6,v7); give = t1 ? X : Y, keep = t1 ? Y : X
-        "v_cndmask_b32_e64 %0, %13, %12, %20\n"
-        "v_cndmask_b32_e64 %4, %12, %13, %20\n"
-        "v_cndmask_b32_e64 %1, %15, %14, %20\n"
-        "v_cndmask_b32_e64 %5, %14, %15, %20\n"
-        "v_cndmask_b32_e64 %2, %17, %16, %20\n"
-        "v_cndmask_b32_e64 %6, %16, %17, %20\n"
-        "v_cndmask_b32_e64 %3, %19, %18, %20\n"
-        "v_cndmask_b32_e64 %7, %18, %19, %20\n"
-        "v_add_f32_dpp %8, %0, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
-        "v_add_f32_dpp %9, %1, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
-        "v_add_f32_dpp %10, %2, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
-        "v_add_f32_dpp %11, %3, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
-        // level 2: (r0,r1) (r2,r3)
-        "v_cndmask_b32_e64 %0, %9, %8, %21\n"
-        "v_cndmask_b32_e64 %4, %8, %9, %21\n"
-        "v_cndmask_b32_e64 %1, %11, %10, %21\n"
-        "v_cndmask_b32_e64 %5, %10, %11, %21\n"
-        "s_nop 0\n"
-        "v_add_f32_dpp %8, %0, %4 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n"
-        "v_add_f32_dpp %9, %1, %5 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n"
-        // level 3: (r0,r1)
-        "v_cndmask_b32_e64 %0, %9, %8, %22\n"
-        "v_cndmask_b32_e64 %4, %8, %9, %22\n"
-        "s_nop 1\n"
-        "v_add_f32_dpp %8, %0, %4 row_half_mirror row_mask:0xf bank_mask:0xf\n"
-        // level 4: plain mirror add inside the 16-lane row
-        "s_nop 1\n"
-        "v_add_f32_dpp %8, %8, %8 row_mirror row_mask:0xf bank_mask:0xf\n"
-        "s_nop 1\n"
-        : "=&v"(s0), "=&v"(s1), "=&v"(s2), "=&v"(s3), "=&v"(k0), "=&v"(k1), "=&v"(k2), "=&v"(k3), "=&v"(r0), "=&v"(r1),
-          "=&v"(r2), "=&v"(r3)
-        : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v7), "s"(m1), "s"(m2), "s"(m3));
-    // levels 5, 6: across the four rows (LDS crossbar permute, no LDS memory)
-    r0 += __shfl_xor(r0, 16);
-    r0 += __shfl_xor(r0, 32);
-    return r0;
-}
-
-// One more wave64 sum with plain DPP adds; total valid in lane 63.
+// Wave64 sum with plain DPP adds; total valid in lane 63.
 __device__ __forceinline__ float wave_sum1_lane63(float a) {
     asm volatile(
         "s_nop 1\n"
@@ -406,10 +324,6 @@ __device__ __forceinline__ float wave_sum1_lane63(float a) {
         "s_nop 1\n"
         : "+v"(a));
     return a;
-}
-
-__device__ __forceinline__ float readlane63(float v) {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {

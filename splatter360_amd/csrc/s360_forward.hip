@@ -162,15 +162,10 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess(
                     // conic stored pre-scaled for the composite: exponent in base 2, -1/2 folded in
                     recA[3 * (size_t)(p)] = make_float4(px, py, conA * kConicDiag, conB * kConicOff);
                     recA[3 * (size_t)(p) + 1] = make_float4(conC * kConicDiag, op, rgb[0], rgb[1]);
-                    // conservative cull radius: alpha = o*exp(power) <= o*exp(-|d|^2 / (2 lambda_max)), so
-                    // outside |d| > sqrt(2 lambda_max ln(255 o)) the 1/255 test always rejects.
-                    // alpha = o*exp(-d^T Q d / 2) >= 1/255  <=>  d^T Q d <= 2 ln(255 o): an ellipse whose exact
-                    // axis-aligned half extents are sqrt(2 ln(255 o) * cov_xx), sqrt(2 ln(255 o) * cov_yy).
-                    const float tau2 = 2.0f * __logf(255.0f * op);
-                    const bool can = 255.0f * op > 1.0f;
-                    const float wx = can ? sqrtf(tau2 * ge.a) * 1.001f + 0.01f : -1.0f;
-                    const float wy = can ? sqrtf(tau2 * ge.c) * 1.001f + 0.01f : -1.0f;
-                    recA[3 * (size_t)(p) + 2] = make_float4(rgb[2], __int_as_float(rad), wx, wy);
+                    // slopes of the two parabola-vertex lines of the composite's exact quadrant cull (quadrant_hit):
+                    // dx* = ka dy maximises the exponent on a row, dy* = kb dx on a column
+                    const float ra = conA * kConicDiag, rb = conB * kConicOff, rc_ = conC * kConicDiag;
+                    recA[3 * (size_t)(p) + 2] = make_float4(rgb[2], __int_as_float(rad), -rb / (2.0f * ra), -rb / (2.0f * rc_));
                     depths[p] = pvz;
                     clamped[p] = (uint8_t)clampbits;
                     // block-local histogram in LDS; one global atomic per (block, touched tile) below
@@ -776,7 +771,7 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
         // fused depth "colour" of this lane's entry: camera z in unscaled units, then the reference's mode
         float ez = 0.f;
         if (WITH_DEPTH) ez = depth_value(nz * inv_scale, v_near, v_far, depth_mode);
-        const float ec = nc.x, ewx = nc.z, ewy = nc.w;
+        const float ec = nc.x, eka = nc.z, ekb = nc.w;
         const bool ev = b + lane < end;
         // issue the next chunk's loads before touching this one
         p_n1 = p_n2;
@@ -788,8 +783,7 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
         }
         if (b + 128 + lane < end) p_n2 = list[b + 128 + lane];
 
-        const bool hit = ev && !(ea.x + ewx < x0 || ea.x - ewx > x0 + (float)(SUB_W - 1) || ea.y + ewy < ys0 ||
-                                 ea.y - ewy > ys0 + (float)(SUB_H - 1));
+        const bool hit = ev && quadrant_hit(ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, eka, ekb, x0, ys0);
         unsigned long long m = __ballot(hit);
 #ifdef S360_DBG_COUNT
         {
