@@ -231,6 +231,32 @@ int s360_pack_views(const float* extrinsics, const float* intrinsics, const floa
                     int32_t n_views, int32_t scale_invariant, S360View* views_out, void* stream);
 
 /*
+ * Gaussian-adapter tail: the producer of the per-Gaussian buffers this library rasterises — replaces
+ * GaussianAdapterERP.forward (/root/reference/src/model/encoder/common/gaussian_adapter_erp.py:50-119: scale map :63-78,
+ * quaternion normalisation :82, sh_mask :38-47,86, world covariance :89-92 with build_covariance of
+ * common/gaussians.py:33-44, sphere un-projection src/geometry/sphere_projection.py:6-86 in the 'hm3d' / 'replica'
+ * ERP convention of src/geometry/utils360.py:93-104,148-153) in one launch.
+ *   extrinsics[V,4,4] context-panorama camera-to-world; depths[V,Gv]; raw_gaussians[V,Gv,7+3*d_sh] = 3 scale logits,
+ *   quaternion (x,y,z,w), 3*d_sh SH coefficients channel-major; Gv = H*W*per_ray Gaussians per view, ray-major;
+ *   sh_rotation[V,d_sh,d_sh] or NULL (= identity): per-view SH rotation, only the (2l+1)x(2l+1) diagonal blocks are
+ *   read — the Wigner-D matrices rotate_sh (src/misc/sh_rotation.py:10-30) obtains from e3nn, built by the caller.
+ * Outputs: means[V*Gv,3], covariances[V*Gv,3,3] (cov9 != 0) or [V*Gv,6] upper triangle (the rasteriser's
+ * cov3D_precomp layout), harmonics[V*Gv,3,d_sh]; optional scales_out[V*Gv,3] / rotations_out[V*Gv,4] (the adapter's
+ * export-only fields).  Opacities pass through the adapter unchanged and are not touched here.
+ * s360_adapter_backward: gradients of (means, covariances, harmonics) -> d_depths[V,Gv], d_raw_gaussians (same layout).
+ */
+int s360_adapter_forward(const float* extrinsics, const float* depths, const float* raw_gaussians,
+                         const float* sh_rotation, int32_t n_views, int32_t per_view, int32_t H, int32_t W,
+                         int32_t per_ray, int32_t d_sh, float scale_min, float scale_max, float eps, float* means,
+                         float* covariances, int32_t cov9, float* harmonics, float* scales_out,
+                         float* rotations_out, void* stream);
+int s360_adapter_backward(const float* extrinsics, const float* depths, const float* raw_gaussians,
+                          const float* sh_rotation, int32_t n_views, int32_t per_view, int32_t H, int32_t W,
+                          int32_t per_ray, int32_t d_sh, float scale_min, float scale_max, float eps,
+                          const float* d_means, const float* d_covariances, int32_t cov9, const float* d_harmonics,
+                          float* d_depths, float* d_raw_gaussians, void* stream);
+
+/*
  * Cube -> equirectangular stitch: replaces Cube2Equirec.forward
  * (/root/reference/src/geometry/layers.py:108-116, F.grid_sample trilinear / border /
  * align_corners=True over the [C,6,fw,fw] face stack).

@@ -14,7 +14,7 @@ from pathlib import Path
 _PKG = Path(__file__).resolve().parent
 _CSRC = _PKG / "csrc"
 LIB_PATH = _PKG / "libs360.so"
-SOURCES = ("s360_forward.hip", "s360_backward.hip", "s360_backward_em.hip", "s360_stitch.hip", "s360_views.hip")
+SOURCES = ("s360_forward.hip", "s360_backward.hip", "s360_backward_em.hip", "s360_stitch.hip", "s360_views.hip", "s360_adapter.hip")
 # per-source extra flags (s360_backward_em.hip: see the launcher comment in csrc/s360_bwd_em.h)
 SOURCE_FLAGS = {"s360_backward_em.hip": ("-fno-slp-vectorize",)}
 HIPCC_FLAGS = ("--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-unused-result")
@@ -41,7 +41,7 @@ class S360Layout(C.Structure):
         "tile_max_contrib", "strip_last", "backward_bytes")]
 
 
-EXPORTS = ("s360_abi_version", "s360_error_string", "s360_layout", "s360_forward", "s360_forward_depth", "s360_forward_mse", "s360_backward", "s360_backward_split", "s360_sh_backward", "s360_pack_views",
+EXPORTS = ("s360_abi_version", "s360_error_string", "s360_layout", "s360_forward", "s360_forward_depth", "s360_forward_mse", "s360_backward", "s360_backward_split", "s360_sh_backward", "s360_pack_views", "s360_adapter_forward", "s360_adapter_backward",
            "s360_cube2erp_forward", "s360_cube2erp_backward", "s360_profile_slots", "s360_profile_slot_name",
            "s360_profile_enable", "s360_profile_collect")
 
@@ -142,6 +142,11 @@ def lib() -> C.CDLL:
     l.s360_sh_backward.argtypes = [C.POINTER(S360Params), i32] + [vp] * 7
     l.s360_pack_views.restype = C.c_int
     l.s360_pack_views.argtypes = [vp] * 5 + [i32, i32, i32, vp, vp]
+    f32 = C.c_float
+    l.s360_adapter_forward.restype = C.c_int
+    l.s360_adapter_forward.argtypes = [vp] * 4 + [i32] * 6 + [f32] * 3 + [vp, vp, i32, vp, vp, vp, vp]
+    l.s360_adapter_backward.restype = C.c_int
+    l.s360_adapter_backward.argtypes = [vp] * 4 + [i32] * 6 + [f32] * 3 + [vp, vp, i32, vp, vp, vp, vp]
     l.s360_cube2erp_forward.restype = C.c_int
     l.s360_cube2erp_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(C.c_int64), vp]
     l.s360_cube2erp_backward.restype = C.c_int

@@ -1,0 +1,311 @@
+// s360_adapter.hip — fused Gaussian-adapter tail (forward + backward).  gfx950 only.
+//
+// The step of the reference's encoder that PRODUCES the per-Gaussian buffers the rasteriser reads
+// (src/model/encoder/common/gaussian_adapter_erp.py:50-119), one thread per Gaussian:
+//   scales   = (smin + (smax - smin) sigmoid(raw_s)) * depth / max(w, h)                      (:63-78)
+//   q^       = q / (|q| + eps)                                                                (:82)
+//   Sigma    = C R(q^) diag(scales^2) R(q^)^T C^T   (R: gaussians.py:8-31, xyzw; C = c2w rotation)   (:89-92)
+//   mean     = C (dir(pixel) * depth) + t           (sphere_projection.py:6-86, utils360.py:93-104,148-153)
+//   harmonics= D_l (sh * sh_mask) per degree l      (:38-47,86; rotate_sh, src/misc/sh_rotation.py:10-30 — the
+//              Wigner-D blocks are an input: e3nn builds them on the host side, one d_sh x d_sh matrix per view)
+// instead of ~20 torch launches with their [G,3,3] intermediates.  grid.y = view, so everything that depends on the
+// view only (pose, SH rotation blocks) is wave-uniform.  Streaming: 336 B read, 352 B (cov6: 340 B) written per Gaussian.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/s360.h"
+
+namespace s360 {
+
+constexpr float kPi = 3.14159265358979323846f;
+
+struct AdapterParams {
+    int V, Gv, H, W, per_ray, d_sh, cov9;
+    float smin, smax, eps;
+};
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// sh_mask per degree: 1, 0.1 * 0.25^l (gaussian_adapter_erp.py:38-47), rounded to float32 like the reference's buffer
+__device__ constexpr float kShMask[5] = {1.0f, 0.025f, 0.00625f, 0.0015625f, 0.000390625f};
+
+// unit ray of ERP pixel n (row-major) in the 'hm3d' / 'replica' convention
+__device__ __forceinline__ void erp_dir(int n, int H, int W, float* d) {
+    const int y = n / W, x = n - y * W;
+    const float theta = ((0.5f - ((float)x + 0.5f) / (float)W) * 2.0f) * kPi;
+    const float phi = -((((float)y + 0.5f) / (float)H - 0.5f)) * kPi;
+    const float cp = cosf(phi);
+    d[0] = cp * sinf(theta);
+    d[1] = sinf(phi);
+    d[2] = cp * cosf(theta);
+}
+
+struct QuatGeom {
+    float q[4];     // normalised quaternion (i, j, k, r)
+    float n, m;     // |q_raw|, |q_raw| + eps
+    float a;        // two_s = 2 / (|q^|^2 + eps)
+    float R[3][3];
+};
+
+__device__ __forceinline__ void quat_geom(const float* qr, float eps, QuatGeom& g) {
+    g.n = sqrtf(qr[0] * qr[0] + qr[1] * qr[1] + qr[2] * qr[2] + qr[3] * qr[3]);
+    g.m = g.n + eps;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) g.q[k] = qr[k] / g.m;
+    const float i = g.q[0], j = g.q[1], k = g.q[2], r = g.q[3];
+    g.a = 2.0f / (i * i + j * j + k * k + r * r + 1e-8f);  // quaternion_to_matrix's own eps (gaussians.py:11)
+    const float a = g.a;
+    g.R[0][0] = 1.0f - a * (j * j + k * k); g.R[0][1] = a * (i * j - k * r); g.R[0][2] = a * (i * k + j * r);
+    g.R[1][0] = a * (i * j + k * r); g.R[1][1] = 1.0f - a * (i * i + k * k); g.R[1][2] = a * (j * k - i * r);
+    g.R[2][0] = a * (i * k - j * r); g.R[2][1] = a * (j * k + i * r); g.R[2][2] = 1.0f - a * (i * i + j * j);
+}
+
+__global__ __launch_bounds__(256) void k_adapter_fwd(AdapterParams ap, const float* __restrict__ extrinsics,
+                                                     const float* __restrict__ depths, const float* __restrict__ raw,
+                                                     const float* __restrict__ sh_rot, float* __restrict__ means,
+                                                     float* __restrict__ cov, float* __restrict__ harmonics,
+                                                     float* __restrict__ scales_out, float* __restrict__ rot_out) {
+    const int v = blockIdx.y;
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= ap.Gv) return;
+    const size_t i = (size_t)v * ap.Gv + g;
+    const float* E = extrinsics + 16 * v;  // wave-uniform
+    const int c_in = 7 + 3 * ap.d_sh;
+    const float* rw = raw + i * c_in;
+    const float depth = depths[i];
+    // scales
+    const float px = 1.0f / (float)max(ap.W, ap.H);
+    float s[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s[k] = ((ap.smin + (ap.smax - ap.smin) * sigmoidf(rw[k])) * depth) * px;
+    // rotation
+    QuatGeom qg;
+    const float qr[4] = {rw[3], rw[4], rw[5], rw[6]};
+    quat_geom(qr, ap.eps, qg);
+    // M = C R ; Sigma = M diag(s^2) M^T
+    float M[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) M[a][b] = E[4 * a] * qg.R[0][b] + E[4 * a + 1] * qg.R[1][b] + E[4 * a + 2] * qg.R[2][b];
+    const float s2[3] = {s[0] * s[0], s[1] * s[1], s[2] * s[2]};
+    float S[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = a; b < 3; ++b) S[a][b] = S[b][a] = M[a][0] * s2[0] * M[b][0] + M[a][1] * s2[1] * M[b][1] + M[a][2] * s2[2] * M[b][2];
+    if (ap.cov9) {
+        float* o = cov + 9 * i;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) o[3 * a + b] = S[a][b];
+    } else {
+        float* o = cov + 6 * i;
+        o[0] = S[0][0]; o[1] = S[0][1]; o[2] = S[0][2]; o[3] = S[1][1]; o[4] = S[1][2]; o[5] = S[2][2];
+    }
+    // mean
+    float d[3];
+    erp_dir(g / ap.per_ray, ap.H, ap.W, d);
+    const float p[3] = {d[0] * depth, d[1] * depth, d[2] * depth};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) means[3 * i + a] = (E[4 * a] * p[0] + E[4 * a + 1] * p[1] + E[4 * a + 2] * p[2]) + E[4 * a + 3];
+    if (scales_out) {
+        scales_out[3 * i] = s[0]; scales_out[3 * i + 1] = s[1]; scales_out[3 * i + 2] = s[2];
+    }
+    if (rot_out) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rot_out[4 * i + k] = qg.q[k];
+    }
+    // harmonics: per colour channel, per degree: D_l (sh * mask)
+    const int deg = ap.d_sh == 25 ? 4 : ap.d_sh == 16 ? 3 : ap.d_sh == 9 ? 2 : ap.d_sh == 4 ? 1 : 0;
+    const float* D = sh_rot ? sh_rot + (size_t)v * ap.d_sh * ap.d_sh : nullptr;  // wave-uniform
+    for (int c = 0; c < 3; ++c) {
+        const float* src = rw + 7 + c * ap.d_sh;
+        float* dst = harmonics + (i * 3 + c) * ap.d_sh;
+        float mask = 1.0f;
+        for (int l = 0; l <= deg; ++l) {
+            const int o = l * l, nl = 2 * l + 1;
+            mask = kShMask[l];
+            for (int a = 0; a < nl; ++a) {
+                float acc;
+                if (D) {
+                    acc = 0.f;
+                    for (int b = 0; b < nl; ++b) acc += D[(o + a) * ap.d_sh + o + b] * (src[o + b] * mask);
+                } else {
+                    acc = src[o + a] * mask;
+                }
+                dst[o + a] = acc;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_adapter_bwd(AdapterParams ap, const float* __restrict__ extrinsics,
+                                                     const float* __restrict__ depths, const float* __restrict__ raw,
+                                                     const float* __restrict__ sh_rot, const float* __restrict__ d_means,
+                                                     const float* __restrict__ d_cov, const float* __restrict__ d_harm,
+                                                     float* __restrict__ d_depths, float* __restrict__ d_raw) {
+    const int v = blockIdx.y;
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= ap.Gv) return;
+    const size_t i = (size_t)v * ap.Gv + g;
+    const float* E = extrinsics + 16 * v;
+    const int c_in = 7 + 3 * ap.d_sh;
+    const float* rw = raw + i * c_in;
+    float* dr = d_raw + i * c_in;
+    const float depth = depths[i];
+    const float px = 1.0f / (float)max(ap.W, ap.H);
+    float sig[3], base[3], s[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        sig[k] = sigmoidf(rw[k]);
+        base[k] = ap.smin + (ap.smax - ap.smin) * sig[k];
+        s[k] = (base[k] * depth) * px;
+    }
+    QuatGeom qg;
+    const float qr[4] = {rw[3], rw[4], rw[5], rw[6]};
+    quat_geom(qr, ap.eps, qg);
+    float M[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) M[a][b] = E[4 * a] * qg.R[0][b] + E[4 * a + 1] * qg.R[1][b] + E[4 * a + 2] * qg.R[2][b];
+    // G = dL/dSigma as a full 3x3 (cov6: the off-diagonal entries stand for one variable each -> upper triangle only)
+    float G[3][3];
+    if (ap.cov9) {
+        const float* gcv = d_cov + 9 * i;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) G[a][b] = gcv[3 * a + b];
+    } else {
+        const float* gcv = d_cov + 6 * i;
+        G[0][0] = gcv[0]; G[0][1] = gcv[1]; G[0][2] = gcv[2]; G[1][1] = gcv[3]; G[1][2] = gcv[4]; G[2][2] = gcv[5];
+        G[1][0] = G[2][0] = G[2][1] = 0.f;
+    }
+    // Sigma = M D M^T, D = diag(s^2):  dM = (G + G^T) M D,  dD_k = (M^T G M)_kk
+    float Gs[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) Gs[a][b] = G[a][b] + G[b][a];
+    float dM[3][3], ds[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float t[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) t[a] = Gs[a][0] * M[0][k] + Gs[a][1] * M[1][k] + Gs[a][2] * M[2][k];  // (Gs M)[:,k]
+        const float s2 = s[k] * s[k];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) dM[a][k] = t[a] * s2;
+        // (M^T G M)_kk = 1/2 (M^T Gs M)_kk
+        ds[k] = 2.0f * s[k] * (0.5f * (M[0][k] * t[0] + M[1][k] * t[1] + M[2][k] * t[2]));
+    }
+    // dR = C^T dM
+    float dR[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) dR[a][b] = E[a] * dM[0][b] + E[4 + a] * dM[1][b] + E[8 + a] * dM[2][b];
+    // R(q^) -> q^   (a = two_s depends on q^ as well)
+    const float qi = qg.q[0], qj = qg.q[1], qk = qg.q[2], qr_ = qg.q[3], a = qg.a;
+    const float B[3][3] = {{-(qj * qj + qk * qk), qi * qj - qk * qr_, qi * qk + qj * qr_},
+                           {qi * qj + qk * qr_, -(qi * qi + qk * qk), qj * qk - qi * qr_},
+                           {qi * qk - qj * qr_, qj * qk + qi * qr_, -(qi * qi + qj * qj)}};
+    float dLda = 0.f;
+#pragma unroll
+    for (int x = 0; x < 3; ++x)
+#pragma unroll
+        for (int y = 0; y < 3; ++y) dLda += dR[x][y] * B[x][y];
+    float dq[4];
+    dq[0] = a * (dR[0][1] * qj + dR[0][2] * qk + dR[1][0] * qj - 2.0f * qi * dR[1][1] - dR[1][2] * qr_ + dR[2][0] * qk + dR[2][1] * qr_ - 2.0f * qi * dR[2][2]);
+    dq[1] = a * (-2.0f * qj * dR[0][0] + dR[0][1] * qi + dR[0][2] * qr_ + dR[1][0] * qi + dR[1][2] * qk - dR[2][0] * qr_ + dR[2][1] * qk - 2.0f * qj * dR[2][2]);
+    dq[2] = a * (-2.0f * qk * dR[0][0] - dR[0][1] * qr_ + dR[0][2] * qi + dR[1][0] * qr_ - 2.0f * qk * dR[1][1] + dR[1][2] * qj + dR[2][0] * qi + dR[2][1] * qj);
+    dq[3] = a * (-dR[0][1] * qk + dR[0][2] * qj + dR[1][0] * qk - dR[1][2] * qi - dR[2][0] * qj + dR[2][1] * qi);
+    const float da = -a * a * dLda;  // da/dq^ = -a^2 q^
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dq[k] += da * qg.q[k];
+    // q^ = q / (|q| + eps):  dq = dq^ / m - q (q . dq^) / (n m^2)
+    const float dot = qr[0] * dq[0] + qr[1] * dq[1] + qr[2] * dq[2] + qr[3] * dq[3];
+    const float f = qg.n > 0.f ? dot / (qg.n * qg.m * qg.m) : 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dr[3 + k] = dq[k] / qg.m - qr[k] * f;
+    // scales and depth
+    float dd = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        dr[k] = ds[k] * depth * px * (ap.smax - ap.smin) * sig[k] * (1.0f - sig[k]);
+        dd += ds[k] * base[k] * px;
+    }
+    float d[3];
+    erp_dir(g / ap.per_ray, ap.H, ap.W, d);
+    const float* gm = d_means + 3 * i;
+#pragma unroll
+    for (int x = 0; x < 3; ++x) dd += (E[x] * gm[0] + E[4 + x] * gm[1] + E[8 + x] * gm[2]) * d[x];  // (C^T dmean) . dir
+    d_depths[i] = dd;
+    // harmonics
+    const int deg = ap.d_sh == 25 ? 4 : ap.d_sh == 16 ? 3 : ap.d_sh == 9 ? 2 : ap.d_sh == 4 ? 1 : 0;
+    const float* D = sh_rot ? sh_rot + (size_t)v * ap.d_sh * ap.d_sh : nullptr;
+    for (int c = 0; c < 3; ++c) {
+        const float* gh = d_harm + (i * 3 + c) * ap.d_sh;
+        float* dst = dr + 7 + c * ap.d_sh;
+        float mask = 1.0f;
+        for (int l = 0; l <= deg; ++l) {
+            const int o = l * l, nl = 2 * l + 1;
+            mask = kShMask[l];
+            for (int b = 0; b < nl; ++b) {
+                float acc;
+                if (D) {
+                    acc = 0.f;
+                    for (int a2 = 0; a2 < nl; ++a2) acc += D[(o + a2) * ap.d_sh + o + b] * gh[o + a2];
+                } else {
+                    acc = gh[o + b];
+                }
+                dst[o + b] = acc * mask;
+            }
+        }
+    }
+}
+
+}  // namespace s360
+
+using namespace s360;
+
+static int adapter_args_ok(const float* extrinsics, const float* depths, const float* raw, int V, int Gv, int H, int W,
+                           int per_ray, int d_sh) {
+    if (!extrinsics || !depths || !raw || V < 0 || Gv < 0 || H < 1 || W < 1 || per_ray < 1) return 0;
+    if (d_sh != 1 && d_sh != 4 && d_sh != 9 && d_sh != 16 && d_sh != 25) return 0;
+    if ((long long)H * W * per_ray != (long long)Gv) return 0;
+    return 1;
+}
+
+extern "C" int s360_adapter_forward(const float* extrinsics, const float* depths, const float* raw_gaussians,
+                                    const float* sh_rotation, int32_t n_views, int32_t per_view, int32_t H, int32_t W,
+                                    int32_t per_ray, int32_t d_sh, float scale_min, float scale_max, float eps,
+                                    float* means, float* covariances, int32_t cov9, float* harmonics, float* scales_out,
+                                    float* rotations_out, void* stream) {
+    if (!adapter_args_ok(extrinsics, depths, raw_gaussians, n_views, per_view, H, W, per_ray, d_sh) || !means || !covariances ||
+        !harmonics)
+        return S360_E_BADARG;
+    if (n_views == 0 || per_view == 0) return S360_OK;
+    AdapterParams ap = {n_views, per_view, H, W, per_ray, d_sh, cov9, scale_min, scale_max, eps};
+    hipLaunchKernelGGL(k_adapter_fwd, dim3((per_view + 255) / 256, n_views), dim3(256), 0, (hipStream_t)stream, ap, extrinsics,
+                       depths, raw_gaussians, sh_rotation, means, covariances, harmonics, scales_out, rotations_out);
+    return hipGetLastError() == hipSuccess ? S360_OK : S360_E_LAUNCH;
+}
+
+extern "C" int s360_adapter_backward(const float* extrinsics, const float* depths, const float* raw_gaussians,
+                                     const float* sh_rotation, int32_t n_views, int32_t per_view, int32_t H, int32_t W,
+                                     int32_t per_ray, int32_t d_sh, float scale_min, float scale_max, float eps,
+                                     const float* d_means, const float* d_covariances, int32_t cov9, const float* d_harmonics,
+                                     float* d_depths, float* d_raw_gaussians, void* stream) {
+    if (!adapter_args_ok(extrinsics, depths, raw_gaussians, n_views, per_view, H, W, per_ray, d_sh) || !d_means ||
+        !d_covariances || !d_harmonics || !d_depths || !d_raw_gaussians)
+        return S360_E_BADARG;
+    if (n_views == 0 || per_view == 0) return S360_OK;
+    AdapterParams ap = {n_views, per_view, H, W, per_ray, d_sh, cov9, scale_min, scale_max, eps};
+    hipLaunchKernelGGL(k_adapter_bwd, dim3((per_view + 255) / 256, n_views), dim3(256), 0, (hipStream_t)stream, ap, extrinsics,
+                       depths, raw_gaussians, sh_rotation, d_means, d_covariances, d_harmonics, d_depths, d_raw_gaussians);
+    return hipGetLastError() == hipSuccess ? S360_OK : S360_E_LAUNCH;
+}
