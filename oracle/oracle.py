@@ -63,7 +63,7 @@ def _params_struct(real):
         _fields_ = [("P", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("sh_degree", C.c_int32),
                     ("M", C.c_int32), ("use_sh", C.c_int32), ("tanfovx", real), ("tanfovy", real),
                     ("bg", real * 3), ("viewmatrix", real * 16), ("projmatrix", real * 16),
-                    ("campos", real * 3)]
+                    ("campos", real * 3), ("spherical", C.c_int32)]
     return OrcParams
 
 
@@ -80,7 +80,7 @@ class OracleRasterizer:
 
     def __init__(self, *, image_height, image_width, tanfovx, tanfovy, bg, viewmatrix, projmatrix,
                  sh_degree, campos, means3D, cov3D_precomp, opacities, shs=None,
-                 colors_precomp=None, dtype=np.float32):
+                 colors_precomp=None, dtype=np.float32, spherical=False):
         self.dt = np.dtype(dtype)
         real = C.c_float if self.dt.itemsize == 4 else C.c_double
         self.lib = _lib(self.dt)
@@ -109,6 +109,8 @@ class OracleRasterizer:
         prm.viewmatrix[:] = [float(v) for v in np.asarray(viewmatrix, dtype=self.dt).reshape(16)]
         prm.projmatrix[:] = [float(v) for v in np.asarray(projmatrix, dtype=self.dt).reshape(16)]
         prm.campos[:] = [float(v) for v in np.asarray(campos, dtype=self.dt).reshape(3)]
+        prm.spherical = int(bool(spherical))
+        self.NP = 2 * self.P if spherical else self.P      # rasterised pairs (spherical: Gaussian g + its seam ghost P + g)
         self._prm = prm
         p = lambda arr: arr.ctypes.data if arr is not None else None
         self.h = self.lib.orc_create(C.addressof(prm), p(self.means), p(self.cov6), p(self.opac),
@@ -126,7 +128,7 @@ class OracleRasterizer:
 
     def forward(self) -> dict:
         L = int(self.lib.orc_forward(self.h))
-        P, H, W, dt, lib, h = self.P, self.H, self.W, self.dt, self.lib, self.h
+        P, H, W, dt, lib, h = self.NP, self.H, self.W, self.dt, self.lib, self.h
         out = {
             "num_rendered": L,
             "radii": _view(lib.orc_radii(h), (P,), np.int32),
@@ -165,10 +167,10 @@ class OracleRasterizer:
             "opacities": d_op[:P].reshape(P, 1),
             "shs": None if d_sh is None else d_sh[:P, : self.M],
             "colors_precomp": None if d_col is None else d_col[:P],
-            "raster_xy_pix": _view(lib.orc_grad_xy_pix(h), (P, 2), dt),
-            "raster_conic": _view(lib.orc_grad_conic(h), (P, 3), dt),
-            "raster_opacity": _view(lib.orc_grad_opacity_raster(h), (P,), dt),
-            "raster_rgb": _view(lib.orc_grad_rgb(h), (P, 3), dt),
+            "raster_xy_pix": _view(lib.orc_grad_xy_pix(h), (self.NP, 2), dt),
+            "raster_conic": _view(lib.orc_grad_conic(h), (self.NP, 3), dt),
+            "raster_opacity": _view(lib.orc_grad_opacity_raster(h), (self.NP,), dt),
+            "raster_rgb": _view(lib.orc_grad_rgb(h), (self.NP, 3), dt),
         }
 
 
@@ -179,7 +181,7 @@ def set_parallel_backward(on: bool, dtype=np.float32) -> None:
 
 
 def rasterize(settings: dict, *, means3D, cov3D_precomp, opacities, shs=None, colors_precomp=None,
-              dtype=np.float32) -> OracleRasterizer:
+              dtype=np.float32, spherical=False) -> OracleRasterizer:
     """Convenience: `settings` holds the GaussianRasterizationSettings fields
     (cuda_splatting.py:99-112) as numpy / python values."""
     return OracleRasterizer(
@@ -188,4 +190,4 @@ def rasterize(settings: dict, *, means3D, cov3D_precomp, opacities, shs=None, co
         viewmatrix=settings["viewmatrix"], projmatrix=settings["projmatrix"],
         sh_degree=settings["sh_degree"], campos=settings["campos"], means3D=means3D,
         cov3D_precomp=cov3D_precomp, opacities=opacities, shs=shs, colors_precomp=colors_precomp,
-        dtype=dtype)
+        dtype=dtype, spherical=spherical)

@@ -75,10 +75,13 @@ typedef struct {
     real viewmatrix[16]; /* as handed over by cuda_splatting.py:86 (transposed w2c, flat) */
     real projmatrix[16]; /* cuda_splatting.py:87 */
     real campos[3];      /* cuda_splatting.py:109 */
+    int32_t spherical;   /* 0: perspective (the reference's path); 1: native equirectangular splat mode (no
+                            reference counterpart — specified by this file, see geo_sph) */
 } OrcParams;
 
 typedef struct {
     OrcParams prm;
+    int32_t NP;  /* rasterised pairs: P (perspective) or 2P (spherical: Gaussian g and its seam ghost P + g) */
     /* inputs (borrowed copies) */
     real *means, *cov6, *opac, *shs, *colors_in;
     /* per-Gaussian forward state */
@@ -233,6 +236,153 @@ static void geo_compute(const OrcParams* p, const real* mean, const real* c6, Ge
     g->c += R(0.3);
 }
 
+/* ====================================================================================================
+ * Native equirectangular ("spherical") splat mode — SURVEY.md 8(f)-4.  NO reference counterpart (the reference only
+ * ever renders cube faces); this is the specification the HIP kernels are tested against.
+ *   camera frame = panorama frame of the encoder's ERP rays (src/geometry/utils360.py:93-104,148-153):
+ *     theta = atan2(t.x, t.z), phi = atan2(t.y, rho), rho = sqrt(t.x^2 + t.z^2), r = |t|
+ *     pixel (centres at integer coordinates): u = (0.5 - theta / 2pi) W - 0.5,  v = (0.5 - phi / pi) H - 0.5
+ *   EWA with the Jacobian of (u, v) w.r.t. t; near the poles rho is clamped to 0.05 r INSIDE THE JACOBIAN only (the
+ *   role the 1.3 tan(fov) clamp plays in the perspective path); +0.3 dilation, conic, radius, 16x16 tile rect, sort
+ *   key (float bits of the RADIAL distance r), cull r <= 0.2 and the composite are those of the perspective path.
+ *   Seam: a Gaussian is splatted at u in [0, W) ("main" pair g) and, when its radius < W/2, once more at u +- W
+ *   ("ghost" pair P + g) so that footprints crossing the +-pi seam appear on both sides; both pairs go through the
+ *   ordinary clipped tile rectangle, share the image, and their gradients add.
+ *   atan2 is evaluated with IEEE add / mul / div / sqrt only (two half-angle reductions + a 5-term series, |err| < 1e-7
+ *   rad) so that the float32 oracle and the HIP kernel agree bit for bit on every integer intermediate.
+ * ==================================================================================================== */
+static inline real s_atan_small(real z) { /* |z| <= tan(pi/16) */
+    real z2 = z * z;
+    return z * (R(1) + z2 * (R(-0.3333333333333333) + z2 * (R(0.2) + z2 * (R(-0.14285714285714285) + z2 * R(0.1111111111111111)))));
+}
+static inline real s_atan_unit(real z) { /* 0 <= z <= 1 */
+    real z1 = z / (R(1) + r_sqrt(R(1) + z * z));
+    real z2 = z1 / (R(1) + r_sqrt(R(1) + z1 * z1));
+    return R(4) * s_atan_small(z2);
+}
+static inline real s_atan2(real y, real x) {
+    real ax = x < R(0) ? -x : x, ay = y < R(0) ? -y : y;
+    if (ax == R(0) && ay == R(0)) return R(0);
+    int swap = ay > ax;
+    real a = s_atan_unit(swap ? ax / ay : ay / ax);
+    if (swap) a = R(1.5707963267948966) - a;
+    if (x < R(0)) a = R(3.141592653589793) - a;
+    return y < R(0) ? -a : a;
+}
+
+typedef struct {
+    real t[3], r2, r, rho2, rho, rc;
+    int clamped;
+    real u, v;          /* pixel coordinates of the main copy */
+    real J0[3], J1[3];  /* rows of d(u,v)/dt (J0[1] == 0) */
+    real M0[3], M1[3], v0[3], v1[3];
+    real a, b, c;
+} GeoS;
+
+static void geo_sph(const OrcParams* p, const real* mean, const real* c6, GeoS* g) {
+    const real* V = p->viewmatrix;
+    xform43(V, mean, g->t);
+    const real t0 = g->t[0], t1 = g->t[1], t2 = g->t[2];
+    g->rho2 = t0 * t0 + t2 * t2;
+    g->r2 = g->rho2 + t1 * t1;
+    g->r = r_sqrt(g->r2);
+    g->rho = r_sqrt(g->rho2);
+    g->clamped = g->rho < R(0.05) * g->r;
+    g->rc = g->clamped ? R(0.05) * g->r : g->rho;
+    const real theta = s_atan2(t0, t2), phi = s_atan2(t1, g->rho);
+    g->u = (R(0.5) - theta / R(6.283185307179586)) * (real)p->W - R(0.5);
+    g->v = (R(0.5) - phi / R(3.141592653589793)) * (real)p->H - R(0.5);
+    const real c0 = -(real)p->W / R(6.283185307179586), c1 = -(real)p->H / R(3.141592653589793);
+    const real A = R(1) / (g->rc * g->rc), Bq = R(1) / (g->r2 * g->rc), Cq = g->rc / g->r2;
+    g->J0[0] = c0 * t2 * A; g->J0[1] = R(0); g->J0[2] = -(c0 * t0 * A);
+    g->J1[0] = -(c1 * t0 * t1 * Bq); g->J1[1] = c1 * Cq; g->J1[2] = -(c1 * t2 * t1 * Bq);
+    for (int j = 0; j < 3; ++j) {
+        g->M0[j] = g->J0[0] * V[j * 4 + 0] + g->J0[2] * V[j * 4 + 2];
+        g->M1[j] = g->J1[0] * V[j * 4 + 0] + g->J1[1] * V[j * 4 + 1] + g->J1[2] * V[j * 4 + 2];
+    }
+    real S[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+    for (int k = 0; k < 3; ++k) {
+        g->v0[k] = S[k][0] * g->M0[0] + S[k][1] * g->M0[1] + S[k][2] * g->M0[2];
+        g->v1[k] = S[k][0] * g->M1[0] + S[k][1] * g->M1[1] + S[k][2] * g->M1[2];
+    }
+    g->a = g->M0[0] * g->v0[0] + g->M0[1] * g->v0[1] + g->M0[2] * g->v0[2];
+    g->b = g->M1[0] * g->v0[0] + g->M1[1] * g->v0[1] + g->M1[2] * g->v0[2];
+    g->c = g->M1[0] * g->v1[0] + g->M1[1] * g->v1[1] + g->M1[2] * g->v1[2];
+    g->a += R(0.3);
+    g->c += R(0.3);
+}
+
+static void shade_one(Orc* o, int i, int gi) {  /* colour of pair i from Gaussian gi (shared by both projection modes) */
+    const OrcParams* p = &o->prm;
+    const real* mean = o->means + 3 * gi;
+    if (p->use_sh) {
+        real d[3] = {mean[0] - p->campos[0], mean[1] - p->campos[1], mean[2] - p->campos[2]};
+        real inv = R(1) / r_sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        real x = d[0] * inv, y = d[1] * inv, z = d[2] * inv;
+        real Y[25];
+        sh_basis(p->sh_degree, x, y, z, Y);
+        int n = (p->sh_degree + 1) * (p->sh_degree + 1);
+        const real* sh = o->shs + (size_t)gi * p->M * 3;
+        for (int c = 0; c < 3; ++c) {
+            real acc = R(0);
+            for (int k = 0; k < n; ++k) acc += Y[k] * sh[k * 3 + c];
+            acc += R(0.5);
+            o->clamped[3 * i + c] = acc < R(0);
+            o->rgb[3 * i + c] = r_max(acc, R(0));
+        }
+    } else {
+        for (int c = 0; c < 3; ++c) {
+            o->rgb[3 * i + c] = o->colors_in[3 * gi + c];
+            o->clamped[3 * i + c] = 0;
+        }
+    }
+}
+
+static void preprocess_one_sph(Orc* o, int i) {  /* i in [0, 2P): pair; ghost pairs are i >= P */
+    const OrcParams* p = &o->prm;
+    const int gi = i % p->P, ghost = i >= p->P;
+    o->radii[i] = 0;
+    o->tiles_touched[i] = 0;
+    const real* mean = o->means + 3 * gi;
+    GeoS g;
+    geo_sph(p, mean, o->cov6 + 6 * gi, &g);
+    if (g.r <= R(0.2)) return;
+    real det = g.a * g.c - g.b * g.b;
+    if (det == R(0)) return;
+    real det_inv = R(1) / det;
+    real conA = g.c * det_inv, conB = -g.b * det_inv, conC = g.a * det_inv;
+    real mid = R(0.5) * (g.a + g.c);
+    real sq = r_sqrt(r_max(R(0.1), mid * mid - det));
+    real lam1 = mid + sq, lam2 = mid - sq;
+    int radius = r2i(r_ceil(R(3) * r_sqrt(r_max(lam1, lam2))));
+    real px = g.u, py = g.v;
+    if (ghost) {
+        if (radius >= p->W / 2) return; /* a footprint wider than half the panorama keeps its main copy only */
+        px = px < R(0.5) * (real)p->W ? px + (real)p->W : px - (real)p->W;
+    }
+    int gx = (p->W + TILE - 1) / TILE, gy = (p->H + TILE - 1) / TILE;
+    real rr = (real)radius;
+    int minx = i_min(gx, i_max(0, r2i((px - rr) / R(TILE))));
+    int miny = i_min(gy, i_max(0, r2i((py - rr) / R(TILE))));
+    int maxx = i_min(gx, i_max(0, r2i((px + rr + R(TILE - 1)) / R(TILE))));
+    int maxy = i_min(gy, i_max(0, r2i((py + rr + R(TILE - 1)) / R(TILE))));
+    if ((maxx - minx) * (maxy - miny) == 0) return;
+    shade_one(o, i, gi);
+    o->depth[i] = g.r;
+    o->radii[i] = radius;
+    o->xy[2 * i] = px;
+    o->xy[2 * i + 1] = py;
+    o->conic_op[4 * i + 0] = conA;
+    o->conic_op[4 * i + 1] = conB;
+    o->conic_op[4 * i + 2] = conC;
+    o->conic_op[4 * i + 3] = o->opac[gi];
+    o->rect[4 * i + 0] = minx;
+    o->rect[4 * i + 1] = miny;
+    o->rect[4 * i + 2] = maxx;
+    o->rect[4 * i + 3] = maxy;
+    o->tiles_touched[i] = (uint32_t)((maxx - minx) * (maxy - miny));
+}
+
 static void preprocess_one(Orc* o, int i) {
     const OrcParams* p = &o->prm;
     o->radii[i] = 0;
@@ -327,7 +477,7 @@ static void bin_and_sort(Orc* o) {
     const OrcParams* p = &o->prm;
     int gx = (p->W + TILE - 1) / TILE, gy = (p->H + TILE - 1) / TILE;
     uint64_t run = 0;
-    for (int i = 0; i < p->P; ++i) {
+    for (int i = 0; i < o->NP; ++i) {
         run += o->tiles_touched[i];
         o->offsets[i] = (uint32_t)run;
     }
@@ -338,7 +488,7 @@ static void bin_and_sort(Orc* o) {
     Inst* inst = (Inst*)malloc((run ? run : 1) * sizeof(Inst));
     Inst* tmp = (Inst*)malloc((run ? run : 1) * sizeof(Inst));
     size_t k = 0;
-    for (int i = 0; i < p->P; ++i) {
+    for (int i = 0; i < o->NP; ++i) {
         if (o->radii[i] <= 0) continue;
         const int32_t* r = o->rect + 4 * i;
         for (int y = r[1]; y < r[3]; ++y)
@@ -408,6 +558,7 @@ EXPORT Orc* orc_create(const OrcParams* prm, const real* means, const real* cov6
     Orc* o = (Orc*)calloc(1, sizeof(Orc));
     o->prm = *prm;
     int P = prm->P;
+    o->NP = prm->spherical ? 2 * P : P;
     size_t np = (size_t)(P ? P : 1);
     o->means = (real*)malloc(np * 3 * sizeof(real)); memcpy(o->means, means, (size_t)P * 3 * sizeof(real));
     o->cov6 = (real*)malloc(np * 6 * sizeof(real)); memcpy(o->cov6, cov6, (size_t)P * 6 * sizeof(real));
@@ -418,6 +569,7 @@ EXPORT Orc* orc_create(const OrcParams* prm, const real* means, const real* cov6
     } else {
         o->colors_in = (real*)malloc(np * 3 * sizeof(real)); memcpy(o->colors_in, colors, (size_t)P * 3 * sizeof(real));
     }
+    np = (size_t)(o->NP ? o->NP : 1); /* per-pair state from here on */
     o->radii = (int32_t*)calloc(np, sizeof(int32_t));
     o->tiles_touched = (uint32_t*)calloc(np, sizeof(uint32_t));
     o->offsets = (uint32_t*)calloc(np, sizeof(uint32_t));
@@ -452,7 +604,9 @@ EXPORT void orc_destroy(Orc* o) {
 
 EXPORT uint64_t orc_forward(Orc* o) {
 #pragma omp parallel for schedule(static, 1024)
-    for (int i = 0; i < o->prm.P; ++i) preprocess_one(o, i);
+    for (int i = 0; i < o->NP; ++i) {
+        if (o->prm.spherical) preprocess_one_sph(o, i); else preprocess_one(o, i);
+    }
     bin_and_sort(o);
     render_forward(o);
     return o->L;
@@ -480,6 +634,116 @@ EXPORT const real* orc_grad_conic(Orc* o) { return o->g_conic; }
 EXPORT const real* orc_grad_opacity_raster(Orc* o) { return o->g_op; }
 EXPORT const real* orc_grad_rgb(Orc* o) { return o->g_rgb; }
 
+/* Per-Gaussian backward of the spherical mode: raster gradients of the main pair i and the ghost pair P + i add (the
+ * ghost's centre is the main one shifted by a constant), then chain through geo_sph.  d_means2D = (dL/du, dL/dv, 0)
+ * in PIXEL units. */
+static void backward_one_sph(Orc* o, int i, real* dm, real* dm2, real* dc, real* dsh, real* dcol, real* dop) {
+    const OrcParams* p = &o->prm;
+    const int P = p->P, j2 = P + i;
+    const int vis0 = o->radii[i] > 0, vis1 = o->radii[j2] > 0;
+    if (!vis0 && !vis1) return;
+    real gxy[2] = {R(0), R(0)}, gcon[3] = {R(0), R(0), R(0)}, grgb[3] = {R(0), R(0), R(0)}, gop = R(0);
+    const int ids[2] = {i, j2};
+    for (int q = 0; q < 2; ++q) {
+        if (!(q ? vis1 : vis0)) continue;
+        const int id = ids[q];
+        gxy[0] += o->g_xy[2 * id]; gxy[1] += o->g_xy[2 * id + 1];
+        for (int k = 0; k < 3; ++k) gcon[k] += o->g_conic[3 * id + k];
+        for (int k = 0; k < 3; ++k) grgb[k] += o->clamped[3 * id + k] && p->use_sh ? R(0) : o->g_rgb[3 * id + k];
+        gop += o->g_op[id];
+    }
+    *dop = gop;
+    dm2[0] = gxy[0]; dm2[1] = gxy[1]; dm2[2] = R(0);
+    const real* mean = o->means + 3 * i;
+    GeoS g;
+    geo_sph(p, mean, o->cov6 + 6 * i, &g);
+    real a = g.a, b = g.b, c = g.c;
+    real det = a * c - b * b;
+    real d2inv = R(1) / (det * det + R(0.0000001));
+    real gA = gcon[0], gB = gcon[1], gC = gcon[2];
+    real dL_da = R(0), dL_db = R(0), dL_dc = R(0);
+    if (d2inv != R(0)) {
+        dL_da = d2inv * (-c * c * gA + b * c * gB + (det - a * c) * gC);
+        dL_dc = d2inv * (-a * a * gC + a * b * gB + (det - a * c) * gA);
+        dL_db = d2inv * (R(2) * b * c * gA - (det + R(2) * b * b) * gB + R(2) * a * b * gC);
+        const real *M0 = g.M0, *M1 = g.M1;
+        dc[0] = M0[0] * M0[0] * dL_da + M0[0] * M1[0] * dL_db + M1[0] * M1[0] * dL_dc;
+        dc[3] = M0[1] * M0[1] * dL_da + M0[1] * M1[1] * dL_db + M1[1] * M1[1] * dL_dc;
+        dc[5] = M0[2] * M0[2] * dL_da + M0[2] * M1[2] * dL_db + M1[2] * M1[2] * dL_dc;
+        dc[1] = R(2) * M0[0] * M0[1] * dL_da + (M0[0] * M1[1] + M0[1] * M1[0]) * dL_db + R(2) * M1[0] * M1[1] * dL_dc;
+        dc[2] = R(2) * M0[0] * M0[2] * dL_da + (M0[0] * M1[2] + M0[2] * M1[0]) * dL_db + R(2) * M1[0] * M1[2] * dL_dc;
+        dc[4] = R(2) * M0[1] * M0[2] * dL_da + (M0[1] * M1[2] + M0[2] * M1[1]) * dL_db + R(2) * M1[1] * M1[2] * dL_dc;
+    }
+    real dM0[3], dM1[3];
+    for (int j = 0; j < 3; ++j) {
+        dM0[j] = R(2) * dL_da * g.v0[j] + dL_db * g.v1[j];
+        dM1[j] = R(2) * dL_dc * g.v1[j] + dL_db * g.v0[j];
+    }
+    const real* V = p->viewmatrix;
+    real dJ00 = R(0), dJ02 = R(0), dJ10 = R(0), dJ11 = R(0), dJ12 = R(0);
+    for (int j = 0; j < 3; ++j) {
+        dJ00 += dM0[j] * V[j * 4 + 0];
+        dJ02 += dM0[j] * V[j * 4 + 2];
+        dJ10 += dM1[j] * V[j * 4 + 0];
+        dJ11 += dM1[j] * V[j * 4 + 1];
+        dJ12 += dM1[j] * V[j * 4 + 2];
+    }
+    const real t0 = g.t[0], t1 = g.t[1], t2 = g.t[2], rc = g.rc, r2 = g.r2;
+    const real c0 = -(real)p->W / R(6.283185307179586), c1 = -(real)p->H / R(3.141592653589793);
+    const real A = R(1) / (rc * rc), Bq = R(1) / (r2 * rc);
+    /* J00 = c0 t2 A, J02 = -c0 t0 A, J10 = -c1 t0 t1 Bq, J11 = c1 rc / r2, J12 = -c1 t2 t1 Bq */
+    real dt[3];
+    dt[0] = -(c0 * A) * dJ02 - (c1 * t1 * Bq) * dJ10;
+    dt[1] = -(c1 * Bq) * (t0 * dJ10 + t2 * dJ12);
+    dt[2] = (c0 * A) * dJ00 - (c1 * t1 * Bq) * dJ12;
+    const real dA = c0 * (dJ00 * t2 - dJ02 * t0);
+    const real dB = -(c1 * t1) * (dJ10 * t0 + dJ12 * t2);
+    const real dC = c1 * dJ11;
+    const real drc = dA * (-R(2) / (rc * rc * rc)) + dB * (-R(1) / (r2 * rc * rc)) + dC / r2;
+    const real dr2 = dB * (-R(1) / (r2 * r2 * rc)) + dC * (-rc / (r2 * r2));
+    for (int k = 0; k < 3; ++k) dt[k] += R(2) * g.t[k] * dr2;
+    if (g.clamped) {
+        for (int k = 0; k < 3; ++k) dt[k] += drc * (R(0.05) * g.t[k] / g.r);
+    } else {
+        dt[0] += drc * (t0 / g.rho);
+        dt[2] += drc * (t2 / g.rho);
+    }
+    /* centre: (u, v) with the TRUE rho */
+    const real iu = c0 / g.rho2, iv = c1 / (r2 * g.rho);
+    dt[0] += gxy[0] * (iu * t2) + gxy[1] * (-(iv * t0 * t1));
+    dt[1] += gxy[1] * (c1 * g.rho / r2);
+    dt[2] += gxy[0] * (-(iu * t0)) + gxy[1] * (-(iv * t2 * t1));
+    for (int j = 0; j < 3; ++j) dm[j] = V[j * 4 + 0] * dt[0] + V[j * 4 + 1] * dt[1] + V[j * 4 + 2] * dt[2];
+    if (!p->use_sh) {
+        if (dcol) for (int cc = 0; cc < 3; ++cc) dcol[cc] = grgb[cc];
+    } else if (dsh) {
+        real d[3] = {mean[0] - p->campos[0], mean[1] - p->campos[1], mean[2] - p->campos[2]};
+        real len = r_sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        real inv = R(1) / len;
+        real x = d[0] * inv, y = d[1] * inv, z = d[2] * inv;
+        real Y[25], bx[25], by[25], bz[25];
+        sh_basis(p->sh_degree, x, y, z, Y);
+        sh_basis_grad(p->sh_degree, x, y, z, bx, by, bz);
+        int n = (p->sh_degree + 1) * (p->sh_degree + 1);
+        const real* sh = o->shs + (size_t)i * p->M * 3;
+        real ddir[3] = {R(0), R(0), R(0)};
+        for (int k = 0; k < n; ++k) {
+            real s_ = R(0);
+            for (int cc = 0; cc < 3; ++cc) {
+                dsh[k * 3 + cc] = Y[k] * grgb[cc];
+                s_ += sh[k * 3 + cc] * grgb[cc];
+            }
+            ddir[0] += bx[k] * s_;
+            ddir[1] += by[k] * s_;
+            ddir[2] += bz[k] * s_;
+        }
+        real dot = x * ddir[0] + y * ddir[1] + z * ddir[2];
+        dm[0] += (ddir[0] - x * dot) * inv;
+        dm[1] += (ddir[1] - y * dot) * inv;
+        dm[2] += (ddir[2] - z * dot) * inv;
+    }
+}
+
 /*
  * Backward (Appendix A.4).  dL_dimage is [3,H,W].  Outputs (caller-allocated):
  *   d_means3D[P,3], d_means2D[P,3] (NDC-scaled: pixel gradient * (0.5W, 0.5H), z = 0),
@@ -496,10 +760,10 @@ EXPORT void orc_backward(Orc* o, const real* dL_dimage, real* d_means3D, real* d
     const OrcParams* p = &o->prm;
     int P = p->P, H = p->H, W = p->W;
     int gx = (W + TILE - 1) / TILE;
-    memset(o->g_xy, 0, sizeof(real) * 2 * (size_t)P);
-    memset(o->g_conic, 0, sizeof(real) * 3 * (size_t)P);
-    memset(o->g_op, 0, sizeof(real) * (size_t)P);
-    memset(o->g_rgb, 0, sizeof(real) * 3 * (size_t)P);
+    memset(o->g_xy, 0, sizeof(real) * 2 * (size_t)o->NP);
+    memset(o->g_conic, 0, sizeof(real) * 3 * (size_t)o->NP);
+    memset(o->g_op, 0, sizeof(real) * (size_t)o->NP);
+    memset(o->g_rgb, 0, sizeof(real) * 3 * (size_t)o->NP);
     /* --- render backward: back-to-front replay per pixel --- */
     const int par = g_parallel_backward;
 #define ACC(dst, val) do { real v_ = (val); if (par) { _Pragma("omp atomic") dst += v_; } else dst += v_; } while (0)
@@ -560,6 +824,11 @@ EXPORT void orc_backward(Orc* o, const real* dL_dimage, real* d_means3D, real* d
         d_opacity[i] = R(0);
         if (d_sh) for (int k = 0; k < p->M * 3; ++k) d_sh[(size_t)i * p->M * 3 + k] = R(0);
         if (d_colors) d_colors[3 * i] = d_colors[3 * i + 1] = d_colors[3 * i + 2] = R(0);
+        if (p->spherical) {
+            backward_one_sph(o, i, dm, d_means2D + 3 * i, d_cov6 + 6 * i, d_sh ? d_sh + (size_t)i * p->M * 3 : NULL,
+                             d_colors ? d_colors + 3 * i : NULL, d_opacity + i);
+            continue;
+        }
         if (o->radii[i] <= 0) continue;
         const real* mean = o->means + 3 * i;
         d_opacity[i] = o->g_op[i];
