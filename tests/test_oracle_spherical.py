@@ -123,6 +123,10 @@ def test_spherical_render_agrees_with_the_cube_render_away_from_the_poles():
     vol = torch.stack(list(c), 1)[None]
     grid = stitch.Cube2Equirec(fw, h, w).sample_grid
     erp_cube = torch.nn.functional.grid_sample(vol, grid, padding_mode="border", align_corners=True)[0, :, 0].numpy()
+    corr = lambda a, b: float(np.corrcoef(a.ravel(), b.ravel())[0, 1])
     band = slice(h // 2 - 8, h // 2 + 8)
-    diff = np.abs(f["image"][:, band] - erp_cube[:, band])
-    assert diff.mean() < 0.03 and f["image"][:, band].mean() > 0.05, (diff.mean(), f["image"][:, band].mean())
+    a = f["image"]
+    assert corr(a[:, band], erp_cube[:, band]) > 0.97 and corr(a, erp_cube) > 0.95          # measured 0.981 / 0.965
+    # and it is THIS alignment: mirrored or shifted variants decorrelate
+    assert corr(a[:, :, ::-1], erp_cube) < 0.5 and corr(a[:, ::-1], erp_cube) < 0.5
+    assert all(corr(np.roll(a, sft, axis=2), erp_cube) < corr(a, erp_cube) - 0.05 for sft in (-1, 1))
