@@ -68,6 +68,16 @@ enum {
                                          default (flag clear) = the standard real-SH degree-4 table, this flag = the
                                          behaviour of a fork that stops at the upstream 3DGS degree 3. */
 
+#define S360_FLAG_SPHERICAL 32u        /* native equirectangular splat mode (NO reference counterpart — the
+                                         reference only ever renders cube faces — specified by oracle/s360_oracle.c geo_sph):
+                                         every image is an H x W equirectangular panorama rendered with the spherical
+                                         projection of the encoder's ERP ray convention (src/geometry/utils360.py:93-104,
+                                         148-153) and its Jacobian; views come in PAIRS (2i = the panorama camera, 2i+1 = its
+                                         seam ghost: the same camera, splat centres shifted by +-W), V must be even, the call
+                                         renders V/2 images [V/2,3,H,W]; viewmatrix = inverse(panorama c2w)^T, projmatrix
+                                         and tanfov are ignored; sort key and near cull use the RADIAL distance;
+                                         d_means2D is in pixel units */
+
 typedef struct S360View {
     float viewmatrix[16];
     float projmatrix[16];

@@ -25,6 +25,7 @@ FLAG_COV9 = 2
 FLAG_SH_CHANNEL_MAJOR = 4
 FLAG_FORWARD_ONLY = 8
 FLAG_SH_DEG4_IGNORED = 16
+FLAG_SPHERICAL = 32
 ABI_VERSION = 10
 
 

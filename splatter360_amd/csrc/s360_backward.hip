@@ -137,59 +137,121 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess_bwd(
                     dm2 += Vm[10] * dzu;
                 }
                 const float* V = vw.viewmatrix;
-                Geo ge;
-                geo_compute(V, vw.tanfovx, vw.tanfovy, kp.W, kp.H, mx, my, mz, c6, ge);
-                const float a = ge.a, b = ge.b, c = ge.c;
-                const float det = a * c - b * b;
-                const float d2inv = 1.0f / (det * det + 0.0000001f);
-                float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
-                if (d2inv != 0.f) {
-                    dL_da = d2inv * (-c * c * gA + b * c * gB + (det - a * c) * gC);
-                    dL_dc = d2inv * (-a * a * gC + a * b * gB + (det - a * c) * gA);
-                    dL_db = d2inv * (2.f * b * c * gA - (det + 2.f * b * b) * gB + 2.f * a * b * gC);
-                    const float *M0 = ge.M0, *M1 = ge.M1;
-                    dcv[0] += M0[0] * M0[0] * dL_da + M0[0] * M1[0] * dL_db + M1[0] * M1[0] * dL_dc;
-                    dcv[3] += M0[1] * M0[1] * dL_da + M0[1] * M1[1] * dL_db + M1[1] * M1[1] * dL_dc;
-                    dcv[5] += M0[2] * M0[2] * dL_da + M0[2] * M1[2] * dL_db + M1[2] * M1[2] * dL_dc;
-                    dcv[1] += 2.f * M0[0] * M0[1] * dL_da + (M0[0] * M1[1] + M0[1] * M1[0]) * dL_db + 2.f * M1[0] * M1[1] * dL_dc;
-                    dcv[2] += 2.f * M0[0] * M0[2] * dL_da + (M0[0] * M1[2] + M0[2] * M1[0]) * dL_db + 2.f * M1[0] * M1[2] * dL_dc;
-                    dcv[4] += 2.f * M0[1] * M0[2] * dL_da + (M0[1] * M1[2] + M0[2] * M1[1]) * dL_db + 2.f * M1[1] * M1[2] * dL_dc;
-                }
-                float dM0[3], dM1[3];
+                if (kp.flags & S360_FLAG_SPHERICAL) {
+                    // native equirectangular splat: chain through geo_sph (oracle backward_one_sph)
+                    GeoS gs;
+                    geo_sph(V, kp.W, kp.H, mx, my, mz, c6, gs);
+                    const float a = gs.a, b = gs.b, c = gs.c;
+                    const float det = a * c - b * b;
+                    const float d2inv = 1.0f / (det * det + 0.0000001f);
+                    float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
+                    if (d2inv != 0.f) {
+                        dL_da = d2inv * (-c * c * gA + b * c * gB + (det - a * c) * gC);
+                        dL_dc = d2inv * (-a * a * gC + a * b * gB + (det - a * c) * gA);
+                        dL_db = d2inv * (2.f * b * c * gA - (det + 2.f * b * b) * gB + 2.f * a * b * gC);
+                        const float *M0 = gs.M0, *M1 = gs.M1;
+                        dcv[0] += M0[0] * M0[0] * dL_da + M0[0] * M1[0] * dL_db + M1[0] * M1[0] * dL_dc;
+                        dcv[3] += M0[1] * M0[1] * dL_da + M0[1] * M1[1] * dL_db + M1[1] * M1[1] * dL_dc;
+                        dcv[5] += M0[2] * M0[2] * dL_da + M0[2] * M1[2] * dL_db + M1[2] * M1[2] * dL_dc;
+                        dcv[1] += 2.f * M0[0] * M0[1] * dL_da + (M0[0] * M1[1] + M0[1] * M1[0]) * dL_db + 2.f * M1[0] * M1[1] * dL_dc;
+                        dcv[2] += 2.f * M0[0] * M0[2] * dL_da + (M0[0] * M1[2] + M0[2] * M1[0]) * dL_db + 2.f * M1[0] * M1[2] * dL_dc;
+                        dcv[4] += 2.f * M0[1] * M0[2] * dL_da + (M0[1] * M1[2] + M0[2] * M1[1]) * dL_db + 2.f * M1[1] * M1[2] * dL_dc;
+                    }
+                    float dJ00 = 0.f, dJ02 = 0.f, dJ10 = 0.f, dJ11 = 0.f, dJ12 = 0.f;
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    dM0[j] = 2.f * dL_da * ge.v0[j] + dL_db * ge.v1[j];
-                    dM1[j] = 2.f * dL_dc * ge.v1[j] + dL_db * ge.v0[j];
-                }
-                float dJ00 = 0.f, dJ02 = 0.f, dJ11 = 0.f, dJ12 = 0.f;
+                    for (int j = 0; j < 3; ++j) {
+                        const float dM0 = 2.f * dL_da * gs.v0[j] + dL_db * gs.v1[j];
+                        const float dM1 = 2.f * dL_dc * gs.v1[j] + dL_db * gs.v0[j];
+                        dJ00 += dM0 * V[j * 4 + 0];
+                        dJ02 += dM0 * V[j * 4 + 2];
+                        dJ10 += dM1 * V[j * 4 + 0];
+                        dJ11 += dM1 * V[j * 4 + 1];
+                        dJ12 += dM1 * V[j * 4 + 2];
+                    }
+                    const float t0 = gs.t0, t1 = gs.t1, t2 = gs.t2, rc = gs.rc, r2 = gs.r2;
+                    const float c0 = -(float)kp.W / 6.283185307179586f, c1 = -(float)kp.H / 3.141592653589793f;
+                    const float A = 1.0f / (rc * rc), Bq = 1.0f / (r2 * rc);
+                    float dt0 = -(c0 * A) * dJ02 - (c1 * t1 * Bq) * dJ10;
+                    float dt1 = -(c1 * Bq) * (t0 * dJ10 + t2 * dJ12);
+                    float dt2 = (c0 * A) * dJ00 - (c1 * t1 * Bq) * dJ12;
+                    const float dA = c0 * (dJ00 * t2 - dJ02 * t0);
+                    const float dB = -(c1 * t1) * (dJ10 * t0 + dJ12 * t2);
+                    const float dC = c1 * dJ11;
+                    const float drc = dA * (-2.0f / (rc * rc * rc)) + dB * (-1.0f / (r2 * rc * rc)) + dC / r2;
+                    const float dr2 = dB * (-1.0f / (r2 * r2 * rc)) + dC * (-rc / (r2 * r2));
+                    dt0 += 2.0f * t0 * dr2;
+                    dt1 += 2.0f * t1 * dr2;
+                    dt2 += 2.0f * t2 * dr2;
+                    if (gs.clamped) {
+                        dt0 += drc * (0.05f * t0 / gs.r);
+                        dt1 += drc * (0.05f * t1 / gs.r);
+                        dt2 += drc * (0.05f * t2 / gs.r);
+                    } else {
+                        dt0 += drc * (t0 / gs.rho);
+                        dt2 += drc * (t2 / gs.rho);
+                    }
+                    const float iu = c0 / gs.rho2, iv = c1 / (r2 * gs.rho);   // centre: (u, v) with the TRUE rho; pixel units
+                    dt0 += gx_ * (iu * t2) + gy_ * (-(iv * t0 * t1));
+                    dt1 += gy_ * (c1 * gs.rho / r2);
+                    dt2 += gx_ * (-(iu * t0)) + gy_ * (-(iv * t2 * t1));
+                    dmv0 += V[0] * dt0 + V[1] * dt1 + V[2] * dt2;
+                    dmv1 += V[4] * dt0 + V[5] * dt1 + V[6] * dt2;
+                    dmv2 += V[8] * dt0 + V[9] * dt1 + V[10] * dt2;
+                } else {
+                    Geo ge;
+                    geo_compute(V, vw.tanfovx, vw.tanfovy, kp.W, kp.H, mx, my, mz, c6, ge);
+                    const float a = ge.a, b = ge.b, c = ge.c;
+                    const float det = a * c - b * b;
+                    const float d2inv = 1.0f / (det * det + 0.0000001f);
+                    float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
+                    if (d2inv != 0.f) {
+                        dL_da = d2inv * (-c * c * gA + b * c * gB + (det - a * c) * gC);
+                        dL_dc = d2inv * (-a * a * gC + a * b * gB + (det - a * c) * gA);
+                        dL_db = d2inv * (2.f * b * c * gA - (det + 2.f * b * b) * gB + 2.f * a * b * gC);
+                        const float *M0 = ge.M0, *M1 = ge.M1;
+                        dcv[0] += M0[0] * M0[0] * dL_da + M0[0] * M1[0] * dL_db + M1[0] * M1[0] * dL_dc;
+                        dcv[3] += M0[1] * M0[1] * dL_da + M0[1] * M1[1] * dL_db + M1[1] * M1[1] * dL_dc;
+                        dcv[5] += M0[2] * M0[2] * dL_da + M0[2] * M1[2] * dL_db + M1[2] * M1[2] * dL_dc;
+                        dcv[1] += 2.f * M0[0] * M0[1] * dL_da + (M0[0] * M1[1] + M0[1] * M1[0]) * dL_db + 2.f * M1[0] * M1[1] * dL_dc;
+                        dcv[2] += 2.f * M0[0] * M0[2] * dL_da + (M0[0] * M1[2] + M0[2] * M1[0]) * dL_db + 2.f * M1[0] * M1[2] * dL_dc;
+                        dcv[4] += 2.f * M0[1] * M0[2] * dL_da + (M0[1] * M1[2] + M0[2] * M1[1]) * dL_db + 2.f * M1[1] * M1[2] * dL_dc;
+                    }
+                    float dM0[3], dM1[3];
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    dJ00 += dM0[j] * V[j * 4 + 0];
-                    dJ02 += dM0[j] * V[j * 4 + 2];
-                    dJ11 += dM1[j] * V[j * 4 + 1];
-                    dJ12 += dM1[j] * V[j * 4 + 2];
+                    for (int j = 0; j < 3; ++j) {
+                        dM0[j] = 2.f * dL_da * ge.v0[j] + dL_db * ge.v1[j];
+                        dM1[j] = 2.f * dL_dc * ge.v1[j] + dL_db * ge.v0[j];
+                    }
+                    float dJ00 = 0.f, dJ02 = 0.f, dJ11 = 0.f, dJ12 = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        dJ00 += dM0[j] * V[j * 4 + 0];
+                        dJ02 += dM0[j] * V[j * 4 + 2];
+                        dJ11 += dM1[j] * V[j * 4 + 1];
+                        dJ12 += dM1[j] * V[j * 4 + 2];
+                    }
+                    const float tz = 1.f / ge.tz, tz2 = tz * tz, tz3 = tz2 * tz;
+                    const float dt0 = (ge.xin ? 1.f : 0.f) * (-ge.fx * tz2 * dJ02);
+                    const float dt1 = (ge.yin ? 1.f : 0.f) * (-ge.fy * tz2 * dJ12);
+                    const float dt2 = -ge.fx * tz2 * dJ00 - ge.fy * tz2 * dJ11 + (2.f * ge.fx * ge.txc) * tz3 * dJ02 +
+                                      (2.f * ge.fy * ge.tyc) * tz3 * dJ12;
+                    dmv0 += V[0] * dt0 + V[1] * dt1 + V[2] * dt2;
+                    dmv1 += V[4] * dt0 + V[5] * dt1 + V[6] * dt2;
+                    dmv2 += V[8] * dt0 + V[9] * dt1 + V[10] * dt2;
+                    // projection chain (NDC-scaled screen-space gradient)
+                    const float m2x = gx_ * (0.5f * (float)kp.W), m2y = gy_ * (0.5f * (float)kp.H);
+                    gx_ = m2x;
+                    gy_ = m2y;
+                    const float* Pm = vw.projmatrix;
+                    const float mhx = Pm[0] * mx + Pm[4] * my + Pm[8] * mz + Pm[12];
+                    const float mhy = Pm[1] * mx + Pm[5] * my + Pm[9] * mz + Pm[13];
+                    const float mhw = Pm[3] * mx + Pm[7] * my + Pm[11] * mz + Pm[15];
+                    const float mw = 1.f / (mhw + 0.0000001f);
+                    const float mul1 = mhx * mw * mw, mul2 = mhy * mw * mw;
+                    dmv0 += (Pm[0] * mw - Pm[3] * mul1) * m2x + (Pm[1] * mw - Pm[3] * mul2) * m2y;
+                    dmv1 += (Pm[4] * mw - Pm[7] * mul1) * m2x + (Pm[5] * mw - Pm[7] * mul2) * m2y;
+                    dmv2 += (Pm[8] * mw - Pm[11] * mul1) * m2x + (Pm[9] * mw - Pm[11] * mul2) * m2y;
                 }
-                const float tz = 1.f / ge.tz, tz2 = tz * tz, tz3 = tz2 * tz;
-                const float dt0 = (ge.xin ? 1.f : 0.f) * (-ge.fx * tz2 * dJ02);
-                const float dt1 = (ge.yin ? 1.f : 0.f) * (-ge.fy * tz2 * dJ12);
-                const float dt2 = -ge.fx * tz2 * dJ00 - ge.fy * tz2 * dJ11 + (2.f * ge.fx * ge.txc) * tz3 * dJ02 +
-                                  (2.f * ge.fy * ge.tyc) * tz3 * dJ12;
-                dmv0 += V[0] * dt0 + V[1] * dt1 + V[2] * dt2;
-                dmv1 += V[4] * dt0 + V[5] * dt1 + V[6] * dt2;
-                dmv2 += V[8] * dt0 + V[9] * dt1 + V[10] * dt2;
-                // projection chain (NDC-scaled screen-space gradient)
-                const float m2x = gx_ * (0.5f * (float)kp.W), m2y = gy_ * (0.5f * (float)kp.H);
-                gx_ = m2x;
-                gy_ = m2y;
-                const float* Pm = vw.projmatrix;
-                const float mhx = Pm[0] * mx + Pm[4] * my + Pm[8] * mz + Pm[12];
-                const float mhy = Pm[1] * mx + Pm[5] * my + Pm[9] * mz + Pm[13];
-                const float mhw = Pm[3] * mx + Pm[7] * my + Pm[11] * mz + Pm[15];
-                const float mw = 1.f / (mhw + 0.0000001f);
-                const float mul1 = mhx * mw * mw, mul2 = mhy * mw * mw;
-                dmv0 += (Pm[0] * mw - Pm[3] * mul1) * m2x + (Pm[1] * mw - Pm[3] * mul2) * m2y;
-                dmv1 += (Pm[4] * mw - Pm[7] * mul1) * m2x + (Pm[5] * mw - Pm[7] * mul2) * m2y;
-                dmv2 += (Pm[8] * mw - Pm[11] * mul1) * m2x + (Pm[9] * mw - Pm[11] * mul2) * m2y;
                 if (USE_SH) {
                     const uint32_t cb = clamped[p];
                     drgb_v[0] = (cb & 1u) ? 0.f : gr;
@@ -521,7 +583,9 @@ static int backward_impl(const S360Params* prm, const S360View* views, const flo
     kp.P = prm->P; kp.V = prm->V; kp.H = prm->H; kp.W = prm->W; kp.deg = s360_effective_degree(prm); kp.M = prm->M;
     kp.gx = (prm->W + 15) / 16; kp.gy = (prm->H + 15) / 16; kp.T = kp.gx * kp.gy;
     kp.flags = prm->flags; kp.cap = prm->max_instances;
-    const int nt = kp.V * kp.T;
+    const bool sph = (kp.flags & S360_FLAG_SPHERICAL) != 0;
+    if (sph && (kp.V & 1)) return S360_E_BADARG;
+    const int nt = (sph ? kp.V / 2 : kp.V) * kp.T;
 
     const uint32_t* header = (const uint32_t*)(ws + L.header);
     const uint32_t* tiles_touched = (const uint32_t*)(ws + L.tiles_touched);

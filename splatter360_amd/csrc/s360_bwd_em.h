@@ -110,7 +110,7 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
     const int qx = tx * 16 + sub_ox(wave), qy = ty * 16 + sub_oy(wave);
     const float x0 = (float)qx, ys0 = (float)qy;
     const uint32_t start = min(tile_start[t], kp.cap);
-    const S360View& vw = views[v];
+    const S360View& vw = views[view_of_image(kp, v)];  // v = image index
 
     // ---- per-pixel constants (lane = pixel of the quadrant) ----
     uint32_t last = 0;

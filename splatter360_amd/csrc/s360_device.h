@@ -243,6 +243,77 @@ __device__ __forceinline__ void geo_compute(const float* V, float tanfovx, float
     g.c += 0.3f;
 }
 
+// ---- native equirectangular ("spherical") projection: mirrors oracle/s360_oracle.c geo_sph operation for operation ----
+__device__ __forceinline__ float s_atan_small(float z) {  // |z| <= tan(pi/16)
+    const float z2 = z * z;
+    return z * (1.0f + z2 * (-0.3333333333333333f + z2 * (0.2f + z2 * (-0.14285714285714285f + z2 * 0.1111111111111111f))));
+}
+__device__ __forceinline__ float s_atan_unit(float z) {  // 0 <= z <= 1
+    const float z1 = z / (1.0f + sqrtf(1.0f + z * z));
+    const float z2 = z1 / (1.0f + sqrtf(1.0f + z1 * z1));
+    return 4.0f * s_atan_small(z2);
+}
+// atan2 from IEEE add / mul / div / sqrt only: bit-identical to the float32 oracle (|error| < 1e-7 rad)
+__device__ __forceinline__ float s_atan2(float y, float x) {
+    const float ax = x < 0.0f ? -x : x, ay = y < 0.0f ? -y : y;
+    if (ax == 0.0f && ay == 0.0f) return 0.0f;
+    const bool swap = ay > ax;
+    float a = s_atan_unit(swap ? ax / ay : ay / ax);
+    if (swap) a = 1.5707963267948966f - a;
+    if (x < 0.0f) a = 3.141592653589793f - a;
+    return y < 0.0f ? -a : a;
+}
+
+struct GeoS {
+    float t0, t1, t2, r2, r, rho2, rho, rc;
+    bool clamped;
+    float u, v;
+    float J00, J02, J10, J11, J12;
+    float M0[3], M1[3], v0[3], v1[3];
+    float a, b, c;
+};
+
+__device__ __forceinline__ void geo_sph(const float* V, int W, int H, float mx, float my, float mz, const float* c6, GeoS& g) {
+    xform43(V, mx, my, mz, g.t0, g.t1, g.t2);
+    const float t0 = g.t0, t1 = g.t1, t2 = g.t2;
+    g.rho2 = t0 * t0 + t2 * t2;
+    g.r2 = g.rho2 + t1 * t1;
+    g.r = sqrtf(g.r2);
+    g.rho = sqrtf(g.rho2);
+    g.clamped = g.rho < 0.05f * g.r;
+    g.rc = g.clamped ? 0.05f * g.r : g.rho;
+    const float theta = s_atan2(t0, t2), phi = s_atan2(t1, g.rho);
+    g.u = (0.5f - theta / 6.283185307179586f) * (float)W - 0.5f;
+    g.v = (0.5f - phi / 3.141592653589793f) * (float)H - 0.5f;
+    const float c0 = -(float)W / 6.283185307179586f, c1 = -(float)H / 3.141592653589793f;
+    const float A = 1.0f / (g.rc * g.rc), Bq = 1.0f / (g.r2 * g.rc), Cq = g.rc / g.r2;
+    g.J00 = c0 * t2 * A;
+    g.J02 = -(c0 * t0 * A);
+    g.J10 = -(c1 * t0 * t1 * Bq);
+    g.J11 = c1 * Cq;
+    g.J12 = -(c1 * t2 * t1 * Bq);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        g.M0[j] = g.J00 * V[j * 4 + 0] + g.J02 * V[j * 4 + 2];
+        g.M1[j] = g.J10 * V[j * 4 + 0] + g.J11 * V[j * 4 + 1] + g.J12 * V[j * 4 + 2];
+    }
+    const float S[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        g.v0[k] = S[k][0] * g.M0[0] + S[k][1] * g.M0[1] + S[k][2] * g.M0[2];
+        g.v1[k] = S[k][0] * g.M1[0] + S[k][1] * g.M1[1] + S[k][2] * g.M1[2];
+    }
+    g.a = g.M0[0] * g.v0[0] + g.M0[1] * g.v0[1] + g.M0[2] * g.v0[2];
+    g.b = g.M1[0] * g.v0[0] + g.M1[1] * g.v0[1] + g.M1[2] * g.v0[2];
+    g.c = g.M1[0] * g.v1[0] + g.M1[1] * g.v1[1] + g.M1[2] * g.v1[2];
+    g.a += 0.3f;
+    g.c += 0.3f;
+}
+
+// image a view renders into (spherical mode: views 2i and 2i+1 are the camera and the seam ghost of panorama i)
+__device__ __forceinline__ int image_of_view(const KParams& kp, int v) { return (kp.flags & S360_FLAG_SPHERICAL) ? (v >> 1) : v; }
+__device__ __forceinline__ int view_of_image(const KParams& kp, int img) { return (kp.flags & S360_FLAG_SPHERICAL) ? 2 * img : img; }
+
 // Composite exponent.  Records hold the conic pre-scaled (a' = -log2(e)/2 * a, b' = -log2(e) * b,
 // c' = -log2(e)/2 * c) so that  log2 G = a' dx^2 + b' dx dy + c' dy^2  is three FMAs + two multiplies
 // and G = v_exp_f32(.) with no extra multiply.  Forward and backward share this function, so both

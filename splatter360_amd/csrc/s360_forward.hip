@@ -40,7 +40,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess(
     const int g = g0 + tid;
     const int P = kp.P;
     uint32_t* hist = reinterpret_cast<uint32_t*>(lds_sh);
-    const int nhist = kp.V * kp.T;
+    const int nhist = (image_of_view(kp, kp.V - 1) + 1) * kp.T;
     if (lds_hist)
         for (int i = tid; i < nhist; i += S360_BLOCK) hist[i] = 0u;
 
@@ -74,30 +74,52 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess(
         float c6[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) c6[k] = c60[k] * sc2;
-        float pvx, pvy, pvz;
-        xform43(vw.viewmatrix, mx, my, mz, pvx, pvy, pvz);
-        if (pvz > 0.2f) {
-            const float* Pm = vw.projmatrix;
-            const float phx = Pm[0] * mx + Pm[4] * my + Pm[8] * mz + Pm[12];
-            const float phy = Pm[1] * mx + Pm[5] * my + Pm[9] * mz + Pm[13];
-            const float phw = Pm[3] * mx + Pm[7] * my + Pm[11] * mz + Pm[15];
-            const float pw = 1.0f / (phw + 0.0000001f);
-            const float prx = phx * pw, pry = phy * pw;
-            Geo ge;
-            geo_compute(vw.viewmatrix, vw.tanfovx, vw.tanfovy, kp.W, kp.H, mx, my, mz, c6, ge);
-            const float det = ge.a * ge.c - ge.b * ge.b;
+        // mode-specific projection: (front, cov2D a b c incl. the dilation, pixel centre, sort key)
+        bool front;
+        float ga = 0.f, gb = 0.f, gc = 0.f, px = 0.f, py = 0.f, zkey = 0.f;
+        if (!(kp.flags & S360_FLAG_SPHERICAL)) {
+            float pvx, pvy, pvz;
+            xform43(vw.viewmatrix, mx, my, mz, pvx, pvy, pvz);
+            front = pvz > 0.2f;
+            if (front) {
+                const float* Pm = vw.projmatrix;
+                const float phx = Pm[0] * mx + Pm[4] * my + Pm[8] * mz + Pm[12];
+                const float phy = Pm[1] * mx + Pm[5] * my + Pm[9] * mz + Pm[13];
+                const float phw = Pm[3] * mx + Pm[7] * my + Pm[11] * mz + Pm[15];
+                const float pw = 1.0f / (phw + 0.0000001f);
+                const float prx = phx * pw, pry = phy * pw;
+                Geo ge;
+                geo_compute(vw.viewmatrix, vw.tanfovx, vw.tanfovy, kp.W, kp.H, mx, my, mz, c6, ge);
+                ga = ge.a; gb = ge.b; gc = ge.c;
+                px = ((prx + 1.0f) * (float)kp.W - 1.0f) * 0.5f;
+                py = ((pry + 1.0f) * (float)kp.H - 1.0f) * 0.5f;
+                zkey = pvz;
+            }
+        } else {  // native equirectangular splat (oracle geo_sph); radial distance is the cull and sort quantity
+            GeoS gs;
+            geo_sph(vw.viewmatrix, kp.W, kp.H, mx, my, mz, c6, gs);
+            front = gs.r > 0.2f;
+            ga = gs.a; gb = gs.b; gc = gs.c;
+            px = gs.u; py = gs.v;
+            zkey = gs.r;
+        }
+        if (front) {
+            const float det = ga * gc - gb * gb;
             if (det != 0.0f) {
                 const float det_inv = 1.0f / det;
-                const float conA = ge.c * det_inv, conB = -ge.b * det_inv, conC = ge.a * det_inv;
-                const float mid = 0.5f * (ge.a + ge.c);
+                const float conA = gc * det_inv, conB = -gb * det_inv, conC = ga * det_inv;
+                const float mid = 0.5f * (ga + gc);
                 const float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
                 const float lam1 = mid + sq, lam2 = mid - sq;
                 const int rad = (int)ceilf(3.0f * sqrtf(fmaxf(lam1, lam2)));
-                const float px = ((prx + 1.0f) * (float)kp.W - 1.0f) * 0.5f;
-                const float py = ((pry + 1.0f) * (float)kp.H - 1.0f) * 0.5f;
+                bool keep = true;
+                if ((kp.flags & S360_FLAG_SPHERICAL) && (v & 1)) {  // seam ghost: the same splat one panorama width away
+                    keep = rad < kp.W / 2;
+                    px = px < 0.5f * (float)kp.W ? px + (float)kp.W : px - (float)kp.W;
+                }
                 int minx, miny, maxx, maxy;
                 tile_rect(px, py, rad, kp.gx, kp.gy, minx, miny, maxx, maxy);
-                const int area = (maxx - minx) * (maxy - miny);
+                const int area = keep ? (maxx - minx) * (maxy - miny) : 0;
                 if (area != 0) {
                     if (USE_SH && (!have_rgb || !shared_cam)) {
                         const float dx = mx - vw.campos[0], dy = my - vw.campos[1], dz = mz - vw.campos[2];
@@ -166,10 +188,10 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess(
                     // dx* = ka dy maximises the exponent on a row, dy* = kb dx on a column
                     const float ra = conA * kConicDiag, rb = conB * kConicOff, rc_ = conC * kConicDiag;
                     recA[3 * (size_t)(p) + 2] = make_float4(rgb[2], __int_as_float(rad), -rb / (2.0f * ra), -rb / (2.0f * rc_));
-                    depths[p] = pvz;
+                    depths[p] = zkey;
                     clamped[p] = (uint8_t)clampbits;
                     // block-local histogram in LDS; one global atomic per (block, touched tile) below
-                    uint32_t* tc = (lds_hist ? hist : tile_count) + (size_t)v * kp.T;
+                    uint32_t* tc = (lds_hist ? hist : tile_count) + (size_t)image_of_view(kp, v) * kp.T;
                     for (int y = miny; y < maxy; ++y)
                         for (int x = minx; x < maxx; ++x) atomicAdd(&tc[y * kp.gx + x], 1u);
                 }
@@ -371,7 +393,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_emit(KParams kp, const uint32_t*
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_bin[];  // [T] counts/cursors, [T] bases
     const int v = blockIdx.y;
     const int g0 = blockIdx.x * (S360_BLOCK * EMIT_PPT) + threadIdx.x;
-    const size_t tb = (size_t)v * kp.T;
+    const size_t tb = (size_t)image_of_view(kp, v) * kp.T;
     uint32_t* cnt = lds_bin;
     uint32_t* base = lds_bin + kp.T;
     if (LDS_BIN) {
@@ -750,8 +772,9 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
     uint32_t last = 0;
     bool done = !inside;
-    const float inv_scale = WITH_DEPTH ? 1.0f / views[v].scale : 0.f;
-    const float v_near = WITH_DEPTH ? views[v].near_plane : 0.f, v_far = WITH_DEPTH ? views[v].far_plane : 0.f;
+    const int vcam = view_of_image(kp, v);  // v = image index
+    const float inv_scale = WITH_DEPTH ? 1.0f / views[vcam].scale : 0.f;
+    const float v_near = WITH_DEPTH ? views[vcam].near_plane : 0.f, v_far = WITH_DEPTH ? views[vcam].far_plane : 0.f;
 
     // software pipeline: list indices two chunks ahead, records one chunk ahead
     uint32_t p_n1 = 0, p_n2 = 0;
@@ -883,7 +906,7 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
     }
     float sq = 0.f, sqc = 0.f;
     if (inside) {
-        const S360View& vw = views[v];
+        const S360View& vw = views[vcam];
         const size_t hw = (size_t)kp.H * kp.W;
         const size_t pix = (size_t)py * kp.W + px;
         float* img = images + (size_t)v * 3 * hw;
@@ -1045,7 +1068,9 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
     kp.P = prm->P; kp.V = prm->V; kp.H = prm->H; kp.W = prm->W; kp.deg = s360_effective_degree(prm); kp.M = prm->M;
     kp.gx = (prm->W + 15) / 16; kp.gy = (prm->H + 15) / 16; kp.T = kp.gx * kp.gy;
     kp.flags = prm->flags; kp.cap = prm->max_instances;
-    const int nt = kp.V * kp.T;
+    const bool sph = (kp.flags & S360_FLAG_SPHERICAL) != 0;
+    if (sph && (kp.V & 1)) return S360_E_BADARG;  // views come in (camera, seam ghost) pairs
+    const int nt = (sph ? kp.V / 2 : kp.V) * kp.T;
     const size_t np = (size_t)kp.V * kp.P;
 
     uint32_t* header = (uint32_t*)(ws + L.header);

@@ -262,6 +262,26 @@ def render_cube_faces(pano_c2w: Tensor, near: Tensor, far: Tensor, face_w: int, 
                               shared_campos=True)   # six faces of one panorama: one camera centre by construction
 
 
+def render_erp_spherical(pano_c2w: Tensor, near, image_shape: tuple, background: Tensor, gaussian_means: Tensor,
+                         gaussian_covariances: Tensor, gaussian_sh_coefficients: Tensor, gaussian_opacities: Tensor, *,
+                         max_instances: Optional[int] = None, check: str = "sync") -> Tensor:
+    """Native equirectangular splatting: n <= 4 panorama poses [n,4,4] of ONE cloud (the reference's
+    Gaussians layouts) -> [n,3,H,W] rendered directly in ERP space, no cube faces and no stitch.  This is what
+    BASELINE.json's north star literally describes; the reference itself never does it (it renders six pinhole faces,
+    model_wrapper_erp.py:221-229), so results are NOT comparable with the reference — the mode is specified and pinned by
+    the oracle (oracle/s360_oracle.c geo_sph, tests/test_oracle_spherical.py).  Differentiable."""
+    h, w = image_shape
+    n = gaussian_sh_coefficients.shape[-1]
+    pose = pano_c2w.reshape(-1, 4, 4)
+    nr = torch.as_tensor(near, dtype=torch.float32, device=pose.device).reshape(-1).expand(pose.shape[0])
+    views = rasterizer.pack_views_spherical(pose, background, scale=1.0 / nr, near=nr)
+    out = rasterizer.rasterize_views(gaussian_means, gaussian_covariances, gaussian_opacities, gaussian_sh_coefficients, None,
+                                     views=views, image_height=h, image_width=w, sh_degree=isqrt(n) - 1, shared_campos=pose.shape[0] == 1,
+                                     want_radii=False, max_instances=max_instances, check=check, cov9=True, sh_channel_major=True,
+                                     spherical=True)
+    return out[0]
+
+
 @dataclass
 class DecoderOutput:
     color: Tensor

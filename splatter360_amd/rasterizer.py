@@ -89,6 +89,23 @@ def pack_views_native(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far:
     return out
 
 
+def pack_views_spherical(pano_c2w: Tensor, background: Tensor, scale=1.0, near=0.0, far=0.0) -> Tensor:
+    """[n,4,4] panorama camera-to-world poses (the encoder's ERP frame: +z = panorama centre, +y = top row) -> views[2n,44]
+    for rasterize_views(..., spherical=True): rows 2i / 2i+1 are panorama i's camera and its seam ghost (identical
+    records).  `scale` multiplies the cloud and the camera centre inside the kernels (pass 1/near for the reference's
+    scale-invariant convention: the radial cull sits at 0.2 scaled units).  Small host-free torch glue (one inverse)."""
+    c2w = pano_c2w.reshape(-1, 4, 4).float().clone()
+    n = c2w.shape[0]
+    dev = c2w.device
+    sc = scale if isinstance(scale, Tensor) else torch.full((n,), float(scale), device=dev)
+    sc = sc.reshape(-1).float().to(dev).expand(n)
+    c2w[:, :3, 3] = c2w[:, :3, 3] * sc[:, None]
+    vm = torch.linalg.inv_ex(c2w, check_errors=False).inverse.transpose(1, 2).contiguous()
+    one = torch.ones(n, device=dev)
+    v = pack_views(vm, torch.eye(4, device=dev).expand(n, 4, 4), c2w[:, :3, 3], one, one, background, scale=sc, near=near, far=far)
+    return v.repeat_interleave(2, dim=0).contiguous()
+
+
 def default_capacity(p: int, v: int) -> int:
     """Initial capacity (instances = (Gaussian, tile) pairs) of the binning buffers."""
     return int(min(2**32 - 1, max(1 << 16, (3 * p * v) // 2 + (1 << 18))))
@@ -154,7 +171,8 @@ def _forward_call(prm, views, means3D, cov6, opac, shs, colors, want_radii: bool
     lay = _lib.layout(prm)
     dev = means3D.device
     ws = torch.empty(lay.total_bytes, dtype=torch.uint8, device=dev)
-    images = torch.empty((prm.V, 3, prm.H, prm.W), dtype=torch.float32, device=dev)
+    n_img = prm.V // 2 if (prm.flags & _lib.FLAG_SPHERICAL) else prm.V     # spherical: views = (camera, seam ghost) pairs
+    images = torch.empty((n_img, 3, prm.H, prm.W), dtype=torch.float32, device=dev)
     radii = torch.empty((prm.V, prm.P), dtype=torch.int32, device=dev) if want_radii else None
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     depth = None
@@ -177,7 +195,7 @@ def _forward_call(prm, views, means3D, cov6, opac, shs, colors, want_radii: bool
         rc = _lib.lib().s360_forward(C.byref(prm), _ptr(views), _ptr(means3D), _ptr(cov6), _ptr(opac), _ptr(shs),
                                      _ptr(colors), _ptr(images), _ptr(radii), _ptr(ws), lay.total_bytes, stream)
     else:
-        depth = torch.empty((prm.V, prm.H, prm.W), dtype=torch.float32, device=dev)
+        depth = torch.empty((n_img, prm.H, prm.W), dtype=torch.float32, device=dev)
         rc = _lib.lib().s360_forward_depth(C.byref(prm), _ptr(views), _ptr(means3D), _ptr(cov6), _ptr(opac), _ptr(shs),
                                            _ptr(colors), _ptr(images), _ptr(depth), DEPTH_MODES[depth_mode], _ptr(radii),
                                            _ptr(ws), lay.total_bytes, stream)
@@ -191,7 +209,9 @@ class _RasterizeViews(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, cov6, views, cfg, mse_target=None):
         (h, w, sh_degree, shared_campos, max_instances, check, want_radii, cov9, sh_channel_major, keep_offsets, depth_mode,
-         defer_sh, mse_weight, mse_count) = cfg
+         defer_sh, mse_weight, mse_count, spherical) = cfg
+        if spherical and (mse_target is not None or int(views.shape[0]) % 2):
+            raise RuntimeError("spherical mode: views come in (camera, seam ghost) pairs; the fused loss epilogue is cube-face only")
         if not means3D.is_cuda:
             raise RuntimeError("means3D must live on the GPU (hip device); the rasteriser has no CPU path")
         with torch.cuda.device(means3D.device):
@@ -214,7 +234,7 @@ class _RasterizeViews(torch.autograd.Function):
             prm.flags = (_lib.FLAG_SHARED_CAMPOS if (shared_campos or v == 1) else 0) | (
                 _lib.FLAG_COV9 if cov9 else 0) | (_lib.FLAG_SH_CHANNEL_MAJOR if sh_channel_major else 0) | (
                 0 if (needs_bwd or keep_offsets) else _lib.FLAG_FORWARD_ONLY) | (
-                _lib.FLAG_SH_DEG4_IGNORED if SH_DEG4_IGNORED else 0)
+                _lib.FLAG_SH_DEG4_IGNORED if SH_DEG4_IGNORED else 0) | (_lib.FLAG_SPHERICAL if spherical else 0)
             prm.max_instances = int(max_instances) if max_instances else default_capacity(p, v)
             mse = None
             if mse_target is not None:
@@ -262,7 +282,8 @@ class _RasterizeViews(torch.autograd.Function):
                 seed = state.d_images * grad_loss.detach().float()   # d_images = 2w/N (image - target) from the epilogue
                 g = seed if g is None else g + seed
             if g is None:
-                g = torch.zeros((prm.V, 3, prm.H, prm.W), dtype=torch.float32, device=dev)
+                n_img = prm.V // 2 if (prm.flags & _lib.FLAG_SPHERICAL) else prm.V
+                g = torch.zeros((n_img, 3, prm.H, prm.W), dtype=torch.float32, device=dev)
             g = g.contiguous()
             gd, dm = None, 0
             if grad_depth is not None and ctx.depth_mode is not None:
@@ -348,7 +369,7 @@ def rasterize_views(means3D: Tensor, cov6: Tensor, opacities: Tensor, shs: Optio
                     check: str = "sync", want_radii: bool = True, means2D: Optional[Tensor] = None,
                     cov9: bool = False, sh_channel_major: bool = False, keep_offsets: bool = False,
                     depth_mode: Optional[str] = None, defer_sh: bool = False, mse_target: Optional[Tensor] = None,
-                    mse_weight: float = 1.0, mse_count: Optional[int] = None):
+                    mse_weight: float = 1.0, mse_count: Optional[int] = None, spherical: bool = False):
     """Render V views ([V,44] packed, see pack_views) of one cloud.  cov9: cov6 is [P,3,3];
     sh_channel_major: shs is [P,3,M] (the reference's Gaussians layouts, consumed without copies).
     When no input requires grad the per-pair offsets scan (backward-only state) is skipped unless
@@ -362,14 +383,17 @@ def rasterize_views(means3D: Tensor, cov6: Tensor, opacities: Tensor, shs: Optio
     default all of this call's), clipped_mse[V] for psnr()).
     check="sync": read the overflow flag after the forward (one host sync, like upstream's own
     scan read-back) and re-run with the exact size if the binning capacity was exceeded;
-    check="lazy": never synchronise — validate later via last_state().overflowed()."""
+    check="lazy": never synchronise — validate later via last_state().overflowed().
+    spherical=True: native equirectangular splat mode (S360_FLAG_SPHERICAL; no reference counterpart, specified by the
+    oracle's geo_sph): `views` = pack_views_spherical(...) — (camera, seam ghost) pairs — and the result is one
+    [H,W] equirectangular image per pair; means2D gradients are in pixel units."""
     if (shs is None) == (colors_precomp is None):
         raise Exception("Please provide excatly one of either SHs or precomputed colors!")
     op2 = opacities.reshape(-1, 1)
     if depth_mode is not None and depth_mode not in DEPTH_MODES:
         raise ValueError(f"depth_mode must be one of {sorted(DEPTH_MODES)}")
     cfg = (image_height, image_width, sh_degree, shared_campos, max_instances, check, want_radii, cov9,
-           sh_channel_major, keep_offsets, depth_mode, defer_sh, mse_weight, mse_count)
+           sh_channel_major, keep_offsets, depth_mode, defer_sh, mse_weight, mse_count, bool(spherical))
     images, radii, depth, loss, clipped = _RasterizeViews.apply(means3D, means2D, shs, colors_precomp, op2, cov6, views,
                                                                 cfg, mse_target)
     out = (images, radii) if depth_mode is None else (images, radii, depth)
