@@ -58,6 +58,9 @@ def parse():
                          "1.53 vs 1.44 ms); 1: record them during the K timed steps")
     ap.add_argument("--fused-loss", type=int, default=1, help="1: L2 loss + its gradient seed fused into the render epilogue; "
                     "0: the reference's torch ops on the rendered faces")
+    ap.add_argument("--overlap-exchange", type=int, default=1,
+                    help="N>1, factored: 1 (default) = a micro-batch's exchange is finished only after the next micro-batch's forward "
+                         "has been queued (it overlaps with that forward); 0 = finished right after its own backward")
     ap.add_argument("--grad-sync", choices=("factored", "allreduce"), default="factored",
                     help="N>1 gradient exchange: factored (default) or one all-reduce of the full 352 B/Gaussian set")
     return ap.parse_args()
@@ -126,6 +129,13 @@ def main():
             out["erp"] = c2e.stitch_rendered(col)
             out["faces"] = col
 
+    pending = [None]   # the previous micro-batch's gradient exchange, still in flight (N > 1)
+
+    def finish_pending():
+        if pending[0] is not None:
+            out["grads"] = pending[0].finish()     # waits (on the stream) for the collectives, rebuilds dL/dSH locally
+            pending[0] = None
+
     def step_train():
         for p in params:
             p.grad = None
@@ -139,10 +149,15 @@ def main():
                                                defer_sh=factored)
             loss = ((faces - gt) ** 2).mean() if a.mode == "fwdbwd" else None
         out["erp"] = c2e.stitch_rendered(faces.detach())
+        # the forward above was queued while the PREVIOUS micro-batch's exchange is still running on the communicator's
+        # stream (gradient accumulation over micro-batches: SURVEY.md 8(e) "overlap with the next view's forward")
+        finish_pending()
         if a.mode == "fwdbwd":
             loss.backward()
-            if factored:   # all-reduce 52 B/Gaussian + all-gather 16 B/Gaussian/rank, SH gradient rebuilt locally
-                distributed.sync_gradients_factored(*params, rasterizer.last_deferred())
+            if factored:   # all-reduce 40 B/Gaussian (one packed buffer) + all-gather 16 B/Gaussian/rank, SH gradient rebuilt locally
+                pending[0] = distributed.start_factored_exchange(*params, rasterizer.deferred_of(faces))
+                if not a.overlap_exchange:
+                    finish_pending()
             else:
                 distributed.allreduce_gradients([p.grad for p in params])
         out["faces"] = faces
@@ -158,12 +173,14 @@ def main():
 
     for _ in range(a.warmup):
         step()
+    finish_pending()
     sync()
     if a.events_in_timed_region:
         _lib.profile_enable(True)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
+    finish_pending()     # the last exchange completes INSIDE the timed region
     sync()
     dt = distributed.max_over_ranks(time.perf_counter() - t0, dev)
     ms_per_step = dt / a.steps * 1e3
@@ -182,6 +199,7 @@ def main():
         _lib.profile_enable(True)
         for _ in range(a.steps):
             step()
+        finish_pending()
         torch.cuda.synchronize(dev)
     prof = _lib.profile_collect()
     _lib.profile_enable(False)
@@ -246,7 +264,7 @@ def main():
                                f"context panoramas {pano_w}x{pano_h}), {erp_w}x{erp_h} ERP = 6 faces {face_w}x{face_w} + stitch, {a.mode}"
                                + (", L2 loss on faces" + (" (fused epilogue)" if a.fused_loss else "") if a.mode == "fwdbwd" else ""),
                    "gaussians": G, "erp": [erp_w, erp_h], "face": face_w, "views_per_gpu": views_per_step,
-                   "parallelism": f"view-sharded x{world}" + ((", RCCL factored grad exchange (all-reduce 52 B/G + all-gather dRGB 16 B/G/rank)" if factored else
+                   "parallelism": f"view-sharded x{world}" + ((", RCCL factored grad exchange (all-reduce 40 B/G packed + all-gather dRGB 16 B/G/rank" + (", overlapped with the next micro-batch's forward" if a.overlap_exchange else "") + ")" if factored else
                                                                   ", RCCL all-reduce of Gaussian grads") if world > 1 and a.mode == "fwdbwd" else ""),
                    "num_rendered": L, "visible_pairs": visible_pairs},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -72,53 +72,134 @@ def allreduce_gradients(grads: Sequence[Optional[Tensor]], average: bool = False
     return []
 
 
-def sync_gradients_factored(means: Tensor, covariances: Tensor, harmonics: Tensor, opacities: Tensor, deferred,
-                            group=None) -> None:
+_TRIU = ((0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2))
+
+
+def _pack_small(d_means: Tensor, d_cov: Tensor, d_op: Tensor) -> Tensor:
+    """means (3) + the 6 unique covariance entries + opacity (1) -> ONE contiguous [P,10] buffer (40 B / Gaussian): a single
+    larger all-reduce instead of three, and the [P,3,3] covariance gradient (whose lower triangle is identically zero —
+    the rasteriser reads the upper triangle only, cuda_splatting.py:115,123) does not travel as 9 floats."""
+    p = d_means.shape[0]
+    c6 = d_cov if d_cov.dim() == 2 else torch.stack([d_cov[:, r, c] for r, c in _TRIU], dim=1)
+    return torch.cat([d_means.reshape(p, 3), c6.reshape(p, 6), d_op.reshape(p, 1)], dim=1).contiguous()
+
+
+def _unpack_small(buf: Tensor, cov_like: Tensor):
+    d_means = buf[:, 0:3].contiguous()
+    if cov_like.dim() == 2:
+        d_cov = buf[:, 3:9].contiguous()
+    else:
+        d_cov = torch.zeros_like(cov_like)
+        for k, (r, c) in enumerate(_TRIU):
+            d_cov[:, r, c] = buf[:, 3 + k]
+    return d_means, d_cov, buf[:, 9].contiguous().reshape(-1)
+
+
+class FactoredExchange:
+    """The gradient exchange of one step, split in two so that it can sit behind other GPU work:
+    start_factored_exchange() issues the collectives (they wait, on the communicator's stream, for the backward kernels
+    that produced the gradients and then run beside whatever the compute stream does next — in bench.py the NEXT
+    micro-batch's forward); finish() waits for the all-gathers, rebuilds the summed dL/dSH locally
+    (s360_sh_backward over the N gathered factors), waits for the all-reduce and returns the four summed gradients
+    (also stored in .grad of the tensors handed to start)."""
+
+    def __init__(self, params, deferred, small, rgb_all, rep_all, works_ag, work_ar, world):
+        self.params, self.deferred, self.small = params, deferred, small
+        self.rgb_all, self.rep_all, self.works_ag, self.work_ar, self.world = rgb_all, rep_all, works_ag, work_ar, world
+        self.result = None
+
+    def finish(self):
+        if self.result is not None:
+            return self.result
+        from . import rasterizer
+        means, covariances, harmonics, opacities = self.params
+        d = self.deferred
+        for w in self.works_ag:
+            w.wait()
+        # the SH pass adds every rank's view-direction term of dL/dmean into a scratch buffer (the packed buffer is still
+        # being all-reduced); it is folded in once the all-reduce has landed
+        dm_extra = torch.zeros((self.small.shape[0], 3), dtype=self.small.dtype, device=self.small.device)
+        d_sh = rasterizer.finish_deferred_sh(d.prm, self.rep_all.reshape(self.world, -1), d.means3D, d.shs,
+                                             self.rgb_all.view(self.world, -1, 4), dm_extra)
+        if self.work_ar is not None:
+            self.work_ar.wait()
+        d_means, d_cov, d_op = _unpack_small(self.small, covariances)
+        d_means = d_means + dm_extra.to(d_means.dtype)
+        means.grad, covariances.grad, harmonics.grad = d_means.reshape(means.shape), d_cov, d_sh
+        opacities.grad = d_op.reshape(opacities.shape)
+        self.result = (means.grad, covariances.grad, harmonics.grad, opacities.grad)
+        return self.result
+
+
+def start_factored_exchange(means: Tensor, covariances: Tensor, harmonics: Tensor, opacities: Tensor, deferred,
+                            group=None) -> FactoredExchange:
     """Gradient exchange for views sharded one panorama per rank, exploiting that each rank's dL/dSH is the
     rank-1 product Y(dir_rank) (x) dL/dRGB_rank per Gaussian:
-        all-reduce   means.grad / covariances.grad / opacities.grad      (52 B per Gaussian)
-        all-gather   d_rgb_sum[P,4] and one camera record per rank        (16 B per Gaussian per rank)
+        all-reduce   [means | cov6 | opacity].grad packed as one [P,10] buffer      (40 B per Gaussian)
+        all-gather   d_rgb_sum[P,4] and one camera record per rank                    (16 B per Gaussian per rank)
     then every rank rebuilds the summed dL/dSH (and the view-direction part of dL/dmean) locally with
-    s360_sh_backward.  At N = 8 and 1 M Gaussians a rank receives ~0.17 GB instead of the ~0.65 GB of a ring
+    s360_sh_backward.  At N = 8 and 1 M Gaussians a rank receives ~0.19 GB instead of the ~0.65 GB of a ring
     all-reduce of the full 369 MB gradient set; results equal the plain all-reduce up to float summation order.
-    `deferred` = rasterizer.last_deferred() of a backward run with defer_sh=True.  Works for world size 1."""
-    from . import rasterizer
+    `deferred` = rasterizer.last_deferred() of a backward run with defer_sh=True.  The .grad tensors are TAKEN from the
+    parameters (set to None) so that the next step's backward cannot touch buffers the communicator is still reading.
+    Works for world size 1.  All collectives are async; call .finish() on the result."""
     dev = harmonics.device
     world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
     rank = dist.get_rank(group) if world > 1 else 0
     d = deferred
     if d is None:
-        raise RuntimeError("sync_gradients_factored needs the DeferredSH of a backward run with defer_sh=True")
+        raise RuntimeError("start_factored_exchange needs the DeferredSH of a backward run with defer_sh=True")
     # every rank must issue the same collectives: a tensor that received no gradient on this rank contributes zeros
-    for t in (means, covariances, opacities):
-        if t.grad is None:
-            t.grad = torch.zeros_like(t)
+    grads = [t.grad if t.grad is not None else torch.zeros_like(t) for t in (means, covariances, opacities)]
+    small = _pack_small(*grads)
+    for t in (means, covariances, harmonics, opacities):
+        t.grad = None
     rgb = d.d_rgb_sum.clone()
     vis = rgb[:, 3].view(torch.int32) >= 0
     rgb[:, 3] = torch.where(vis, torch.full_like(rgb[:, 3].view(torch.int32), rank), torch.full_like(rgb[:, 3].view(torch.int32), -1)).view(torch.float32)
     rep = d.views[:1].contiguous()  # all views of the call share campos and scale
-    ar = []
+    works_ag, work_ar = [], None
     if world > 1:
         # the communicator runs its work in issue order: the all-gathers first (the local SH pass waits for them),
-        # the three all-reduces behind them, overlapping with that pass
+        # the all-reduce behind them, overlapping with that pass
         rgb_all = torch.empty((world * rgb.shape[0], 4), dtype=rgb.dtype, device=dev)   # dim-0 concat: gloo-compatible
         rep_all = torch.empty((world * rep.shape[1],), dtype=rep.dtype, device=dev)
-        ag = [dist.all_gather_into_tensor(rgb_all, rgb, group=group, async_op=True),
-              dist.all_gather_into_tensor(rep_all, rep.reshape(-1), group=group, async_op=True)]
-        ar = [dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group, async_op=True)
-              for g in (covariances.grad, means.grad, opacities.grad)]
-        for w in ag:
-            w.wait()
+        works_ag = [dist.all_gather_into_tensor(rgb_all, rgb, group=group, async_op=True),
+                    dist.all_gather_into_tensor(rep_all, rep.reshape(-1), group=group, async_op=True)]
+        work_ar = dist.all_reduce(small, op=dist.ReduceOp.SUM, group=group, async_op=True)
     else:
         rgb_all, rep_all = rgb, rep
-    # the SH pass adds every rank's view-direction term of dL/dmean into a scratch buffer (means.grad is still
-    # being all-reduced); it is folded in once the all-reduce has landed
-    dm_extra = torch.zeros_like(means.grad)
-    harmonics.grad = rasterizer.finish_deferred_sh(d.prm, rep_all.reshape(world, -1), d.means3D, d.shs,
-                                                   rgb_all.view(world, -1, 4), dm_extra)
-    for w in ar:
+    return FactoredExchange((means, covariances, harmonics, opacities), d, small, rgb_all, rep_all, works_ag, work_ar, world)
+
+
+def sync_gradients_factored(means: Tensor, covariances: Tensor, harmonics: Tensor, opacities: Tensor, deferred,
+                            group=None) -> None:
+    """start_factored_exchange(...).finish(): the blocking form (kept for callers that do not pipeline steps)."""
+    start_factored_exchange(means, covariances, harmonics, opacities, deferred, group).finish()
+
+
+def reduce_scatter_gradients(grads: Sequence[Tensor], group=None) -> List[Tensor]:
+    """For a consumer that is itself sharded by Gaussian range (rank r owns Gaussians [r*ceil(P/N), ...)): every rank
+    receives only ITS slice of the summed gradients — half the bytes of an all-reduce on a ring.
+    Each tensor is [P, ...]; P is padded up to a multiple of the world size for the collective and the padding dropped.
+    Returns the local slices (views of fresh buffers)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return [g for g in grads]
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    outs, works = [], []
+    for g in grads:
+        p = g.shape[0]
+        per = (p + world - 1) // world
+        flat = g.reshape(p, -1)
+        if per * world != p:
+            flat = torch.cat([flat, flat.new_zeros((per * world - p, flat.shape[1]))])
+        out = torch.empty((per, flat.shape[1]), dtype=g.dtype, device=g.device)
+        works.append(dist.reduce_scatter_tensor(out, flat.contiguous(), op=dist.ReduceOp.SUM, group=group, async_op=True))
+        lo, hi = rank * per, min(p, (rank + 1) * per)
+        outs.append((out, max(0, hi - lo), g.shape[1:]))
+    for w in works:
         w.wait()
-    means.grad += dm_extra
+    return [o[:n].reshape(n, *tail) for o, n, tail in outs]
 
 
 def max_over_ranks(value: float, device) -> float:

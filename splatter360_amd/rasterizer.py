@@ -256,6 +256,8 @@ class _RasterizeViews(torch.autograd.Function):
                 clipped_mse = loss
         ctx.set_materialize_grads(False)
         ctx.state = state
+        ctx.holder = {}                       # filled by a deferred-SH backward; reachable from the output (deferred_of)
+        _RasterizeViews.last_holder = ctx.holder
         ctx.defer_sh = bool(defer_sh) and sh is not None
         ctx.has_means2D = means2D is not None
         ctx.depth_mode = depth_mode if depth is not None else None
@@ -307,7 +309,7 @@ class _RasterizeViews(torch.autograd.Function):
                     _ptr(g), _ptr(gd), dm, _ptr(d_m3), _ptr(d_m2), _ptr(d_c6), _ptr(d_op), _ptr(d_rgb),
                     _ptr(bws), lay.backward_bytes, stream)
                 _lib.check(rc, "s360_backward_split")
-                _RasterizeViews.last_deferred = DeferredSH(prm, vw, m3, sh, d_rgb)
+                ctx.holder["deferred"] = _RasterizeViews.last_deferred = DeferredSH(prm, vw, m3, sh, d_rgb)
                 if d_m2 is not None:
                     d_m2 = d_m2.sum(0) if v > 1 else d_m2[0]
                 return d_m3, d_m2, None, None, d_op.view(-1, 1), d_c6, None, None, None
@@ -323,6 +325,7 @@ class _RasterizeViews(torch.autograd.Function):
 
 _RasterizeViews.last_state = None
 _RasterizeViews.last_deferred = None
+_RasterizeViews.last_holder = None
 
 
 class FusedMse(NamedTuple):
@@ -346,7 +349,16 @@ class DeferredSH:
 
 
 def last_deferred() -> Optional[DeferredSH]:
+    """DeferredSH of the most recent deferred-SH backward in this process (prefer deferred_of(images): it is tied to one
+    rasteriser call and therefore safe with several defer_sh calls per step)."""
     return _RasterizeViews.last_deferred
+
+
+def deferred_of(images: Tensor) -> Optional[DeferredSH]:
+    """The DeferredSH that the backward of THIS rasteriser call left behind (images = the tensor returned by
+    rasterize_views / render_views_fused with defer_sh=True); None before its backward has run."""
+    holder = getattr(images, "s360_deferred", None)
+    return None if holder is None else holder.get("deferred")
 
 
 def finish_deferred_sh(prm, views: Tensor, means3D: Tensor, shs: Tensor, d_rgb_sums: Tensor, d_means3D: Tensor) -> Tensor:
@@ -396,6 +408,7 @@ def rasterize_views(means3D: Tensor, cov6: Tensor, opacities: Tensor, shs: Optio
            sh_channel_major, keep_offsets, depth_mode, defer_sh, mse_weight, mse_count, bool(spherical))
     images, radii, depth, loss, clipped = _RasterizeViews.apply(means3D, means2D, shs, colors_precomp, op2, cov6, views,
                                                                 cfg, mse_target)
+    images.s360_deferred = _RasterizeViews.last_holder      # see deferred_of()
     out = (images, radii) if depth_mode is None else (images, radii, depth)
     return out if mse_target is None else out + (FusedMse(loss, clipped),)
 

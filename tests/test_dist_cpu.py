@@ -172,3 +172,96 @@ def test_two_rank_factored_exchange_reconstructs_the_summed_sh_gradient():
         for a, b, tol in zip(got, want, (1e-12, 1e-12, 2e-5, 1e-12)):   # SH goes through float32 factors
             scale = np.abs(b).max() + 1e-30
             assert np.abs(a - b).max() / scale <= tol
+
+
+def _pipe_inputs(rank, step, p=257):
+    """Deterministic per-(rank, step) gradients and factors of a made-up backward (float64 so that sums are exact enough)."""
+    rng = np.random.default_rng(1000 * step + rank)
+    cov = np.zeros((p, 3, 3)); r, c = np.triu_indices(3); cov[:, r, c] = rng.standard_normal((p, 6))
+    vis = rng.uniform(size=p) < 0.7
+    drgb = rng.standard_normal((p, 3)) * vis[:, None]
+    campos = np.array([0.1 * rank, -0.2 * rank, 0.05 * step], np.float32)
+    return dict(means=rng.standard_normal((p, 3)), cov=cov, op=rng.standard_normal(p), drgb=drgb, vis=vis, campos=campos)
+
+
+def _pipe_cloud(p=257):
+    rng = np.random.default_rng(77)
+    return rng.uniform(-2, 2, (p, 3)).astype(np.float32), rng.standard_normal((p, 25, 3)).astype(np.float32)
+
+
+def _pipelined_worker(rank, world, port, q):
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    sys.path[:0] = [str(root), str(root / "tests")]
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from splatter360_amd import distributed as D, rasterizer
+    D.init(backend="gloo")
+    rasterizer.finish_deferred_sh = _sh_pass_restated
+    m3, shs = _pipe_cloud()
+    means = torch.tensor(m3, dtype=torch.float64)
+    cov = torch.zeros((257, 3, 3), dtype=torch.float64)
+    op = torch.zeros(257, dtype=torch.float64)
+    sh = torch.tensor(shs)
+    results, pending = [], None
+    for step in range(3):
+        inp = _pipe_inputs(rank, step)
+        # --- "forward of micro-batch `step`" would be enqueued here, while the previous exchange is in flight ---
+        if pending is not None:
+            results.append([g.double().numpy().copy() for g in pending.finish()])
+        # --- "backward of micro-batch `step`": fills .grad and leaves the deferred SH factors ---
+        means.grad, cov.grad, op.grad = torch.tensor(inp["means"]), torch.tensor(inp["cov"]), torch.tensor(inp["op"])
+        d_rgb_sum = torch.zeros((257, 4), dtype=torch.float32)
+        d_rgb_sum[:, :3] = torch.tensor(inp["drgb"], dtype=torch.float32)
+        d_rgb_sum[:, 3] = torch.where(torch.tensor(inp["vis"]), torch.tensor(0, dtype=torch.int32), torch.tensor(-1, dtype=torch.int32)).view(torch.float32)
+        views = torch.zeros((1, 44), dtype=torch.float32)
+        views[0, 32:35] = torch.tensor(inp["campos"])
+        views[0, 40] = 1.0
+        pending = D.start_factored_exchange(means, cov, sh, op, rasterizer.DeferredSH(None, views, means.float(), sh, d_rgb_sum))
+        assert means.grad is None and cov.grad is None and op.grad is None     # buffers now belong to the exchange
+    results.append([g.double().numpy().copy() for g in pending.finish()])
+    # reduce-scatter by Gaussian range (sharded consumer): rank r gets rows [r*per, (r+1)*per) of the sum
+    full = [torch.tensor(_pipe_inputs(rank, 9)["means"]), torch.tensor(_pipe_inputs(rank, 9)["cov"])]
+    mine = D.reduce_scatter_gradients(full)
+    q.put((rank, results, [m.numpy() for m in mine]))
+    torch.distributed.destroy_process_group()
+
+
+def test_four_rank_pipelined_factored_exchange_and_reduce_scatter():
+    """world size 4 (gloo): three micro-steps whose exchanges are started after each backward and finished only after the
+    next micro-step's forward slot (the overlapped schedule of bench.py), the 40-byte packed all-reduce with the 6-entry
+    covariance, and the reduce-scatter variant for a consumer sharded by Gaussian range."""
+    world, port = 4, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pipelined_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    outs = [q.get(timeout=300) for _ in range(world)]
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    m3, shs = _pipe_cloud()
+    for step in range(3):
+        ins = [_pipe_inputs(r, step) for r in range(world)]
+        want_m = sum(i["means"] for i in ins)
+        want_c = sum(i["cov"] for i in ins)
+        want_o = sum(i["op"] for i in ins)
+        rgb = torch.zeros((world, 257, 4), dtype=torch.float32)
+        views = torch.zeros((world, 44), dtype=torch.float32)
+        for r, i in enumerate(ins):
+            rgb[r, :, :3] = torch.tensor(i["drgb"], dtype=torch.float32)
+            rgb[r, :, 3] = torch.where(torch.tensor(i["vis"]), torch.tensor(r, dtype=torch.int32), torch.tensor(-1, dtype=torch.int32)).view(torch.float32)
+            views[r, 32:35] = torch.tensor(i["campos"]); views[r, 40] = 1.0
+        want_sh = _sh_pass_restated(None, views, torch.tensor(m3), torch.tensor(shs), rgb, None).double().numpy()
+        for rank, results, _ in outs:
+            gm, gc, gs, go = results[step]
+            np.testing.assert_allclose(gm, want_m, rtol=1e-12, atol=1e-12)
+            np.testing.assert_allclose(gc, want_c, rtol=1e-12, atol=1e-12)
+            np.testing.assert_allclose(go, want_o, rtol=1e-12, atol=1e-12)
+            np.testing.assert_allclose(gs, want_sh, rtol=1e-5, atol=1e-5)
+    full_m = sum(_pipe_inputs(r, 9)["means"] for r in range(world))
+    full_c = sum(_pipe_inputs(r, 9)["cov"] for r in range(world))
+    per = (257 + world - 1) // world
+    for rank, _, mine in outs:
+        lo, hi = rank * per, min(257, (rank + 1) * per)
+        np.testing.assert_allclose(mine[0], full_m[lo:hi], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(mine[1], full_c[lo:hi], rtol=1e-12, atol=1e-12)
