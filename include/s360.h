@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define S360_ABI_VERSION 10
+#define S360_ABI_VERSION 11
 #define S360_MAX_VIEWS 8
 #define S360_TILE 16
 
@@ -125,6 +125,10 @@ typedef struct S360Layout {
     size_t n_contrib;           /* uint32[V*H*W] */
     size_t tile_max_contrib;    /* uint32[V*T] */
     size_t strip_last;          /* uint32[V*T*4] max n_contrib of each of the four 8x8 quadrants of a tile */
+    size_t rgbc;                /* float4[P]  SH colour of every Gaussian (r, g, b, clamp bits) when the views share a camera
+                                   centre: evaluated once per call by a streaming kernel ahead of the geometry pass */
+    size_t sh_jac;              /* float[P,3,3] d(rgb_c)/d(mean) through the view direction (training calls only): lets the
+                                   backward add that term to dL/dmean without re-reading the 300-byte SH slab */
     size_t backward_bytes;      /* size of the separate backward scratch workspace */
 } S360Layout;
 
@@ -209,11 +213,12 @@ int s360_backward(const S360Params* prm, const S360View* views, const float* mea
  * parameters under DDP, src/main.py:117-130).  dL/dSH of one rendered panorama is, per Gaussian, the rank-1
  * product Y(dir) (x) dL/dRGB; summing it over N ranks by all-reducing N full 300-byte slabs moves 25x more
  * bytes than exchanging the factors.  s360_backward_split() is s360_backward() for views sharing one camera
- * centre (S360_FLAG_SHARED_CAMPOS) WITHOUT the SH pass: it returns d_means3D (without the view-direction
- * term), d_cov6, d_opacities and d_rgb_sum[P,4] = (clamp-masked sum of dL/dRGB, index of the first view that
- * saw the Gaussian or -1 as int32 bits).  After all-gathering d_rgb_sum (with .w rewritten to the index of the
- * owning rank's representative view, or -1) and one S360View per rank, s360_sh_backward() produces the summed
- * dL/dSH and adds every rank's view-direction term to d_means3D (already all-reduced).
+ * centre (S360_FLAG_SHARED_CAMPOS) WITHOUT the dL/dSH pass: it returns d_means3D (complete, including this rank's
+ * view-direction term — the forward keeps d(rgb)/d(mean) per Gaussian, S360Layout.sh_jac), d_cov6, d_opacities and
+ * d_rgb_sum[P,4] = (clamp-masked sum of dL/dRGB, index of the first view that saw the Gaussian or -1 as int32
+ * bits).  After all-gathering d_rgb_sum (with .w rewritten to the index of the owning rank's representative view,
+ * or -1) and one S360View per rank, s360_sh_backward() writes the summed dL/dSH = sum_ranks Y(dir_rank) (x) dRGB_rank
+ * (it reads neither the SH coefficients nor any gradient buffer: 16 B in per Gaussian and rank, 300 B out).
  */
 int s360_backward_split(const S360Params* prm, const S360View* views, const float* means3D,
                         const float* cov6, const float* opacities, const float* shs,
@@ -223,8 +228,8 @@ int s360_backward_split(const S360Params* prm, const S360View* views, const floa
                         float* d_opacities, float* d_rgb_sum, void* bwd_workspace,
                         size_t bwd_workspace_bytes, void* stream);
 int s360_sh_backward(const S360Params* prm, int32_t n_groups, const S360View* views,
-                     const float* means3D, const float* shs, const float* d_rgb_sums /* [n_groups,P,4] */,
-                     float* d_means3D_inout, float* d_shs, void* stream);
+                     const float* means3D, const float* d_rgb_sums /* [n_groups,P,4] */, float* d_shs,
+                     void* stream);
 
 /*
  * Camera records of a call in one launch: replaces the reference's per-call camera glue

@@ -26,7 +26,7 @@ FLAG_SH_CHANNEL_MAJOR = 4
 FLAG_FORWARD_ONLY = 8
 FLAG_SH_DEG4_IGNORED = 16
 FLAG_SPHERICAL = 32
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class S360Params(C.Structure):
@@ -39,7 +39,7 @@ class S360Layout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in (
         "total_bytes", "header", "tiles_touched", "offsets", "rec_a", "rec_b", "rec_c",
         "clamped", "depths", "tile_count", "scan_scratch", "tile_start", "tile_cursor", "chunk_start", "tile_order", "keys", "keys_alt", "list", "final_T", "n_contrib",
-        "tile_max_contrib", "strip_last", "backward_bytes")]
+        "tile_max_contrib", "strip_last", "rgbc", "sh_jac", "backward_bytes")]
 
 
 EXPORTS = ("s360_abi_version", "s360_error_string", "s360_layout", "s360_forward", "s360_forward_depth", "s360_forward_mse", "s360_backward", "s360_backward_split", "s360_sh_backward", "s360_pack_views", "s360_adapter_forward", "s360_adapter_backward",
@@ -140,7 +140,7 @@ def lib() -> C.CDLL:
     l.s360_backward_split.restype = C.c_int
     l.s360_backward_split.argtypes = [C.POINTER(S360Params)] + [vp] * 6 + [sz] + [vp] * 2 + [i32] + [vp] * 6 + [sz, vp]
     l.s360_sh_backward.restype = C.c_int
-    l.s360_sh_backward.argtypes = [C.POINTER(S360Params), i32] + [vp] * 7
+    l.s360_sh_backward.argtypes = [C.POINTER(S360Params), i32] + [vp] * 5
     l.s360_pack_views.restype = C.c_int
     l.s360_pack_views.argtypes = [vp] * 5 + [i32, i32, i32, vp, vp]
     f32 = C.c_float

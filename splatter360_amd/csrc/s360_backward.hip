@@ -64,7 +64,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess_bwd(
     const float* __restrict__ shs, const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ offsets,
     const uint8_t* __restrict__ clamped, const float4* __restrict__ pairgrad, float* __restrict__ d_means3D,
     float* __restrict__ d_means2D, float* __restrict__ d_cov6, float* __restrict__ d_opac, float* __restrict__ d_shs,
-    float* __restrict__ d_colors, float4* __restrict__ drgb_out, int depth_mode) {
+    float* __restrict__ d_colors, float4* __restrict__ drgb_out, int depth_mode, const float* __restrict__ sh_jac) {
     extern __shared__ __attribute__((aligned(16))) float lds_sh[];  // [256*M*3] SH slab, then [256*V*3] dRGB
     const int tid = threadIdx.x;
     const int g0 = blockIdx.x * S360_BLOCK;
@@ -349,6 +349,16 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess_bwd(
                 }
             }
         }
+        if (USE_SH && !SH_PASS && sh_jac && any_visible) {
+            // view-direction term of dL/dmean from the forward's d(rgb)/d(mean) (k_sh_eval): no SH slab re-read
+            const float* J = sh_jac + 9 * (size_t)g;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                dm0 += drgb_sum[ch] * J[3 * ch];
+                dm1 += drgb_sum[ch] * J[3 * ch + 1];
+                dm2 += drgb_sum[ch] * J[3 * ch + 2];
+            }
+        }
         d_means3D[3 * g] = dm0;
         d_means3D[3 * g + 1] = dm1;
         d_means3D[3 * g + 2] = dm2;
@@ -386,123 +396,49 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess_bwd(
     }
 }
 
-// SH backward for views sharing one camera centre: a pure streaming kernel, ONE WAVE per workgroup so the
-// load / compute / store phases of the (up to 8) waves on a CU overlap freely.  Per Gaussian a lane reads
-// its 300-byte SH slab directly (16-byte loads, every byte of every line consumed by that lane) and the
-// summed dL/dRGB, computes dL/dSH = Y_k * dRGB_c and the view-direction term of dL/dmean; the 64 output
-// slabs (19.2 KB, contiguous in memory) go through LDS so the global stores are fully coalesced 16-byte
-// writes (lane-strided stores of partial lines cost ~2x here).
-// MULTI: more than one (view, dRGB) group per Gaussian — the slab is accumulated in LDS instead of stored once.
-#define S360_SH_PUT(i, v)            \
-    do {                             \
-        if (MULTI)                   \
-            mine[i] += (v);          \
-        else                         \
-            mine[i] = (v);           \
-    } while (0)
-template <bool CH_MAJOR, bool FAST, bool MULTI>  // FAST: degree 4, 25 stored coefficients (the reference's configuration)
+// dL/dSH for views sharing one camera centre: a pure streaming WRITE kernel, ONE WAVE per workgroup so that the
+// compute / store phases of the (up to 8) waves on a CU overlap freely.  Per Gaussian a lane reads the summed dL/dRGB
+// (16 B) and its mean (12 B), evaluates the SH basis at the view direction and forms dL/dSH = Y_k * dRGB_c; the 64 output
+// slabs (19.2 KB, contiguous in memory) go through LDS so the global stores are fully coalesced 16-byte writes
+// (lane-strided stores of partial lines cost ~2x here).  The SH coefficients themselves are NOT read: the view-direction
+// term of dL/dmean they used to be needed for comes from the forward's sh_jac (k_preprocess_bwd).
+// n_groups (view, summed dL/dRGB) pairs per Gaussian: 1 for a local backward; N when the factors of the rank-1 products
+// Y (x) dRGB of N ranks were all-gathered instead of all-reducing N full SH gradients (slab accumulated in LDS).
+template <bool CH_MAJOR>
 __global__ __launch_bounds__(64) void k_sh_bwd(KParams kp, const S360View* __restrict__ views, const float* __restrict__ means,
-                                              const float* __restrict__ shs, const float4* __restrict__ drgb_in, int n_groups,
-                                              float* __restrict__ d_means3D, float* __restrict__ d_shs) {
+                                              const float4* __restrict__ drgb_in, int n_groups, float* __restrict__ d_shs) {
     extern __shared__ __attribute__((aligned(16))) float lds_o[];  // [64][M*3]
     const int lane = threadIdx.x;
     const int g0 = blockIdx.x * 64;
     const int g = g0 + lane;
     const int slab = kp.M * 3;
     float* mine = lds_o + lane * slab;
-    const int deg = FAST ? 4 : kp.deg;
-    const int n_sh = (deg + 1) * (deg + 1);
-    // n_groups (view, summed dL/dRGB) pairs per Gaussian: 1 for a local backward; N when the factors of the
-    // rank-1 products Y (x) dRGB of N ranks were all-gathered instead of all-reducing N full SH gradients.
+    const int n_sh = (kp.deg + 1) * (kp.deg + 1);
+    const int sk = CH_MAJOR ? 1 : 3, sc_ = CH_MAJOR ? kp.M : 1;
     if (g < kp.P) {
-        if (MULTI)
-            for (int k = 0; k < slab; ++k) mine[k] = 0.f;
-        const float* sh = shs + (size_t)g * slab;
-        float dm0 = 0.f, dm1 = 0.f, dm2 = 0.f;
-        bool any = false;
+        for (int k = 0; k < slab; ++k) mine[k] = 0.f;
+        const float m0 = means[3 * g], m1 = means[3 * g + 1], m2 = means[3 * g + 2];
 #pragma unroll 1
         for (int j = 0; j < n_groups; ++j) {
             const float4 dr = drgb_in[(size_t)j * kp.P + g];
             const int fv = __float_as_int(dr.w);
-            if (fv < 0) {  // invisible in that group's views: no contribution
-                if (!MULTI)
-                    for (int k = 0; k < slab; ++k) mine[k] = 0.f;
-                continue;
-            }
-            any = true;
+            if (fv < 0) continue;  // invisible in that group's views: no contribution
             const S360View& vw = views[fv];
             const float sc = vw.scale;
-            const float ddx = means[3 * g] * sc - vw.campos[0], ddy = means[3 * g + 1] * sc - vw.campos[1],
-                        ddz = means[3 * g + 2] * sc - vw.campos[2];
+            const float ddx = m0 * sc - vw.campos[0], ddy = m1 * sc - vw.campos[1], ddz = m2 * sc - vw.campos[2];
             const float inv = 1.f / sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
-            const float x = ddx * inv, y = ddy * inv, z = ddz * inv;
-            float Y[25], s[25];
-            sh_basis(deg, x, y, z, Y);
-            const float drc[3] = {dr.x, dr.y, dr.z};
-            if (FAST && CH_MAJOR) {
-#pragma unroll
-                for (int k = 0; k < 25; ++k) s[k] = 0.f;
-#pragma unroll 1
-                for (int ch = 0; ch < 3; ++ch) {
-                    float c[25];
-                    load25(sh + 25 * ch, c);
-                    const float d = drc[ch];
-#pragma unroll
-                    for (int k = 0; k < 25; ++k) {
-                        s[k] += c[k] * d;
-                        S360_SH_PUT(25 * ch + k, Y[k] * d);
-                    }
-                }
-            } else if (FAST) {
-#pragma unroll 1
-                for (int q = 0; q < 5; ++q) {
-                    float c[15];
-                    load15(sh + 15 * q, c);
-#pragma unroll
-                    for (int k = 0; k < 5; ++k) {
-                        s[5 * q + k] = c[3 * k] * drc[0] + c[3 * k + 1] * drc[1] + c[3 * k + 2] * drc[2];
-                        S360_SH_PUT(15 * q + 3 * k, Y[5 * q + k] * drc[0]);
-                        S360_SH_PUT(15 * q + 3 * k + 1, Y[5 * q + k] * drc[1]);
-                        S360_SH_PUT(15 * q + 3 * k + 2, Y[5 * q + k] * drc[2]);
-                    }
-                }
-            } else {
-                const int sk = CH_MAJOR ? 1 : 3, sc_ = CH_MAJOR ? kp.M : 1;
-                if (!MULTI)
-                    for (int k = 0; k < slab; ++k) mine[k] = 0.f;  // stored coefficients beyond the active degree
-#pragma unroll
-                for (int k = 0; k < 25; ++k) {  // generic layout / degree (<= 25 active coefficients)
-                    if (k < n_sh) {
-                        s[k] = sh[k * sk] * drc[0] + sh[k * sk + sc_] * drc[1] + sh[k * sk + 2 * sc_] * drc[2];
-                        S360_SH_PUT(k * sk, Y[k] * drc[0]);
-                        S360_SH_PUT(k * sk + sc_, Y[k] * drc[1]);
-                        S360_SH_PUT(k * sk + 2 * sc_, Y[k] * drc[2]);
-                    }
-                }
-            }
-            float bx[25], by[25], bz[25];
-            sh_basis_grad(deg, x, y, z, bx, by, bz);
-            float q0 = 0.f, q1 = 0.f, q2 = 0.f;
+            float Y[25];
+            sh_basis(kp.deg, ddx * inv, ddy * inv, ddz * inv, Y);
 #pragma unroll
             for (int k = 0; k < 25; ++k) {
                 if (k < n_sh) {
-                    q0 += bx[k] * s[k];
-                    q1 += by[k] * s[k];
-                    q2 += bz[k] * s[k];
+                    mine[k * sk] += Y[k] * dr.x;
+                    mine[k * sk + sc_] += Y[k] * dr.y;
+                    mine[k * sk + 2 * sc_] += Y[k] * dr.z;
                 }
             }
-            const float dot = x * q0 + y * q1 + z * q2;
-            dm0 += sc * ((q0 - x * dot) * inv);
-            dm1 += sc * ((q1 - y * dot) * inv);
-            dm2 += sc * ((q2 - z * dot) * inv);
-        }
-        if (any) {
-            d_means3D[3 * g] += dm0;
-            d_means3D[3 * g + 1] += dm1;
-            d_means3D[3 * g + 2] += dm2;
         }
     }
-    if (!d_shs) return;  // only the view-direction term of dL/dmean was wanted (harmonics frozen / detached)
     __syncthreads();  // single wave: orders the LDS writes above before the cooperative read below
     const int nb = min(64, kp.P - g0);
     const int nfl = nb * slab;
@@ -531,30 +467,15 @@ using namespace s360;
         }                                                                                            \
     } while (0)
 
-static int launch_sh_bwd(const KParams& kp, const S360View* views, const float* means3D, const float* shs,
-                         const float4* drgb, int n_groups, float* d_means3D, float* d_shs, hipStream_t st) {
-    const bool fast = kp.M == 25 && kp.deg == 4, chm = (kp.flags & S360_FLAG_SH_CHANNEL_MAJOR) != 0;
+static int launch_sh_bwd(const KParams& kp, const S360View* views, const float* means3D, const float4* drgb, int n_groups,
+                         float* d_shs, hipStream_t st) {
     const int wblk = (kp.P + 63) / 64;
     const size_t wlds = (size_t)64 * kp.M * 3 * 4;
     if (wlds > 64 * 1024) return S360_E_UNSUPPORTED;
-#define S360_SH_LAUNCH(A, B)                                                                                        \
-    do {                                                                                                             \
-        if (n_groups > 1)                                                                                            \
-            hipLaunchKernelGGL((k_sh_bwd<A, B, true>), dim3(wblk), dim3(64), wlds, st, kp, views, means3D, shs, drgb, \
-                               n_groups, d_means3D, d_shs);                                                          \
-        else                                                                                                         \
-            hipLaunchKernelGGL((k_sh_bwd<A, B, false>), dim3(wblk), dim3(64), wlds, st, kp, views, means3D, shs, drgb, \
-                               n_groups, d_means3D, d_shs);                                                          \
-    } while (0)
-    if (chm && fast)
-        S360_SH_LAUNCH(true, true);
-    else if (chm)
-        S360_SH_LAUNCH(true, false);
-    else if (fast)
-        S360_SH_LAUNCH(false, true);
+    if (kp.flags & S360_FLAG_SH_CHANNEL_MAJOR)
+        hipLaunchKernelGGL((k_sh_bwd<true>), dim3(wblk), dim3(64), wlds, st, kp, views, means3D, drgb, n_groups, d_shs);
     else
-        S360_SH_LAUNCH(false, false);
-#undef S360_SH_LAUNCH
+        hipLaunchKernelGGL((k_sh_bwd<false>), dim3(wblk), dim3(64), wlds, st, kp, views, means3D, drgb, n_groups, d_shs);
     return S360_OK;
 }
 
@@ -629,13 +550,13 @@ static int backward_impl(const S360Params* prm, const S360View* views, const flo
         const bool shared = (kp.flags & S360_FLAG_SHARED_CAMPOS) != 0;
         if (d_rgb_sum && !shared) return S360_E_UNSUPPORTED;  // the split form needs one camera centre per call
         if (shared) {
+            // dRGB/d(view direction) reaches dL/dmean here (from the forward's sh_jac), whether or not dL/dSH is wanted
+            // (harmonics frozen: d_shs == NULL), as upstream does
             hipLaunchKernelGGL((k_preprocess_bwd<true, false>), dim3(nblk), dim3(S360_BLOCK), 0, st, kp, views, means3D, cov6, shs,
                                tiles_touched, offsets, clamped, pairgrad, d_means3D, d_means2D, d_cov6, d_opacities, d_shs,
-                               d_colors, drgb, dmode);
-            // the SH pass always runs: with d_shs == NULL (harmonics frozen) it still adds dRGB/ddir to dL/dmean,
-            // as upstream does
-            if (!d_rgb_sum) {
-                const int rc2 = launch_sh_bwd(kp, views, means3D, shs, drgb, 1, d_means3D, d_shs, st);
+                               d_colors, drgb, dmode, (const float*)(ws + L.sh_jac));
+            if (!d_rgb_sum && d_shs) {
+                const int rc2 = launch_sh_bwd(kp, views, means3D, drgb, 1, d_shs, st);
                 if (rc2) return rc2;
             }
         } else {
@@ -652,12 +573,12 @@ static int backward_impl(const S360Params* prm, const S360View* views, const flo
             }
             hipLaunchKernelGGL((k_preprocess_bwd<true, true>), dim3(nblk), dim3(S360_BLOCK), lds, st, kp, views, means3D, cov6, shs,
                                tiles_touched, offsets, clamped, pairgrad, d_means3D, d_means2D, d_cov6, d_opacities, d_shs,
-                               d_colors, (float4*)nullptr, dmode);
+                               d_colors, (float4*)nullptr, dmode, (const float*)nullptr);
         }
     } else {
         hipLaunchKernelGGL((k_preprocess_bwd<false, false>), dim3(nblk), dim3(S360_BLOCK), 0, st, kp, views, means3D, cov6, shs,
                            tiles_touched, offsets, clamped, pairgrad, d_means3D, d_means2D, d_cov6, d_opacities, d_shs,
-                           d_colors, (float4*)nullptr, dmode);
+                           d_colors, (float4*)nullptr, dmode, (const float*)nullptr);
     }
     S360_CHECK_LAUNCH();
     return S360_OK;
@@ -687,9 +608,8 @@ extern "C" int s360_backward_split(const S360Params* prm, const S360View* views,
 }
 
 extern "C" int s360_sh_backward(const S360Params* prm, int32_t n_groups, const S360View* views, const float* means3D,
-                                const float* shs, const float* d_rgb_sums, float* d_means3D_inout, float* d_shs,
-                                void* stream_) {
-    if (!prm || !views || !means3D || !shs || !d_rgb_sums || !d_means3D_inout || !d_shs || n_groups < 1) return S360_E_BADARG;
+                                const float* d_rgb_sums, float* d_shs, void* stream_) {
+    if (!prm || !views || !means3D || !d_rgb_sums || !d_shs || n_groups < 1) return S360_E_BADARG;
     if (prm->M < 1 || prm->sh_degree < 0 || prm->sh_degree > 4 || (prm->sh_degree + 1) * (prm->sh_degree + 1) > prm->M)
         return S360_E_BADARG;
     if (prm->P == 0) return S360_OK;
@@ -697,8 +617,7 @@ extern "C" int s360_sh_backward(const S360Params* prm, int32_t n_groups, const S
     kp.P = prm->P; kp.V = prm->V; kp.H = prm->H; kp.W = prm->W; kp.deg = s360_effective_degree(prm); kp.M = prm->M;
     kp.gx = kp.gy = kp.T = 0;
     kp.flags = prm->flags; kp.cap = prm->max_instances;
-    const int rc = launch_sh_bwd(kp, views, means3D, shs, (const float4*)d_rgb_sums, n_groups, d_means3D_inout, d_shs,
-                                 (hipStream_t)stream_);
+    const int rc = launch_sh_bwd(kp, views, means3D, (const float4*)d_rgb_sums, n_groups, d_shs, (hipStream_t)stream_);
     if (rc) return rc;
     S360_CHECK_LAUNCH();
     return S360_OK;

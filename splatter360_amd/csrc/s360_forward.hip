@@ -22,14 +22,94 @@
 
 namespace s360 {
 
+// ------------------------------------------------------------------------------ SH -> RGB (shared camera centre)
+// When all views of a call share one camera centre (the six faces of a panorama) the colour of a Gaussian does not
+// depend on the view: this streaming kernel evaluates it ONCE per Gaussian ahead of the geometry pass — each lane reads
+// its own 300-byte slab one colour channel (25 floats, 16-byte loads) at a time, so nothing but the SH basis is live and
+// the geometry kernel (k_preprocess<.., EAGER = true>) no longer carries the slab code.  Training calls (JAC) also store
+// J_c = d(rgb_c)/d(mean) through the view direction — (G_c - dir (dir . G_c)) * scale / |d| with
+// G_c = sum_k grad Y_k(dir) sh_kc — 36 bytes with which the backward adds that term to dL/dmean and never re-reads the slab.
+// Each lane streams its own slab with 16-byte loads, ALL of them (19 for the reference's 75 coefficients) in flight before
+// the first use: every byte of every cache line is consumed by the same lane within a few instructions, so HBM traffic stays
+// 1x whatever the occupancy (loading one colour channel at a time, the round-1 form, re-fetched every line three times once
+// occupancy let a CU's slabs outgrow its share of the L2: 365 us for the forward's SH + geometry pair instead of 140 us;
+// staging the wave's 19.2 KB through LDS with coalesced loads measured 156 us for this kernel: 8 waves per CU is too few).
+template <bool CH_MAJOR, bool JAC>
+__global__ __launch_bounds__(S360_BLOCK) void k_sh_eval(KParams kp, const S360View* __restrict__ views,
+                                                       const float* __restrict__ means, const float* __restrict__ shs,
+                                                       float4* __restrict__ rgbc, float* __restrict__ sh_jac) {
+    const int g = blockIdx.x * S360_BLOCK + threadIdx.x;
+    if (g >= kp.P) return;
+    const bool fast = kp.M == 25 && kp.deg == 4;
+    const float* sh = shs + (size_t)g * kp.M * 3;
+    float c[75];
+    if (fast) load75(sh, c);
+    const S360View& vw = views[0];
+    const float sc = vw.scale;
+    const float dx = means[3 * g] * sc - vw.campos[0], dy = means[3 * g + 1] * sc - vw.campos[1], dz = means[3 * g + 2] * sc - vw.campos[2];
+    const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+    const float x = dx * inv, y = dy * inv, z = dz * inv;
+    const int n = (kp.deg + 1) * (kp.deg + 1);
+    const int sk = CH_MAJOR ? 1 : 3, sc_ = CH_MAJOR ? kp.M : 1;
+    float acc[3], G[3][3];
+    // (Measured alternatives for the training variant, whose four 25-entry basis tables + 75 coefficients need 200 VGPRs =
+    // 2 waves per SIMD: one table at a time in four passes compiles to 176 VGPRs — still 2 waves; forcing 3 waves spills
+    // and runs 121 us instead of 106 us.)
+    float Y[25], bx[25], by[25], bz[25];
+    sh_basis(kp.deg, x, y, z, Y);
+    if (JAC) sh_basis_grad(kp.deg, x, y, z, bx, by, bz);
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        float a = 0.f, g0_ = 0.f, g1 = 0.f, g2 = 0.f;
+        if (fast) {
+#pragma unroll
+            for (int k = 0; k < 25; ++k) {
+                const float ck = c[CH_MAJOR ? 25 * ch + k : 3 * k + ch];
+                a += Y[k] * ck;  // sequential (unfused) accumulation: same rounding as the CPU oracle
+                if (JAC) {
+                    g0_ += bx[k] * ck;
+                    g1 += by[k] * ck;
+                    g2 += bz[k] * ck;
+                }
+            }
+        } else {
+            for (int k = 0; k < n; ++k) {
+                const float ck = sh[k * sk + ch * sc_];
+                a += Y[k] * ck;
+                if (JAC) {
+                    g0_ += bx[k] * ck;
+                    g1 += by[k] * ck;
+                    g2 += bz[k] * ck;
+                }
+            }
+        }
+        acc[ch] = a;
+        G[ch][0] = g0_; G[ch][1] = g1; G[ch][2] = g2;
+    }
+    const float a0 = acc[0] + 0.5f, a1 = acc[1] + 0.5f, a2 = acc[2] + 0.5f;
+    const uint32_t clampbits = (a0 < 0.f ? 1u : 0u) | (a1 < 0.f ? 2u : 0u) | (a2 < 0.f ? 4u : 0u);
+    rgbc[g] = make_float4(fmaxf(a0, 0.f), fmaxf(a1, 0.f), fmaxf(a2, 0.f), __uint_as_float(clampbits));
+    if (JAC) {
+        float* o = sh_jac + 9 * (size_t)g;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const float dot = x * G[ch][0] + y * G[ch][1] + z * G[ch][2];
+            o[3 * ch] = sc * ((G[ch][0] - x * dot) * inv);
+            o[3 * ch + 1] = sc * ((G[ch][1] - y * dot) * inv);
+            o[3 * ch + 2] = sc * ((G[ch][2] - z * dot) * inv);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------ preprocess
-template <bool USE_SH, bool CH_MAJOR>
+template <bool USE_SH, bool CH_MAJOR, bool EAGER = false>  // EAGER: colours come from k_sh_eval (rgbc), no slab code here
 __global__ __launch_bounds__(S360_BLOCK) void k_preprocess(
     KParams kp, const S360View* __restrict__ views, const float* __restrict__ means,
     const float* __restrict__ cov6, const float* __restrict__ opac, const float* __restrict__ shs,
     const float* __restrict__ colors, int32_t* __restrict__ radii, uint32_t* __restrict__ tiles_touched,
     float4* __restrict__ recA, float4* __restrict__ recB, float4* __restrict__ recC,
-    uint8_t* __restrict__ clamped, float* __restrict__ depths, uint32_t* __restrict__ tile_count, int lds_hist) {
+    uint8_t* __restrict__ clamped, float* __restrict__ depths, uint32_t* __restrict__ tile_count, int lds_hist,
+    const float4* __restrict__ rgbc) {
     // dynamic LDS: tile histogram V*T uint32 (lds_hist).  SH coefficients are NOT staged: every lane
     // streams its own Gaussian's 300-byte slab with 16-byte loads (all bytes of every cache line are
     // consumed by the same lane within a few instructions, so HBM traffic stays 1x) — this keeps the
@@ -121,7 +201,14 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess(
                 tile_rect(px, py, rad, kp.gx, kp.gy, minx, miny, maxx, maxy);
                 const int area = keep ? (maxx - minx) * (maxy - miny) : 0;
                 if (area != 0) {
-                    if (USE_SH && (!have_rgb || !shared_cam)) {
+                    if (USE_SH && EAGER) {
+                        if (!have_rgb) {
+                            const float4 cc = rgbc[g];
+                            rgb[0] = cc.x; rgb[1] = cc.y; rgb[2] = cc.z;
+                            clampbits = __float_as_uint(cc.w);
+                            have_rgb = true;
+                        }
+                    } else if (USE_SH && (!have_rgb || !shared_cam)) {
                         const float dx = mx - vw.campos[0], dy = my - vw.campos[1], dz = mz - vw.campos[2];
                         const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
                         const float x = dx * inv, y = dy * inv, z = dz * inv;
@@ -1029,6 +1116,8 @@ extern "C" int s360_layout(const S360Params* prm, S360Layout* out) {
     out->n_contrib = take(npix * 4);
     out->tile_max_contrib = take(nt * 4);
     out->strip_last = take(nt * 4 * 4);
+    out->rgbc = take((size_t)(prm->P > 0 ? prm->P : 1) * 16);
+    out->sh_jac = take((size_t)(prm->P > 0 ? prm->P : 1) * 36);
     out->total_bytes = o;
     // backward scratch: 4 quadrant-partial raster-gradient records (12 floats) + 4 validity bytes per instance
     // ... + tile order [V*T] + one gathered 48-byte record per (view, Gaussian) pair
@@ -1103,20 +1192,37 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
         const int nblk = (kp.P + S360_BLOCK - 1) / S360_BLOCK;
         const size_t hist_bytes = (size_t)nt * 4;
         const int lds_hist = hist_bytes <= 48 * 1024 ? 1 : 0;
+        // views sharing one camera centre: SH colours once per Gaussian in their own streaming kernel.  Always in training
+        // calls (the backward relies on sh_jac); in inference calls only when several views amortise the full-cloud read
+        // (a single-face drop-in call sees ~17 % of the cloud and keeps the lazy in-kernel evaluation).
+        const bool eager = shs && (kp.flags & S360_FLAG_SHARED_CAMPOS) && (!(kp.flags & S360_FLAG_FORWARD_ONLY) || kp.V >= 2);
+        float4* rgbc = (float4*)(ws + L.rgbc);
+        if (eager) {
+            float* sh_jac = (float*)(ws + L.sh_jac);
+            const bool jac = !(kp.flags & S360_FLAG_FORWARD_ONLY);
+            const bool chm = (kp.flags & S360_FLAG_SH_CHANNEL_MAJOR) != 0;
+#define S360_SHE(A, B) hipLaunchKernelGGL((k_sh_eval<A, B>), dim3(nblk), dim3(S360_BLOCK), 0, st, kp, views, means3D, shs, rgbc, sh_jac)
+            if (chm && jac) S360_SHE(true, true); else if (chm) S360_SHE(true, false); else if (jac) S360_SHE(false, true); else S360_SHE(false, false);
+#undef S360_SHE
+        }
         if (shs) {
             const size_t lds = lds_hist ? hist_bytes : 0;
-            if (kp.flags & S360_FLAG_SH_CHANNEL_MAJOR)
+            if (eager)
+                hipLaunchKernelGGL((k_preprocess<true, true, true>), dim3(nblk), dim3(S360_BLOCK), lds, st, kp, views, means3D, cov6,
+                                   opacities, shs, colors_precomp, radii, tiles_touched, recA, recB, recC, clamped, depths,
+                                   tile_count, lds_hist, rgbc);
+            else if (kp.flags & S360_FLAG_SH_CHANNEL_MAJOR)
                 hipLaunchKernelGGL((k_preprocess<true, true>), dim3(nblk), dim3(S360_BLOCK), lds, st, kp, views, means3D, cov6,
                                    opacities, shs, colors_precomp, radii, tiles_touched, recA, recB, recC, clamped, depths,
-                                   tile_count, lds_hist);
+                                   tile_count, lds_hist, rgbc);
             else
                 hipLaunchKernelGGL((k_preprocess<true, false>), dim3(nblk), dim3(S360_BLOCK), lds, st, kp, views, means3D, cov6,
                                    opacities, shs, colors_precomp, radii, tiles_touched, recA, recB, recC, clamped, depths,
-                                   tile_count, lds_hist);
+                                   tile_count, lds_hist, rgbc);
         } else {
             hipLaunchKernelGGL((k_preprocess<false, false>), dim3(nblk), dim3(S360_BLOCK), lds_hist ? hist_bytes : 0, st, kp, views,
                                means3D, cov6, opacities, shs, colors_precomp, radii, tiles_touched, recA, recB, recC, clamped,
-                               depths, tile_count, lds_hist);
+                               depths, tile_count, lds_hist, rgbc);
         }
         }
         S360_CHECK_LAUNCH();

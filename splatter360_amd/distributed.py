@@ -116,15 +116,13 @@ class FactoredExchange:
         d = self.deferred
         for w in self.works_ag:
             w.wait()
-        # the SH pass adds every rank's view-direction term of dL/dmean into a scratch buffer (the packed buffer is still
-        # being all-reduced); it is folded in once the all-reduce has landed
-        dm_extra = torch.zeros((self.small.shape[0], 3), dtype=self.small.dtype, device=self.small.device)
+        # dL/dSH = sum over ranks of Y(dir_rank) (x) dRGB_rank, rebuilt locally while the packed buffer is still being
+        # all-reduced (every rank's view-direction term of dL/dmean is already inside its d_means: s360_backward_split)
         d_sh = rasterizer.finish_deferred_sh(d.prm, self.rep_all.reshape(self.world, -1), d.means3D, d.shs,
-                                             self.rgb_all.view(self.world, -1, 4), dm_extra)
+                                             self.rgb_all.view(self.world, -1, 4))
         if self.work_ar is not None:
             self.work_ar.wait()
         d_means, d_cov, d_op = _unpack_small(self.small, covariances)
-        d_means = d_means + dm_extra.to(d_means.dtype)
         means.grad, covariances.grad, harmonics.grad = d_means.reshape(means.shape), d_cov, d_sh
         opacities.grad = d_op.reshape(opacities.shape)
         self.result = (means.grad, covariances.grad, harmonics.grad, opacities.grad)

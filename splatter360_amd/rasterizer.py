@@ -361,16 +361,16 @@ def deferred_of(images: Tensor) -> Optional[DeferredSH]:
     return None if holder is None else holder.get("deferred")
 
 
-def finish_deferred_sh(prm, views: Tensor, means3D: Tensor, shs: Tensor, d_rgb_sums: Tensor, d_means3D: Tensor) -> Tensor:
+def finish_deferred_sh(prm, views: Tensor, means3D: Tensor, shs: Tensor, d_rgb_sums: Tensor) -> Tensor:
     """s360_sh_backward: views[n,44] (one representative camera per group), d_rgb_sums[n,P,4] with .w = the
-    group's index into `views` (int32 bits) or -1.  Adds the view-direction terms to d_means3D in place and
-    returns dL/dSH (same layout as shs)."""
+    group's index into `views` (int32 bits) or -1.  Returns the summed dL/dSH (shape / layout of `shs`, which is only a
+    template here: the kernel reads neither the coefficients nor any gradient buffer)."""
     d_sh = torch.empty_like(shs)
     n = int(d_rgb_sums.shape[0])
     with torch.cuda.device(shs.device):
         stream = C.c_void_p(torch.cuda.current_stream(shs.device).cuda_stream)
-        rc = _lib.lib().s360_sh_backward(C.byref(prm), n, _ptr(views.contiguous()), _ptr(means3D), _ptr(shs),
-                                         _ptr(d_rgb_sums.contiguous()), _ptr(d_means3D), _ptr(d_sh), stream)
+        rc = _lib.lib().s360_sh_backward(C.byref(prm), n, _ptr(views.contiguous()), _ptr(means3D),
+                                         _ptr(d_rgb_sums.contiguous()), _ptr(d_sh), stream)
     _lib.check(rc, "s360_sh_backward")
     return d_sh
 

@@ -102,9 +102,9 @@ def _rank_view(rank):
     return cloud, S, g, drgb, vis
 
 
-def _sh_pass_restated(prm, views, means3D, shs, d_rgb_sums, d_means3D):
-    """torch restatement of what s360_sh_backward computes for dL/dSH (the view-direction term of dL/dmean is left
-    out: d_means3D is not touched) — stands in for the HIP kernel in this CPU test of the exchange logic."""
+def _sh_pass_restated(prm, views, means3D, shs, d_rgb_sums):
+    """torch restatement of what s360_sh_backward computes (dL/dSH = sum over groups of Y(dir) (x) dRGB; `shs` is only a
+    shape template) — stands in for the HIP kernel in this CPU test of the exchange logic."""
     from oracle import torch_ref
     out = torch.zeros_like(shs)                       # [P, 25, 3]
     for j in range(d_rgb_sums.shape[0]):
@@ -251,7 +251,7 @@ def test_four_rank_pipelined_factored_exchange_and_reduce_scatter():
             rgb[r, :, :3] = torch.tensor(i["drgb"], dtype=torch.float32)
             rgb[r, :, 3] = torch.where(torch.tensor(i["vis"]), torch.tensor(r, dtype=torch.int32), torch.tensor(-1, dtype=torch.int32)).view(torch.float32)
             views[r, 32:35] = torch.tensor(i["campos"]); views[r, 40] = 1.0
-        want_sh = _sh_pass_restated(None, views, torch.tensor(m3), torch.tensor(shs), rgb, None).double().numpy()
+        want_sh = _sh_pass_restated(None, views, torch.tensor(m3), torch.tensor(shs), rgb).double().numpy()
         for rank, results, _ in outs:
             gm, gc, gs, go = results[step]
             np.testing.assert_allclose(gm, want_m, rtol=1e-12, atol=1e-12)
