@@ -3,9 +3,9 @@ Units: FETCH_SIZE / WRITE_SIZE are in KiB.  gfx950 correction (MI355X_MICROARCH.
 counts 64 B per 128-B request for wide (16 B/lane) coalesced streaming reads -> doubled for the kernels
 whose reads are dominated by such streams; other kernels are reported raw (uncalibrated)."""
 import collections, csv, json, sys
-STREAMING = ("k_preprocess<", "k_preprocess_bwd<", "k_sh_bwd<")   # wide (16 B/lane) streaming reads dominate
+STREAMING = ("k_preprocess<", "k_preprocess_bwd<", "k_sh_eval<")   # wide (16 B/lane) streaming reads dominate
 SLOT = {"k_preprocess<": "preprocess", "k_render<": "render", "k_render_bwd": "render_bwd", "k_preprocess_bwd<": "geometry_bwd",
-        "k_sh_bwd<": "sh_bwd", "k_emit<": "emit", "k_gather_pairs": "gather_pairs", "k_cube2erp_fwd": "cube2erp"}
+        "k_sh_bwd<": "sh_bwd", "k_sh_eval<": "sh_eval", "k_render_bwd_em<": "render_bwd", "k_emit<": "emit", "k_gather_pairs": "gather_pairs", "k_cube2erp_fwd": "cube2erp"}
 
 
 def slot_of(k):
