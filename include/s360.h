@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define S360_ABI_VERSION 11
+#define S360_ABI_VERSION 12
 #define S360_MAX_VIEWS 8
 #define S360_TILE 16
 
@@ -125,6 +125,8 @@ typedef struct S360Layout {
     size_t n_contrib;           /* uint32[V*H*W] */
     size_t tile_max_contrib;    /* uint32[V*T] */
     size_t strip_last;          /* uint32[V*T*4] max n_contrib of each of the four 8x8 quadrants of a tile */
+    size_t slot_pair;           /* uint32[max_instances] pair index p of every instance slot (training calls): lets the backward
+                                   sum the per-(instance, quadrant) partial gradients slot-parallel */
     size_t rgbc;                /* float4[P]  SH colour of every Gaussian (r, g, b, clamp bits) when the views share a camera
                                    centre: evaluated once per call by a streaming kernel ahead of the geometry pass */
     size_t sh_jac;              /* float[P,3,3] d(rgb_c)/d(mean) through the view direction (training calls only): lets the

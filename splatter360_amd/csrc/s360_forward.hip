@@ -459,6 +459,11 @@ __global__ __launch_bounds__(S360_BLOCK) void k_tile_scan(const uint32_t* __rest
         header[0] = carry;                    // num_instances ("num_rendered")
         header[1] = carry > cap ? 1u : 0u;    // overflow flag
         header[2] = lds_max;                  // longest tile list
+        {   // merge passes the longest (capacity-clamped) list needs: k_merge_pass launches beyond it return at once
+            const uint32_t nmax = min(lds_max, cap);
+            const uint32_t nch = nmax > SORT_SHORT ? (nmax + SORT_CHUNK - 1) / SORT_CHUNK : 0u;
+            header[3] = nch <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(nch - 1);
+        }
         for (int i = 8; i < 16; ++i) header[i] = 0;  // debug counters
     }
 }
@@ -476,7 +481,8 @@ template <bool LDS_BIN>
 __global__ __launch_bounds__(S360_BLOCK) void k_emit(KParams kp, const uint32_t* __restrict__ tiles_touched,
                                                     const float4* __restrict__ recA, const float4* __restrict__ recC,
                                                     const float* __restrict__ depths, const uint32_t* __restrict__ tile_start,
-                                                    uint32_t* __restrict__ tile_cursor, uint64_t* __restrict__ keys) {
+                                                    uint32_t* __restrict__ tile_cursor, uint64_t* __restrict__ keys,
+                                                    const uint32_t* __restrict__ offsets, uint32_t* __restrict__ slot_pair) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_bin[];  // [T] counts/cursors, [T] bases
     const int v = blockIdx.y;
     const int g0 = blockIdx.x * (S360_BLOCK * EMIT_PPT) + threadIdx.x;
@@ -521,12 +527,19 @@ __global__ __launch_bounds__(S360_BLOCK) void k_emit(KParams kp, const uint32_t*
         int minx, miny, maxx, maxy;
         tile_rect(ra.x, ra.y, __float_as_int(rc.y), kp.gx, kp.gy, minx, miny, maxx, maxy);
         const uint64_t key = ((uint64_t)__float_as_uint(depths[p]) << 32) | (uint64_t)(uint32_t)p;
+        // training calls: owner table of the pair's instance slots (slot = offsets[p-1] + position inside the rectangle in
+        // this emission order — the slot the backward composite writes its partial gradients to)
+        uint32_t slot = slot_pair ? (p == 0 ? 0u : offsets[p - 1]) : 0u;
         for (int y = miny; y < maxy; ++y)
             for (int x = minx; x < maxx; ++x) {
                 const int t = y * kp.gx + x;
                 const uint32_t pos = LDS_BIN ? base[t] + atomicAdd(&cnt[t], 1u)
                                              : tile_start[tb + t] + atomicAdd(&tile_cursor[tb + t], 1u);
                 if (pos < kp.cap) keys[pos] = key;
+                if (slot_pair) {
+                    if (slot < kp.cap) slot_pair[slot] = (uint32_t)p;
+                    ++slot;
+                }
             }
     }
 }
@@ -667,11 +680,16 @@ __global__ __launch_bounds__(512) void k_sort_chunks(const uint32_t* __restrict_
                                                     int nt, uint64_t* __restrict__ keys, uint64_t* __restrict__ alt,
                                                     uint32_t* __restrict__ list, uint32_t cap, uint32_t max_passes) {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds_m[];
-    const ChunkUnit u = chunk_unit(tile_start, chunk_start, nt, cap, blockIdx.x);
-    if (!u.valid || u.passes > max_passes) return;
-    const uint32_t c0 = u.k * SORT_CHUNK, len = min(SORT_CHUNK, u.n - c0);
-    uint64_t* dst = ((u.passes & 1u) ? alt : keys) + u.s + c0;
-    block_merge_sort<512, 8>(keys + u.s + c0, dst, u.passes == 0 ? list + u.s : nullptr, len, lds_m);  // single chunk: done
+    const uint32_t nchunks = chunk_start[nt];
+    for (uint32_t b = blockIdx.x; b < nchunks; b += gridDim.x) {  // the grid is sized on the host without knowing nchunks
+        const ChunkUnit u = chunk_unit(tile_start, chunk_start, nt, cap, b);
+        if (u.valid && u.passes <= max_passes) {
+            const uint32_t c0 = u.k * SORT_CHUNK, len = min(SORT_CHUNK, u.n - c0);
+            uint64_t* dst = ((u.passes & 1u) ? alt : keys) + u.s + c0;
+            block_merge_sort<512, 8>(keys + u.s + c0, dst, u.passes == 0 ? list + u.s : nullptr, len, lds_m);  // single chunk: done
+        }
+        __syncthreads();
+    }
 }
 
 // Merge path over two sorted runs in global memory: number of A elements among the first d outputs.  Executed by
@@ -698,13 +716,17 @@ __device__ __forceinline__ uint32_t merge_path_global_wave(const uint64_t* __res
 
 __global__ __launch_bounds__(512) void k_merge_pass(const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ chunk_start,
                                                    int nt, uint64_t* __restrict__ keys, uint64_t* __restrict__ alt,
-                                                   uint32_t* __restrict__ list, uint32_t cap, uint32_t pass, uint32_t max_passes) {
+                                                   uint32_t* __restrict__ list, uint32_t cap, uint32_t pass, uint32_t max_passes,
+                                                   const uint32_t* __restrict__ header) {
     constexpr int THREADS = 512, E = 8;
     extern __shared__ __attribute__((aligned(16))) uint64_t lds_m[];  // [SORT_CHUNK + SORT_CHUNK/E] skewed
     __shared__ uint32_t s_part[2];
 #define S360_PHYS(i) ((i) + (i) / E)
-    const ChunkUnit u = chunk_unit(tile_start, chunk_start, nt, cap, blockIdx.x);
-    if (!u.valid || u.passes > max_passes || pass >= u.passes) return;
+    if (pass >= header[3]) return;  // no list of this call needs this pass (the host launches the worst-case count)
+    const uint32_t nchunks = chunk_start[nt];
+    for (uint32_t blk = blockIdx.x; blk < nchunks; blk += gridDim.x) {
+    const ChunkUnit u = chunk_unit(tile_start, chunk_start, nt, cap, blk);
+    if (!u.valid || u.passes > max_passes || pass >= u.passes) continue;  // block-uniform
     const uint32_t R = SORT_CHUNK << pass;
     const uint32_t o_tile = u.k * SORT_CHUNK, len = min(SORT_CHUNK, u.n - o_tile);
     const uint32_t pair0 = o_tile / (2 * R) * (2 * R);
@@ -752,6 +774,8 @@ __global__ __launch_bounds__(512) void k_merge_pass(const uint32_t* __restrict__
                 if (last_pass) lst[out0 + q] = (uint32_t)kq;
             }
         }
+    }
+    __syncthreads();  // LDS and s_part are reused by the next unit of this block
     }
 #undef S360_PHYS
 }
@@ -1116,6 +1140,7 @@ extern "C" int s360_layout(const S360Params* prm, S360Layout* out) {
     out->n_contrib = take(npix * 4);
     out->tile_max_contrib = take(nt * 4);
     out->strip_last = take(nt * 4 * 4);
+    out->slot_pair = take(cap * 4);
     out->rgbc = take((size_t)(prm->P > 0 ? prm->P : 1) * 16);
     out->sh_jac = take((size_t)(prm->P > 0 ? prm->P : 1) * 36);
     out->total_bytes = o;
@@ -1243,14 +1268,15 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
     S360_CHECK_LAUNCH();
     if (kp.P > 0) {
         const dim3 egrid((kp.P + S360_BLOCK * EMIT_PPT - 1) / (S360_BLOCK * EMIT_PPT), kp.V);
+        uint32_t* slot_pair = (kp.flags & S360_FLAG_FORWARD_ONLY) ? nullptr : (uint32_t*)(ws + L.slot_pair);
         {
         ProfScope ps(PS_EMIT, st);
         if ((size_t)kp.T * 8 <= 64 * 1024)
             hipLaunchKernelGGL(k_emit<true>, egrid, dim3(S360_BLOCK), (size_t)kp.T * 8, st, kp, tiles_touched, recA, recC,
-                               depths, tile_start, tile_cursor, keys);
+                               depths, tile_start, tile_cursor, keys, offsets, slot_pair);
         else
             hipLaunchKernelGGL(k_emit<false>, egrid, dim3(S360_BLOCK), 0, st, kp, tiles_touched, recA, recC, depths, tile_start,
-                               tile_cursor, keys);
+                               tile_cursor, keys, offsets, slot_pair);
         }
         S360_CHECK_LAUNCH();
         ProfScope ps(PS_SORT, st);
@@ -1268,7 +1294,9 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
             while (passes < MAX_PASSES && ((size_t)SORT_CHUNK << passes) < cap_keys) ++passes;
             const uint32_t global_lo = SORT_CHUNK << passes;  // lists longer than this go to the global-memory network
             // >= number of chunks: every chunk but the last of a tile is full, and a tile with chunks has > SORT_SHORT keys
-            const unsigned cgrid = (unsigned)((size_t)kp.cap / SORT_CHUNK + (size_t)kp.cap / SORT_SHORT + 2);
+            // >= number of chunks would be cap/4096 + cap/2048 + 2; the kernels walk the chunk table grid-stride instead,
+            // so a moderate grid serves any count (1 536 blocks: 6 per CU, more than fit at 36 KB of LDS each)
+            const unsigned cgrid = (unsigned)min((size_t)1536, (size_t)kp.cap / SORT_CHUNK + (size_t)kp.cap / SORT_SHORT + 2);
             const size_t lds512 = (4096 + 512) * 8;
             if (ss) (void)hipEventRecord(ss->fork, st);
             // main-stream work is queued first so that it starts while the host is still setting up the side stream
@@ -1283,7 +1311,7 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
             }
             for (uint32_t p = 0; p < passes; ++p)
                 hipLaunchKernelGGL(k_merge_pass, dim3(cgrid), dim3(512), lds512, st, tile_start, chunk_start, nt, keys, keys_alt, list,
-                                   kp.cap, p, passes);
+                                   kp.cap, p, passes, header);
             if (ss)
                 (void)hipStreamWaitEvent(st, ss->join, 0);
             else {
