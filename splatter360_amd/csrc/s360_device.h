@@ -334,16 +334,21 @@ __device__ __forceinline__ float power2(float a, float b, float c, float dx, flo
 // The test is conservative (continuous box instead of the pixel lattice, +0.02 in log2 units against float rounding of
 // ~1e-5): a culled entry fails alpha >= 1/255 on every pixel of the quadrant, so skipping it changes nothing.
 // Round 1 tested the ellipse's axis-aligned bounding box instead: 18 % of its survivors contributed to no pixel.
-__device__ __forceinline__ bool quadrant_hit(float x, float y, float a, float b, float c, float op, float ka, float kb,
-                                             float x0, float y0) {
-    const float dh = x - x0, dl = dh - (float)(SUB_W - 1);   // range of dx = x - px over the quadrant's columns
-    const float eh = y - y0, el = eh - (float)(SUB_H - 1);   // range of dy = y - py over its rows
+template <int BW, int BH>
+__device__ __forceinline__ bool box_hit(float x, float y, float a, float b, float c, float op, float ka, float kb,
+                                        float x0, float y0) {
+    const float dh = x - x0, dl = dh - (float)(BW - 1);   // range of dx = x - px over the box's columns
+    const float eh = y - y0, el = eh - (float)(BH - 1);   // range of dy = y - py over its rows
     const float dx1 = __builtin_amdgcn_fmed3f(0.0f, dl, dh);  // column closest to the centre
     const float dy1 = __builtin_amdgcn_fmed3f(0.0f, el, eh);
     const float dys = __builtin_amdgcn_fmed3f(kb * dx1, el, eh);  // best row on that column
     const float dxs = __builtin_amdgcn_fmed3f(ka * dy1, dl, dh);  // best column on that row
     const float pmax = fmaxf(power2(a, b, c, dx1, dys), power2(a, b, c, dxs, dy1));
     return pmax + __builtin_amdgcn_logf(op) + (7.994353436858858f + 0.02f) >= 0.0f;  // log2(255) = 7.9943...
+}
+__device__ __forceinline__ bool quadrant_hit(float x, float y, float a, float b, float c, float op, float ka, float kb,
+                                             float x0, float y0) {
+    return box_hit<SUB_W, SUB_H>(x, y, a, b, c, op, ka, kb, x0, y0);
 }
 
 // Per-Gaussian "colour" of the fused depth map for the reference's DepthRenderingMode

@@ -58,33 +58,41 @@ __global__ __launch_bounds__(S360_BLOCK) void k_sh_eval(KParams kp, const S360Vi
     float Y[25], bx[25], by[25], bz[25];
     sh_basis(kp.deg, x, y, z, Y);
     if (JAC) sh_basis_grad(kp.deg, x, y, z, bx, by, bz);
+    // coefficient-major loop: the three colour sums (sequential, unfused: the oracle's rounding) and the nine jacobian sums
+    // (fused multiply-adds) are twelve independent dependency chains — at 2 waves per SIMD the issue stalls of a
+    // channel-major loop (four 25-deep chains at a time) were 56 % of this kernel's wave cycles
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-        float a = 0.f, g0_ = 0.f, g1 = 0.f, g2 = 0.f;
-        if (fast) {
+        acc[ch] = 0.f;
+        G[ch][0] = G[ch][1] = G[ch][2] = 0.f;
+    }
+    if (fast) {
 #pragma unroll
-            for (int k = 0; k < 25; ++k) {
+        for (int k = 0; k < 25; ++k) {
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
                 const float ck = c[CH_MAJOR ? 25 * ch + k : 3 * k + ch];
-                a += Y[k] * ck;  // sequential (unfused) accumulation: same rounding as the CPU oracle
+                acc[ch] += Y[k] * ck;
                 if (JAC) {
-                    g0_ += bx[k] * ck;
-                    g1 += by[k] * ck;
-                    g2 += bz[k] * ck;
-                }
-            }
-        } else {
-            for (int k = 0; k < n; ++k) {
-                const float ck = sh[k * sk + ch * sc_];
-                a += Y[k] * ck;
-                if (JAC) {
-                    g0_ += bx[k] * ck;
-                    g1 += by[k] * ck;
-                    g2 += bz[k] * ck;
+                    G[ch][0] = __builtin_fmaf(bx[k], ck, G[ch][0]);
+                    G[ch][1] = __builtin_fmaf(by[k], ck, G[ch][1]);
+                    G[ch][2] = __builtin_fmaf(bz[k], ck, G[ch][2]);
                 }
             }
         }
-        acc[ch] = a;
-        G[ch][0] = g0_; G[ch][1] = g1; G[ch][2] = g2;
+    } else {
+        for (int k = 0; k < n; ++k) {
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const float ck = sh[k * sk + ch * sc_];
+                acc[ch] += Y[k] * ck;
+                if (JAC) {
+                    G[ch][0] = __builtin_fmaf(bx[k], ck, G[ch][0]);
+                    G[ch][1] = __builtin_fmaf(by[k], ck, G[ch][1]);
+                    G[ch][2] = __builtin_fmaf(bz[k], ck, G[ch][2]);
+                }
+            }
+        }
     }
     const float a0 = acc[0] + 0.5f, a1 = acc[1] + 0.5f, a2 = acc[2] + 0.5f;
     const uint32_t clampbits = (a0 < 0.f ? 1u : 0u) | (a1 < 0.f ? 2u : 0u) | (a2 < 0.f ? 4u : 0u);
