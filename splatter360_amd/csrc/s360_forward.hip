@@ -874,6 +874,7 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
 #ifdef S360_DBG_TIMING
     const long long t_begin = wall_clock64();
 #endif
+    __shared__ float4 s_rec[S360_BLOCK / 64][64][3];  // per wave: the current chunk's records, for uniform-address broadcast reads
     // tiles are dealt longest list first (LPT: the sequential per-pixel chains of the long polar lists would
     // otherwise form the tail of the kernel): 249 -> 224 us.  (Single-wave workgroups per (tile, quadrant), as in
     // the backward, bring nothing more here: 229 us.)
@@ -937,6 +938,9 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
         const uint32_t rel = b - start;  // list position of this chunk's lane 0
         const unsigned long long act = __ballot(!done);
         if (__popcll(act) > SPARSE_PIXELS) {
+            s_rec[wave][lane][0] = ea;
+            s_rec[wave][lane][1] = eb;
+            s_rec[wave][lane][2] = make_float4(ec, ez, 0.f, 0.f);
             // two list entries per iteration: their alpha evaluations are independent instruction
             // chains (ILP for the in-order wave); the T / colour updates stay strictly sequential
             while (m) {
@@ -945,12 +949,17 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
                 const bool two = m != 0ull;
                 const int b1 = two ? __builtin_ctzll(m) : b0;
                 m &= m - 1;  // no-op when m == 0
-                const float dx0 = rl(ea.x, b0) - pxf, dy0 = rl(ea.y, b0) - pyf;
-                const float dx1 = rl(ea.x, b1) - pxf, dy1 = rl(ea.y, b1) - pyf;
-                const float pw0 = power2(rl(ea.z, b0), rl(ea.w, b0), rl(eb.x, b0), dx0, dy0);
-                const float pw1 = power2(rl(ea.z, b1), rl(ea.w, b1), rl(eb.x, b1), dx1, dy1);
-                const float al0 = fminf(0.99f, rl(eb.y, b0) * __builtin_amdgcn_exp2f(pw0));
-                const float al1 = fminf(0.99f, rl(eb.y, b1) * __builtin_amdgcn_exp2f(pw1));
+                // the two entries' records, broadcast through the wave's LDS slice: 3 ds_read_b128 with a wave-uniform
+                // address per entry instead of 9 v_readlane_b32 (VALU) — the composite is VALU-issue-bound
+                const float4* r0 = &s_rec[wave][b0][0];
+                const float4* r1 = &s_rec[wave][b1][0];
+                const float4 A0 = r0[0], B0 = r0[1], K0 = r0[2], A1 = r1[0], B1 = r1[1], K1 = r1[2];
+                const float dx0 = A0.x - pxf, dy0 = A0.y - pyf;
+                const float dx1 = A1.x - pxf, dy1 = A1.y - pyf;
+                const float pw0 = power2(A0.z, A0.w, B0.x, dx0, dy0);
+                const float pw1 = power2(A1.z, A1.w, B1.x, dx1, dy1);
+                const float al0 = fminf(0.99f, B0.y * __builtin_amdgcn_exp2f(pw0));
+                const float al1 = fminf(0.99f, B1.y * __builtin_amdgcn_exp2f(pw1));
                 const bool v0 = !done && !(pw0 > 0.0f) && !(al0 < 1.0f / 255.0f);
                 const bool v1 = two && !done && !(pw1 > 0.0f) && !(al1 < 1.0f / 255.0f);
 #ifdef S360_DBG_COUNT
@@ -970,10 +979,10 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
                     const bool contrib = v0 && !stop;
                     done = done || stop;
                     const float w = contrib ? al0 * T : 0.0f;
-                    C0 += rl(eb.z, b0) * w;
-                    C1 += rl(eb.w, b0) * w;
-                    C2 += rl(ec, b0) * w;
-                    if (WITH_DEPTH) D += rl(ez, b0) * w;
+                    C0 += B0.z * w;
+                    C1 += B0.w * w;
+                    C2 += K0.x * w;
+                    if (WITH_DEPTH) D += K0.y * w;
                     T = contrib ? test_T : T;
                     last = contrib ? rel + (uint32_t)b0 + 1u : last;
                 }
@@ -984,10 +993,10 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
                     const bool contrib = v1b && !stop;
                     done = done || stop;
                     const float w = contrib ? al1 * T : 0.0f;
-                    C0 += rl(eb.z, b1) * w;
-                    C1 += rl(eb.w, b1) * w;
-                    C2 += rl(ec, b1) * w;
-                    if (WITH_DEPTH) D += rl(ez, b1) * w;
+                    C0 += B1.z * w;
+                    C1 += B1.w * w;
+                    C2 += K1.x * w;
+                    if (WITH_DEPTH) D += K1.y * w;
                     T = contrib ? test_T : T;
                     last = contrib ? rel + (uint32_t)b1 + 1u : last;
                 }
