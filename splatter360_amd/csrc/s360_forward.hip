@@ -874,7 +874,7 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
 #ifdef S360_DBG_TIMING
     const long long t_begin = wall_clock64();
 #endif
-    __shared__ float4 s_rec[S360_BLOCK / 64][64][3];  // per wave: the current chunk's records, for uniform-address broadcast reads
+    __shared__ float4 s_rec[S360_BLOCK / 64][68][3];  // per wave: the current chunk's culled records (+ padding), read as uniform-address broadcasts
     // tiles are dealt longest list first (LPT: the sequential per-pixel chains of the long polar lists would
     // otherwise form the tail of the kernel): 249 -> 224 us.  (Single-wave workgroups per (tile, quadrant), as in
     // the backward, bring nothing more here: 229 us.)
@@ -938,67 +938,63 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
         const uint32_t rel = b - start;  // list position of this chunk's lane 0
         const unsigned long long act = __ballot(!done);
         if (__popcll(act) > SPARSE_PIXELS) {
-            s_rec[wave][lane][0] = ea;
-            s_rec[wave][lane][1] = eb;
-            s_rec[wave][lane][2] = make_float4(ec, ez, 0.f, 0.f);
-            // two list entries per iteration: their alpha evaluations are independent instruction
-            // chains (ILP for the in-order wave); the T / colour updates stay strictly sequential
-            while (m) {
-                const int b0 = __builtin_ctzll(m);
-                m &= m - 1;
-                const bool two = m != 0ull;
-                const int b1 = two ? __builtin_ctzll(m) : b0;
-                m &= m - 1;  // no-op when m == 0
-                // the two entries' records, broadcast through the wave's LDS slice: 3 ds_read_b128 with a wave-uniform
-                // address per entry instead of 9 v_readlane_b32 (VALU) — the composite is VALU-issue-bound
-                const float4* r0 = &s_rec[wave][b0][0];
-                const float4* r1 = &s_rec[wave][b1][0];
-                const float4 A0 = r0[0], B0 = r0[1], K0 = r0[2], A1 = r1[0], B1 = r1[1], K1 = r1[2];
-                const float dx0 = A0.x - pxf, dy0 = A0.y - pyf;
-                const float dx1 = A1.x - pxf, dy1 = A1.y - pyf;
-                const float pw0 = power2(A0.z, A0.w, B0.x, dx0, dy0);
-                const float pw1 = power2(A1.z, A1.w, B1.x, dx1, dy1);
-                const float al0 = fminf(0.99f, B0.y * __builtin_amdgcn_exp2f(pw0));
-                const float al1 = fminf(0.99f, B1.y * __builtin_amdgcn_exp2f(pw1));
-                const bool v0 = !done && !(pw0 > 0.0f) && !(al0 < 1.0f / 255.0f);
-                const bool v1 = two && !done && !(pw1 > 0.0f) && !(al1 < 1.0f / 255.0f);
+            // Survivors are COMPACTED into the wave's LDS slice (rank = prefix count of the cull ballot) and padded with
+            // null records (opacity 0 => alpha 0 => rejected like any other miss) to a multiple of four, so the loop below is
+            // a plain counted loop over consecutive 48-byte records: no bit scanning on the scalar unit, uniform-address
+            // ds_read_b128 broadcasts instead of 9 v_readlane per entry, and the alpha evaluations of FOUR entries per
+            // iteration are independent instruction chains; the T / colour updates stay strictly sequential.
+            const uint32_t cnt = (uint32_t)__popcll(m);
+            {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (hit) {
+                    s_rec[wave][rank][0] = ea;
+                    s_rec[wave][rank][1] = eb;
+                    s_rec[wave][rank][2] = make_float4(ec, ez, __uint_as_float(rel + (uint32_t)lane + 1u), 0.f);
+                }
+                if (lane < 3) {
+                    s_rec[wave][cnt + lane][0] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    s_rec[wave][cnt + lane][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    s_rec[wave][cnt + lane][2] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+            for (uint32_t i = 0; i < cnt; i += 4) {
+                const float4* r = &s_rec[wave][i][0];
+                float4 A[4], B[4], K[4];
+                float al[4];
+                bool ok[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    A[e] = r[3 * e];
+                    B[e] = r[3 * e + 1];
+                    K[e] = r[3 * e + 2];
+                }
+                bool any_ok = false;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float dx = A[e].x - pxf, dy = A[e].y - pyf;
+                    const float pw = power2(A[e].z, A[e].w, B[e].x, dx, dy);
+                    al[e] = fminf(0.99f, B[e].y * __builtin_amdgcn_exp2f(pw));
+                    ok[e] = !done && !(pw > 0.0f) && !(al[e] < 1.0f / 255.0f);
+                    any_ok = any_ok || ok[e];
+                }
 #ifdef S360_DBG_COUNT
-                {
-                    const unsigned long long q0 = __ballot(v0), q1 = __ballot(v1);
-                    if (lane == 0) {
-                        atomicAdd(&dbg[0], two ? 2u : 1u);                          // entries past the cull
-                        atomicAdd(&dbg[1], (q0 ? 1u : 0u) + (q1 ? 1u : 0u));        // entries with >= 1 valid lane
-                        atomicAdd(&dbg[2], (uint32_t)(__popcll(q0) + __popcll(q1)));  // valid lanes
-                    }
-                }
+                if (lane == 0) atomicAdd(&dbg[0], min(4u, cnt - i));
 #endif
-                if (__ballot(v0 || v1) == 0ull) continue;  // wave-uniform
-                {
-                    const float test_T = T * (1.0f - al0);
-                    const bool stop = v0 && test_T < 0.0001f;
-                    const bool contrib = v0 && !stop;
+                if (__ballot(any_ok) == 0ull) continue;  // wave-uniform
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool v = ok[e] && !done;
+                    const float test_T = T * (1.0f - al[e]);
+                    const bool stop = v && test_T < 0.0001f;
+                    const bool contrib = v && !stop;
                     done = done || stop;
-                    const float w = contrib ? al0 * T : 0.0f;
-                    C0 += B0.z * w;
-                    C1 += B0.w * w;
-                    C2 += K0.x * w;
-                    if (WITH_DEPTH) D += K0.y * w;
+                    const float w = contrib ? al[e] * T : 0.0f;
+                    C0 += B[e].z * w;
+                    C1 += B[e].w * w;
+                    C2 += K[e].x * w;
+                    if (WITH_DEPTH) D += K[e].y * w;
                     T = contrib ? test_T : T;
-                    last = contrib ? rel + (uint32_t)b0 + 1u : last;
-                }
-                {
-                    const bool v1b = v1 && !done;
-                    const float test_T = T * (1.0f - al1);
-                    const bool stop = v1b && test_T < 0.0001f;
-                    const bool contrib = v1b && !stop;
-                    done = done || stop;
-                    const float w = contrib ? al1 * T : 0.0f;
-                    C0 += B1.z * w;
-                    C1 += B1.w * w;
-                    C2 += K1.x * w;
-                    if (WITH_DEPTH) D += K1.y * w;
-                    T = contrib ? test_T : T;
-                    last = contrib ? rel + (uint32_t)b1 + 1u : last;
+                    last = contrib ? __float_as_uint(K[e].z) : last;
                 }
             }
         } else {
