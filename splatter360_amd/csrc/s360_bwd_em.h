@@ -155,6 +155,17 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
         const uint32_t pos_min = (uint32_t)__builtin_amdgcn_readlane((int)pos, (int)n - 1);
         float g_op = 0.f, X = 0.f, Y = 0.f, XX = 0.f, XY = 0.f, YY = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f, g_z = 0.f;
         bool anyc = false;
+        // which of the 16 four-pixel runs can still receive anything from this group (some pixel's last contributor lies at
+        // or in front of the group's frontmost entry): one LDS pass up front, so that the loop below branches on a scalar bit
+        // instead of waiting for the pixel table before it can decide
+        uint32_t qmask;
+        {
+            const int ql = lane & 15;
+            const int qp = (ql >> 1) * 8 + (ql & 1) * 4;
+            const uint32_t lm = max(max(__float_as_uint(s_pb[qp].w), __float_as_uint(s_pb[qp + 1].w)),
+                                    max(__float_as_uint(s_pb[qp + 2].w), __float_as_uint(s_pb[qp + 3].w)));
+            qmask = (uint32_t)__ballot(lm > pos_min) & 0xFFFFu;
+        }
 #pragma unroll 1
         for (int row = 0; row < 8; ++row) {
             const float pyf = (float)(qy + row);
@@ -165,16 +176,13 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int p0 = row * 8 + half * 4;
+                if (!((qmask >> (row * 2 + half)) & 1u)) continue;  // none of the four pixels reaches back to this group
                 float4 pa[4], pb[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     pa[k] = s_pa[p0 + k];
                     pb[k] = s_pb[p0 + k];
                 }
-                const uint32_t lmax = max(max(__float_as_uint(pb[0].w), __float_as_uint(pb[1].w)),
-                                          max(__float_as_uint(pb[2].w), __float_as_uint(pb[3].w)));
-                // none of the four pixels reaches as far back as this group's frontmost entry (wave-uniform)
-                if ((uint32_t)__builtin_amdgcn_readfirstlane((int)lmax) <= pos_min) continue;
                 float dx[4], a[4], Gm[4], om[4], Qx[4], px_[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
