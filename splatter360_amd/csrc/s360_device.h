@@ -417,6 +417,36 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 // the sequential per-quadrant chains, which cannot be split).
 // The same launch also clears the backward's validity words (valid[instance*4 + quadrant] = 1 when that
 // quadrant's wave wrote a partial record): block 0 orders, blocks 1.. zero (one 32-bit word = 4 flags per instance).
+template <int THREADS>
+__device__ __forceinline__ void order_units_body(const uint32_t* __restrict__ weight, uint32_t* __restrict__ order, int n) {
+    __shared__ uint32_t s_max;
+    __shared__ uint32_t s_cnt[64];
+    __shared__ uint32_t s_base[64];
+    if (threadIdx.x == 0) s_max = 1;
+    if (threadIdx.x < 64) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t mx = 0;
+    for (int i = threadIdx.x; i < n; i += THREADS) mx = max(mx, weight[i]);
+    mx = wave_max_u32(mx);
+    if ((threadIdx.x & 63) == 0) atomicMax(&s_max, mx);
+    __syncthreads();
+    const uint32_t wmax = s_max;
+    for (int i = threadIdx.x; i < n; i += THREADS) atomicAdd(&s_cnt[63 - (uint32_t)(((uint64_t)weight[i] * 63) / wmax)], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int b = 0; b < 64; ++b) {
+            s_base[b] = run;
+            run += s_cnt[b];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += THREADS) {
+        const uint32_t b = 63 - (uint32_t)(((uint64_t)weight[i] * 63) / wmax);
+        order[atomicAdd(&s_base[b], 1u)] = (uint32_t)i;
+    }
+}
+
 static __global__ __launch_bounds__(1024) void k_order_units(const uint32_t* __restrict__ weight, uint32_t* __restrict__ order, int n,
                                                      uint32_t* __restrict__ valid_words, const uint32_t* __restrict__ header,
                                                      uint32_t cap) {
@@ -427,32 +457,7 @@ static __global__ __launch_bounds__(1024) void k_order_units(const uint32_t* __r
         return;
     }
     if (!order) return;
-    __shared__ uint32_t s_max;
-    __shared__ uint32_t s_cnt[64];
-    __shared__ uint32_t s_base[64];
-    if (threadIdx.x == 0) s_max = 1;
-    if (threadIdx.x < 64) s_cnt[threadIdx.x] = 0;
-    __syncthreads();
-    uint32_t mx = 0;
-    for (int i = threadIdx.x; i < n; i += 1024) mx = max(mx, weight[i]);
-    mx = wave_max_u32(mx);
-    if ((threadIdx.x & 63) == 0) atomicMax(&s_max, mx);
-    __syncthreads();
-    const uint32_t wmax = s_max;
-    for (int i = threadIdx.x; i < n; i += 1024) atomicAdd(&s_cnt[63 - (uint32_t)(((uint64_t)weight[i] * 63) / wmax)], 1u);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t run = 0;
-        for (int b = 0; b < 64; ++b) {
-            s_base[b] = run;
-            run += s_cnt[b];
-        }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < n; i += 1024) {
-        const uint32_t b = 63 - (uint32_t)(((uint64_t)weight[i] * 63) / wmax);
-        order[atomicAdd(&s_base[b], 1u)] = (uint32_t)i;
-    }
+    order_units_body<1024>(weight, order, n);
 }
 
 

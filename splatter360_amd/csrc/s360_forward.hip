@@ -1,14 +1,14 @@
 // s360_forward.hip — forward kernels: fused multi-view preprocess, scans, tile binning,
 // per-tile depth sort, front-to-back composite.  gfx950 / wave64 only.
 //
-// Pipeline (all asynchronous on the caller's stream + one internal side stream, no host sync):
+// Pipeline (all asynchronous on the caller's stream, no host sync, no library-global state):
 //   k_preprocess     1 thread / Gaussian, loops the V views in registers: cull, EWA cov2D, conic,
 //                    radius, tile rect; SH->RGB once per Gaussian when the views share campos
 //                    (each lane streams its own 300-byte slab with 16-byte loads).
 //   k_scan_lookback  single-pass inclusive scan of tiles_touched over the V*P (view, Gaussian) pairs
 //   k_tile_scan      exclusive scan of the per-tile instance counts -> tile ranges (+ sort-chunk table)
 //   k_emit           scatter (depth bits << 32 | pair) keys into their tile's bucket
-//   k_sort_tiles_merge / k_sort_chunks / k_merge_pass / k_sort_tiles_global
+//   k_sort_stage1 / k_merge_pass / k_sort_tiles_global
 //                    per-tile ascending sort of the unique 64-bit keys (== stable radix sort by
 //                    (tile, depth) with ascending-index emission): LDS merge sort per list or per
 //                    4096-key chunk, global merge-path passes for multi-chunk lists
@@ -18,7 +18,6 @@
 
 #include <cstdio>
 #include <cstdlib>
-#include <mutex>
 
 namespace s360 {
 
@@ -307,6 +306,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess(
 
 // ------------------------------------------------------------------------------ scans
 
+template <int NW = S360_BLOCK / 64>
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* lds, uint32_t& total) {
     // wave-level inclusive scan by shuffles, then 4 wave totals through LDS
     const int lane = lane_id(), wave = threadIdx.x >> 6;
@@ -320,7 +320,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* l
     __syncthreads();
     uint32_t base = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < S360_BLOCK / 64; ++w) {
+    for (int w = 0; w < NW; ++w) {
         const uint32_t s = lds[w];
         if (w < wave) base += s;
         tot += s;
@@ -423,33 +423,34 @@ __global__ __launch_bounds__(S360_BLOCK) void k_scan_lookback(const uint32_t* __
 }
 
 // single block: tile_start[0..nt] = exclusive scan of tile_count; header bookkeeping.
-// Lists longer than SORT_SHORT keys are sorted as chunks of SORT_CHUNK keys (k_sort_chunks: one 512-thread
+// Lists longer than SORT_SHORT keys are sorted as chunks of SORT_CHUNK keys (k_sort_stage1: one 512-thread
 // workgroup per chunk) followed, when there is more than one chunk, by global merge passes (k_merge_pass);
 // chunk_start[t] = number of such chunks before tile t (0 chunks for the short tiles, which have their own class).
 constexpr uint32_t SORT_SHORT = 2048;
 constexpr uint32_t SORT_CHUNK = 4096;
 constexpr uint32_t MAX_PASSES = 4;
 
-__global__ __launch_bounds__(S360_BLOCK) void k_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_start,
+constexpr int TS_BLOCK = 1024;  // one workgroup; 16 waves: 1 536 tiles in two sweeps (a 256-thread block needed six: 10 us of barriers)
+__global__ __launch_bounds__(TS_BLOCK) void k_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_start,
                                                          uint32_t* __restrict__ tile_cursor, uint32_t* __restrict__ tile_max_contrib,
                                                          int nt, uint32_t cap, uint32_t* __restrict__ header,
                                                          uint32_t* __restrict__ chunk_start) {
-    __shared__ uint32_t lds[8];
+    __shared__ uint32_t lds[TS_BLOCK / 64];
     __shared__ uint32_t lds_max;
     if (threadIdx.x == 0) lds_max = 0;
     __syncthreads();
     uint32_t carry = 0, mx = 0, ccarry = 0;
-    for (int b = 0; b < nt; b += S360_BLOCK) {
+    for (int b = 0; b < nt; b += TS_BLOCK) {
         const int i = b + threadIdx.x;
         const uint32_t v = i < nt ? tile_count[i] : 0u;
         mx = max(mx, v);
         uint32_t tot;
-        const uint32_t ex = block_exclusive_scan(v, lds, tot);
+        const uint32_t ex = block_exclusive_scan<TS_BLOCK / 64>(v, lds, tot);
         // the sort kernels see list lengths clamped to the binning capacity
         const uint32_t nclamp = min(carry + ex + v, cap) - min(carry + ex, cap);
         const uint32_t nch = nclamp > SORT_SHORT ? (nclamp + SORT_CHUNK - 1) / SORT_CHUNK : 0u;
         uint32_t ctot;
-        const uint32_t cex = block_exclusive_scan(nch, lds, ctot);
+        const uint32_t cex = block_exclusive_scan<TS_BLOCK / 64>(nch, lds, ctot);
         if (i < nt) {
             tile_start[i] = carry + ex;
             tile_cursor[i] = 0;
@@ -636,17 +637,6 @@ __device__ __forceinline__ void block_merge_sort(const uint64_t* __restrict__ in
 #undef S360_PHYS
 }
 
-// One workgroup per tile whose list length n satisfies lo < n <= THREADS*E.
-template <int THREADS, int E>
-__global__ __launch_bounds__(THREADS) void k_sort_tiles_merge(const uint32_t* __restrict__ tile_start, uint64_t* __restrict__ keys,
-                                                             uint32_t* __restrict__ list, uint32_t lo, uint32_t cap) {
-    extern __shared__ __attribute__((aligned(16))) uint64_t lds_m[];
-    const uint32_t s = min(tile_start[blockIdx.x], cap), e = min(tile_start[blockIdx.x + 1], cap);
-    const uint32_t n = e - s;
-    if (n <= lo || n > (uint32_t)(THREADS * E)) return;
-    block_merge_sort<THREADS, E>(keys + s, keys + s, list + s, n, lds_m);
-}
-
 // ---- long lists (n > SORT_CHUNK): chunk sort + global merge passes ------------------------------------------
 // Work unit = one SORT_CHUNK-sized output chunk (t, k) of a long tile, found from the block index by a binary
 // search over chunk_start[].  A tile with c chunks needs P = ceil(log2 c) merge passes; it ping-pongs between
@@ -684,20 +674,38 @@ __device__ __forceinline__ ChunkUnit chunk_unit(const uint32_t* __restrict__ til
     return u;
 }
 
-__global__ __launch_bounds__(512) void k_sort_chunks(const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ chunk_start,
+// ONE launch for the first sorting stage: chunk blocks first in the grid (their results feed the merge passes, the critical
+// path), then one block per tile for the short lists, and a last block that deals the composite's tile order — round 1
+// ran the short-list sort and the ordering on a process-wide side stream (fork / join events, a host mutex): ~25 us of
+// cross-stream latency inside a 100-us stage, and library-global state.
+__global__ __launch_bounds__(512) void k_sort_stage1(const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ chunk_start,
                                                     int nt, uint64_t* __restrict__ keys, uint64_t* __restrict__ alt,
-                                                    uint32_t* __restrict__ list, uint32_t cap, uint32_t max_passes) {
+                                                    uint32_t* __restrict__ list, uint32_t cap, uint32_t max_passes, uint32_t cgrid,
+                                                    const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_order) {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds_m[];
-    const uint32_t nchunks = chunk_start[nt];
-    for (uint32_t b = blockIdx.x; b < nchunks; b += gridDim.x) {  // the grid is sized on the host without knowing nchunks
-        const ChunkUnit u = chunk_unit(tile_start, chunk_start, nt, cap, b);
-        if (u.valid && u.passes <= max_passes) {
-            const uint32_t c0 = u.k * SORT_CHUNK, len = min(SORT_CHUNK, u.n - c0);
-            uint64_t* dst = ((u.passes & 1u) ? alt : keys) + u.s + c0;
-            block_merge_sort<512, 8>(keys + u.s + c0, dst, u.passes == 0 ? list + u.s : nullptr, len, lds_m);  // single chunk: done
+    const uint32_t bid = blockIdx.x;
+    if (bid < cgrid) {  // 4 096-key chunks of the long lists, grid-stride over the chunk table
+        const uint32_t nchunks = chunk_start[nt];
+        for (uint32_t b = bid; b < nchunks; b += cgrid) {
+            const ChunkUnit u = chunk_unit(tile_start, chunk_start, nt, cap, b);
+            if (u.valid && u.passes <= max_passes) {
+                const uint32_t c0 = u.k * SORT_CHUNK, len = min(SORT_CHUNK, u.n - c0);
+                uint64_t* dst = ((u.passes & 1u) ? alt : keys) + u.s + c0;
+                block_merge_sort<512, 8>(keys + u.s + c0, dst, u.passes == 0 ? list + u.s : nullptr, len, lds_m);
+            }
+            __syncthreads();
         }
-        __syncthreads();
+        return;
     }
+    if (bid < cgrid + (uint32_t)nt) {  // lists of up to 2 048 keys: one workgroup each
+        const uint32_t tile = bid - cgrid;
+        const uint32_t s = min(tile_start[tile], cap), e = min(tile_start[tile + 1], cap);
+        const uint32_t n = e - s;
+        if (n == 0 || n > SORT_SHORT) return;
+        block_merge_sort<512, 4>(keys + s, keys + s, list + s, n, lds_m);
+        return;
+    }
+    if (tile_order) order_units_body<512>(tile_count, tile_order, nt);  // longest list first (dispatch order of k_render)
 }
 
 // Merge path over two sorted runs in global memory: number of A elements among the first d outputs.  Executed by
@@ -1092,32 +1100,6 @@ static size_t occupancy_cap_lds(const char* env, size_t dflt) {
     return e ? (size_t)atol(e) : dflt;
 }
 
-// One non-blocking side stream (+ fork/join events) per device, created on first use.  The only process-wide
-// state of the library besides the optional profiler: callers on different host threads / streams of one device
-// share it, so the fork ... join enqueue sequence is serialised on the host by `mu` (enqueue only — nothing waits
-// on the GPU while the lock is held).
-struct SideStream {
-    hipStream_t stream;
-    hipEvent_t fork, join;
-    std::mutex mu;
-};
-static SideStream* side_stream() {
-    static SideStream ss[64];
-    static int state[64] = {};  // 0 = not created, 1 = ready, -1 = unavailable
-    static std::mutex create_mu;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || getenv("S360_NO_SIDE_STREAM")) return nullptr;
-    std::lock_guard<std::mutex> lk(create_mu);
-    if (state[dev] == 0) {
-        const bool ok = hipStreamCreateWithFlags(&ss[dev].stream, hipStreamNonBlocking) == hipSuccess &&
-                        hipEventCreateWithFlags(&ss[dev].fork, hipEventDisableTiming) == hipSuccess &&
-                        hipEventCreateWithFlags(&ss[dev].join, hipEventDisableTiming) == hipSuccess;
-        state[dev] = ok ? 1 : -1;
-        (void)hipGetLastError();
-    }
-    return state[dev] == 1 ? &ss[dev] : nullptr;
-}
-
 extern "C" int s360_layout(const S360Params* prm, S360Layout* out) {
     if (!prm || !out) return S360_E_BADARG;
     if (prm->P < 0 || prm->V < 1 || prm->V > S360_MAX_VIEWS || prm->H < 1 || prm->W < 1) return S360_E_BADARG;
@@ -1275,7 +1257,7 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
     }
     {
         ProfScope ps(PS_TILE_SCAN, st);
-        hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(S360_BLOCK), 0, st, tile_count, tile_start, tile_cursor, tile_max_contrib, nt, kp.cap, header,
+        hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(TS_BLOCK), 0, st, tile_count, tile_start, tile_cursor, tile_max_contrib, nt, kp.cap, header,
                            chunk_start);
     }
     S360_CHECK_LAUNCH();
@@ -1293,45 +1275,23 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
         }
         S360_CHECK_LAUNCH();
         ProfScope ps(PS_SORT, st);
-        SideStream* ss = side_stream();
         {
-            std::unique_lock<std::mutex> side_lock;
-            if (ss) side_lock = std::unique_lock<std::mutex>(ss->mu);
-            // Lists of up to 2 048 keys (the bulk) are sorted by one 256-thread workgroup each, on the side stream;
-            // meanwhile the main stream takes the rest as 4 096-key chunks, one 512-thread workgroup each
-            // (k_sort_chunks), followed for multi-chunk lists by `passes` global merge passes (k_merge_pass).  The
-            // number of pass launches is fixed on the host (no read-back): enough for the longest possible list,
-            // capped at MAX_PASSES (4 096 << 4 = 65 536 keys); anything longer falls through to the global network.
+            // Lists of up to 2 048 keys (the bulk) are sorted by one workgroup each; longer ones as 4 096-key chunks followed,
+            // for multi-chunk lists, by `passes` global merge passes (k_merge_pass).  The number of pass launches is fixed on
+            // the host (no read-back): enough for the longest possible list, capped at MAX_PASSES (4 096 << 4 = 65 536 keys);
+            // passes no list of the call needs return at once (header[3]); anything longer falls through to the global network.
             const size_t cap_keys = kp.cap < (uint32_t)kp.P ? kp.cap : (size_t)kp.P;   // a tile holds a Gaussian at most once
             uint32_t passes = 0;
             while (passes < MAX_PASSES && ((size_t)SORT_CHUNK << passes) < cap_keys) ++passes;
             const uint32_t global_lo = SORT_CHUNK << passes;  // lists longer than this go to the global-memory network
-            // >= number of chunks: every chunk but the last of a tile is full, and a tile with chunks has > SORT_SHORT keys
-            // >= number of chunks would be cap/4096 + cap/2048 + 2; the kernels walk the chunk table grid-stride instead,
-            // so a moderate grid serves any count (1 536 blocks: 6 per CU, more than fit at 36 KB of LDS each)
-            const unsigned cgrid = (unsigned)min((size_t)1536, (size_t)kp.cap / SORT_CHUNK + (size_t)kp.cap / SORT_SHORT + 2);
+            // the chunk blocks walk the chunk table grid-stride, so a moderate grid serves any count
+            const unsigned cgrid = (unsigned)min((size_t)1024, (size_t)kp.cap / SORT_CHUNK + (size_t)kp.cap / SORT_SHORT + 2);
             const size_t lds512 = (4096 + 512) * 8;
-            if (ss) (void)hipEventRecord(ss->fork, st);
-            // main-stream work is queued first so that it starts while the host is still setting up the side stream
-            hipLaunchKernelGGL(k_sort_chunks, dim3(cgrid), dim3(512), lds512, st, tile_start, chunk_start, nt, keys, keys_alt, list, kp.cap, passes);
-            if (ss) {
-                (void)hipStreamWaitEvent(ss->stream, ss->fork, 0);
-                hipLaunchKernelGGL((k_sort_tiles_merge<256, 8>), dim3(nt), dim3(256), (2048 + 256) * 8, ss->stream, tile_start, keys, list, 0u, kp.cap);
-                if (tile_order)  // dispatch order of the composite: only needed after the join, the side stream has slack
-                    hipLaunchKernelGGL(k_order_units, dim3(1), dim3(1024), 0, ss->stream, tile_count, tile_order, nt, (uint32_t*)nullptr,
-                                       header, 0u);
-                (void)hipEventRecord(ss->join, ss->stream);
-            }
+            hipLaunchKernelGGL(k_sort_stage1, dim3(cgrid + nt + 1), dim3(512), lds512, st, tile_start, chunk_start, nt, keys, keys_alt, list,
+                               kp.cap, passes, cgrid, tile_count, tile_order);
             for (uint32_t p = 0; p < passes; ++p)
                 hipLaunchKernelGGL(k_merge_pass, dim3(cgrid), dim3(512), lds512, st, tile_start, chunk_start, nt, keys, keys_alt, list,
                                    kp.cap, p, passes, header);
-            if (ss)
-                (void)hipStreamWaitEvent(st, ss->join, 0);
-            else {
-                if (tile_order)
-                    hipLaunchKernelGGL(k_order_units, dim3(1), dim3(1024), 0, st, tile_count, tile_order, nt, (uint32_t*)nullptr, header, 0u);
-                hipLaunchKernelGGL((k_sort_tiles_merge<256, 8>), dim3(nt), dim3(256), (2048 + 256) * 8, st, tile_start, keys, list, 0u, kp.cap);
-            }
             if ((size_t)global_lo < cap_keys)  // otherwise no list can be that long
                 hipLaunchKernelGGL(k_sort_tiles_global, dim3(nt), dim3(S360_BLOCK), 0, st, tile_start, keys, list, global_lo, kp.cap);
         }
