@@ -92,6 +92,31 @@ def cpu_baseline(cloud, face_w, near, far, mode):
                        f"oracle/s360_oracle.c with OpenMP, {dt:.1f} s incl. boundary-tensor prep")
 
 
+def cpu_baseline_torch():
+    """BASELINE configs[0]: the PyTorch-CPU restatement of the composite (oracle/torch_ref.py) on 10 000 Gaussians, one
+    256x128 ERP view = six 64x64 faces, forward + backward, all host cores.  (The reference has no CPU path; this times
+    the project's own torch restatement, as SURVEY.md 8(d) asks.)"""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import numpy as np
+    from helpers import boundary_tensors, face_settings
+    from oracle import torch_ref
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cloud = synthetic.uniform_cloud(10_000, seed=0, extent=3.0, scale_range=(0.02, 0.3))
+    t0 = time.time()
+    for face in range(6):
+        S = face_settings(face, 64, 64)
+        means, cov6, shs, opac = boundary_tensors(cloud, S["scale"])
+        t = lambda x: torch.tensor(x, dtype=torch.float32, requires_grad=True)
+        m, c, s_, o = t(means), t(cov6), t(shs), t(opac)
+        img = torch_ref.render(S, m, c, o, shs=s_)
+        ((img - 0.5) ** 2).mean().backward()
+    dt = time.time() - t0
+    return dict(value=10_000 / dt / 1e6, unit="Msplats/s", cores=cores, kind="port",
+                sample=f"BASELINE configs[0]: 10000 Gaussians, 256x128 ERP (6 faces 64x64), fwd+bwd, oracle/torch_ref.py "
+                       f"(PyTorch CPU, {cores} threads), {dt:.1f} s")
+
+
 def main():
     a = parse()
     rank, local_rank, world = distributed.init()
@@ -297,6 +322,10 @@ def main():
         res["per_face_dropin_ms_per_step"] = (time.perf_counter() - t0) / 3 * 1e3
     if rank == 0 and world == 1 and a.cpu_baseline and a.mode != "eval":
         res["cpu_baseline"] = cpu_baseline(cloud, face_w, 0.1, 10.0, a.mode)
+        try:
+            res["cpu_baseline_torch"] = cpu_baseline_torch()
+        except Exception as e:  # the torch restatement is an extra, never a reason to lose the bench line
+            res["cpu_baseline_torch"] = {"error": repr(e)}
     elif rank == 0:
         res["cpu_baseline"] = None
     if rank == 0:

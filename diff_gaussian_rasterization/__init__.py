@@ -2,10 +2,6 @@
 GaussianRasterizationSettings, GaussianRasterizer`, /root/reference/src/model/decoder/
 cuda_splatting.py:5-8).  Putting this repository on PYTHONPATH ahead of (or instead of) the CUDA
 pip package routes the reference's decoder to the MI355X-native HIP rasteriser unchanged."""
-from splatter360_amd.rasterizer import (  # noqa: F401
-    GaussianRasterizationSettings,
-    GaussianRasterizer,
-    _RasterizeViews as _RasterizeGaussians,
-)
+from splatter360_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer  # noqa: F401
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer"]
