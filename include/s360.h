@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define S360_ABI_VERSION 12
+#define S360_ABI_VERSION 13
 #define S360_MAX_VIEWS 8
 #define S360_TILE 16
 
@@ -43,7 +43,7 @@ enum {
 
 /* flags */
 #define S360_FLAG_SHARED_CAMPOS 1u    /* all V views share campos (and scale): SH->RGB evaluated once per Gaussian */
-#define S360_FLAG_FORWARD_ONLY 8u     /* inference: skip the per-pair offsets scan (only s360_backward needs it);
+#define S360_FLAG_FORWARD_ONLY 8u     /* inference: skip the instance-slot tables (only s360_backward needs them);
                                          s360_backward returns S360_E_BADARG on a workspace rendered with this flag */
 #define S360_FLAG_COV9 2u             /* covariances given (and their gradient returned) as [P,3,3] row-major, the
                                          reference's Gaussians.covariances layout (src/model/types.py:9); only the
@@ -105,7 +105,9 @@ typedef struct S360Layout {
     size_t total_bytes;         /* forward workspace size */
     size_t header;              /* uint32[64]: [0]=num_instances [1]=overflow flag [2]=max tile list length */
     size_t tiles_touched;       /* uint32[V*P] */
-    size_t offsets;             /* uint32[V*P]  inclusive scan of tiles_touched (upstream point_offsets) */
+    size_t slot_base;           /* uint32[V*P]  training calls: first instance slot of a visible pair (it owns `tiles_touched`
+                                   consecutive slots; upstream's point_offsets scan is replaced by a block-wise reservation,
+                                   so which range a pair gets is run-dependent — the ranges tile [0, num_instances)) */
     /* one 48-byte record per pair, stride 48 B: rec_b / rec_c = rec_a + 16 / + 32 (one cache line per gather) */
     size_t rec_a;               /* float4  x, y, -log2(e)/2 * conic.a, -log2(e) * conic.b */
     size_t rec_b;               /* float4  -log2(e)/2 * conic.c, opacity, r, g */
@@ -113,7 +115,7 @@ typedef struct S360Layout {
     size_t clamped;             /* uint8[V*P]   bit c set: colour channel c was clamped at 0 */
     size_t depths;              /* float[V*P]   view-space z of visible pairs (sort key) */
     size_t tile_count;          /* uint32[V*T] */
-    size_t scan_scratch;        /* look-back scan state + ticket (cleared together with tile_count) */
+    size_t slot_ticket;         /* per-image instance-slot tickets, 256 B apart (cleared together with tile_count) */
     size_t tile_start;          /* uint32[V*T+1] exclusive scan (upstream ranges: [start[t], start[t+1])) */
     size_t tile_cursor;         /* uint32[V*T] */
     size_t chunk_start;         /* uint32[V*T+1] number of 4096-key sort chunks of long lists before tile t */

@@ -28,7 +28,7 @@ constexpr int GREC = 12;  // floats per partial record: gx gy gA gB | gC gop gr 
 // slot i — it adds that slot's (up to four) quadrant partials in quadrant order, parks the 10-float sum in LDS, and the thread
 // that holds the FIRST slot of a pair (slot_pair[i-1] != slot_pair[i]) then adds the pair's consecutive slots in slot order
 // and writes the pair's 48-byte raster-gradient record.  Every global load is independent of every other (the round-1 form —
-// one thread per pair walking offsets -> validity flags -> partial records — was a chain of dependent round trips at 6 %
+// one thread per pair walking slot bases -> validity flags -> partial records — was a chain of dependent round trips at 6 %
 // VALU utilisation: 87 us for 180 MB).  Fixed summation order: deterministic.  Slots of a pair that spill into the next
 // workgroup (1 pair in ~100) are re-read from global memory by the owner.
 __device__ __forceinline__ void slot_sum(const float4* __restrict__ part, const uint32_t* __restrict__ valid_words, uint32_t i,
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_gather_slots(uint32_t cap, const
 template <bool USE_SH, bool SH_PASS>
 __global__ __launch_bounds__(S360_BLOCK) void k_preprocess_bwd(
     KParams kp, const S360View* __restrict__ views, const float* __restrict__ means, const float* __restrict__ cov6,
-    const float* __restrict__ shs, const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ offsets,
+    const float* __restrict__ shs, const uint32_t* __restrict__ tiles_touched,
     const uint8_t* __restrict__ clamped, const float4* __restrict__ pairgrad, float* __restrict__ d_means3D,
     float* __restrict__ d_means2D, float* __restrict__ d_cov6, float* __restrict__ d_opac, float* __restrict__ d_shs,
     float* __restrict__ d_colors, float4* __restrict__ drgb_out, int depth_mode, const float* __restrict__ sh_jac) {
@@ -546,7 +546,7 @@ static int backward_impl(const S360Params* prm, const S360View* views, const flo
 
     const uint32_t* header = (const uint32_t*)(ws + L.header);
     const uint32_t* tiles_touched = (const uint32_t*)(ws + L.tiles_touched);
-    const uint32_t* offsets = (const uint32_t*)(ws + L.offsets);
+    const uint32_t* slot_base = (const uint32_t*)(ws + L.slot_base);
     const float4* recA = (const float4*)(ws + L.rec_a);
     const float4* recB = (const float4*)(ws + L.rec_b);
     const float4* recC = (const float4*)(ws + L.rec_c);
@@ -568,7 +568,7 @@ static int backward_impl(const S360Params* prm, const S360View* views, const flo
     hipLaunchKernelGGL(k_order_units, dim3(1 + 512), dim3(1024), 0, st, strip_last, use_order ? order : (uint32_t*)nullptr, nt * 4,
                        valid_words, header, kp.cap);
     const uint32_t* ord = use_order ? order : (const uint32_t*)nullptr;
-    launch_render_bwd_em(with_depth, nt * 4, st, kp, views, tile_start, list, offsets, recA, depths, final_T, n_contrib,
+    launch_render_bwd_em(with_depth, nt * 4, st, kp, views, tile_start, list, slot_base, recA, depths, final_T, n_contrib,
                          dL_dimages, dL_ddepth, part, (uint8_t*)valid_words, ord, depth_mode);
     }
     S360_CHECK_LAUNCH();
@@ -586,7 +586,7 @@ static int backward_impl(const S360Params* prm, const S360View* views, const flo
             // dRGB/d(view direction) reaches dL/dmean here (from the forward's sh_jac), whether or not dL/dSH is wanted
             // (harmonics frozen: d_shs == NULL), as upstream does
             hipLaunchKernelGGL((k_preprocess_bwd<true, false>), dim3(nblk), dim3(S360_BLOCK), 0, st, kp, views, means3D, cov6, shs,
-                               tiles_touched, offsets, clamped, pairgrad, d_means3D, d_means2D, d_cov6, d_opacities, d_shs,
+                               tiles_touched, clamped, pairgrad, d_means3D, d_means2D, d_cov6, d_opacities, d_shs,
                                d_colors, drgb, dmode, (const float*)(ws + L.sh_jac));
             if (!d_rgb_sum && d_shs) {
                 const int rc2 = launch_sh_bwd(kp, views, means3D, drgb, 1, d_shs, st);
@@ -605,12 +605,12 @@ static int backward_impl(const S360Params* prm, const S360View* views, const flo
                 }
             }
             hipLaunchKernelGGL((k_preprocess_bwd<true, true>), dim3(nblk), dim3(S360_BLOCK), lds, st, kp, views, means3D, cov6, shs,
-                               tiles_touched, offsets, clamped, pairgrad, d_means3D, d_means2D, d_cov6, d_opacities, d_shs,
+                               tiles_touched, clamped, pairgrad, d_means3D, d_means2D, d_cov6, d_opacities, d_shs,
                                d_colors, (float4*)nullptr, dmode, (const float*)nullptr);
         }
     } else {
         hipLaunchKernelGGL((k_preprocess_bwd<false, false>), dim3(nblk), dim3(S360_BLOCK), 0, st, kp, views, means3D, cov6, shs,
-                           tiles_touched, offsets, clamped, pairgrad, d_means3D, d_means2D, d_cov6, d_opacities, d_shs,
+                           tiles_touched, clamped, pairgrad, d_means3D, d_means2D, d_cov6, d_opacities, d_shs,
                            d_colors, (float4*)nullptr, dmode, (const float*)nullptr);
     }
     S360_CHECK_LAUNCH();

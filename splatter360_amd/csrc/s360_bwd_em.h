@@ -94,7 +94,7 @@ __device__ __forceinline__ float depth_value_grad(float z, float nearp, float fa
 template <bool WITH_DEPTH>
 __global__ __launch_bounds__(64) void k_render_bwd_em(
     KParams kp, const S360View* __restrict__ views, const uint32_t* __restrict__ tile_start,
-    const uint32_t* __restrict__ list, const uint32_t* __restrict__ offsets, const float4* __restrict__ recA,
+    const uint32_t* __restrict__ list, const uint32_t* __restrict__ slot_base, const float4* __restrict__ recA,
     const float* __restrict__ depths, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dimages, const float* __restrict__ dL_ddepth, float4* __restrict__ part,
     uint8_t* __restrict__ valid, const uint32_t* __restrict__ order, int depth_mode) {
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
         na = recA[3 * (size_t)p_n1];
         nb = recA[3 * (size_t)p_n1 + 1];
         nc = recA[3 * (size_t)p_n1 + 2];
-        nbase = p_n1 == 0 ? 0u : offsets[p_n1 - 1];
+        nbase = slot_base[p_n1];
         if (WITH_DEPTH) nz = depths[p_n1];
     }
     for (int64_t hi = hi0; hi >= 0; hi -= 64) {
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
             na = recA[3 * (size_t)p_n1];
             nb = recA[3 * (size_t)p_n1 + 1];
             nc = recA[3 * (size_t)p_n1 + 2];
-            nbase = p_n1 == 0 ? 0u : offsets[p_n1 - 1];
+            nbase = slot_base[p_n1];
             if (WITH_DEPTH) nz = depths[p_n1];
         }
         if (hi - 128 - lane >= 0) p_n2 = list[start + (uint32_t)(hi - 128 - lane)];
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
 // -fno-slp-vectorize: the SLP vectoriser packs pairs of the four pixel chains into v_pk_* instructions but pays for it
 // with 23 register moves per half row and 14 more VGPRs — 138 instead of 125, i.e. 3 instead of 4 waves per SIMD).
 void launch_render_bwd_em(bool with_depth, int n_units, hipStream_t st, const KParams& kp, const S360View* views,
-                          const uint32_t* tile_start, const uint32_t* list, const uint32_t* offsets, const float4* recA,
+                          const uint32_t* tile_start, const uint32_t* list, const uint32_t* slot_base, const float4* recA,
                           const float* depths, const float* final_T, const uint32_t* n_contrib, const float* dL_dimages,
                           const float* dL_ddepth, float4* part, uint8_t* valid, const uint32_t* order, int depth_mode);
 

@@ -5,9 +5,9 @@
 //   k_preprocess     1 thread / Gaussian, loops the V views in registers: cull, EWA cov2D, conic,
 //                    radius, tile rect; SH->RGB once per Gaussian when the views share campos
 //                    (each lane streams its own 300-byte slab with 16-byte loads).
-//   k_scan_lookback  single-pass inclusive scan of tiles_touched over the V*P (view, Gaussian) pairs
 //   k_tile_scan      exclusive scan of the per-tile instance counts -> tile ranges (+ sort-chunk table)
-//   k_emit           scatter (depth bits << 32 | pair) keys into their tile's bucket
+//   k_emit           scatter (depth bits << 32 | pair) keys into their tile's bucket; training calls: reserve the
+//                    pairs' instance slots (one atomic per block) and write the slot owner table
 //   k_sort_stage1 / k_merge_pass / k_sort_tiles_global
 //                    per-tile ascending sort of the unique 64-bit keys (== stable radix sort by
 //                    (tile, depth) with ascending-index emission): LDS merge sort per list or per
@@ -330,98 +330,6 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* l
     return base + inc - v;
 }
 
-// Single-pass inclusive scan (decoupled look-back): out[i] = in[0] + ... + in[i].  Blocks take their tile from
-// a ticket counter (so a block only ever waits for blocks that already hold a ticket and are therefore
-// resident), publish (flag, value) packed in one 64-bit word — flag 1 = tile aggregate, 2 = inclusive prefix —
-// and the first wave of each block walks back over its predecessors 64 at a time.  One 4-byte read and one
-// 4-byte write per element; coalesced 16-byte accesses (row k of a tile = 1024 consecutive elements, 4 per lane).
-// `state` ([ntiles] words) and `ticket` must be zero at launch (cleared together with tile_count).
-#ifndef S360_LB_ROWS
-#define S360_LB_ROWS 8
-#endif
-constexpr int LB_ROWS = S360_LB_ROWS;
-constexpr int LB_TILE = S360_BLOCK * 4 * LB_ROWS;  // 4096 elements per block
-
-__global__ __launch_bounds__(S360_BLOCK) void k_scan_lookback(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t n,
-                                                             unsigned long long* __restrict__ state, uint32_t* __restrict__ ticket) {
-    __shared__ uint32_t lds[8];
-    __shared__ uint32_t s_bid, s_prefix;
-    if (threadIdx.x == 0) s_bid = atomicAdd(ticket, 1u);
-    __syncthreads();
-    const uint32_t bid = s_bid;
-    const size_t tile0 = (size_t)bid * LB_TILE;
-    uint32_t v[LB_ROWS][4], row_ex[LB_ROWS], row_tot[LB_ROWS];
-#pragma unroll
-    for (int k = 0; k < LB_ROWS; ++k) {
-        const size_t i = tile0 + (size_t)k * (S360_BLOCK * 4) + (size_t)threadIdx.x * 4;
-        if (i + 3 < n) {
-            const uint4 q = *reinterpret_cast<const uint4*>(in + i);
-            v[k][0] = q.x; v[k][1] = q.y; v[k][2] = q.z; v[k][3] = q.w;
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[k][j] = i + j < n ? in[i + j] : 0u;
-        }
-    }
-    uint32_t total = 0;
-#pragma unroll
-    for (int k = 0; k < LB_ROWS; ++k) {
-        row_ex[k] = block_exclusive_scan(v[k][0] + v[k][1] + v[k][2] + v[k][3], lds, row_tot[k]);
-        total += row_tot[k];
-    }
-    if (threadIdx.x < 64) {
-        const int lane = threadIdx.x;
-        if (lane == 0)
-            __hip_atomic_store(&state[bid], ((unsigned long long)(bid == 0 ? 2u : 1u) << 32) | total, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t prefix = 0;
-        long long j = (long long)bid - 1;
-        while (j >= 0) {
-            const long long idx = j - lane;
-            unsigned long long w;
-            do {  // all 64 predecessors of this window must have published something
-                w = idx >= 0 ? __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 32);
-                if (__ballot((uint32_t)(w >> 32) == 0u) == 0ull) break;
-                __builtin_amdgcn_s_sleep(1);
-            } while (true);
-            const unsigned long long full = __ballot((uint32_t)(w >> 32) == 2u);
-            // nearest predecessor holding an inclusive prefix ends the walk: sum lanes 0..first
-            const int first = full ? __builtin_ctzll(full) : 63;
-            uint32_t part = lane <= first ? (uint32_t)w : 0u;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) part += (uint32_t)__shfl_xor((int)part, o);
-            prefix += part;
-            if (full) break;
-            j -= 64;
-        }
-        if (lane == 0) {
-            s_prefix = prefix;
-            if (bid > 0)
-                __hip_atomic_store(&state[bid], (2ull << 32) | (unsigned long long)(prefix + total), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    __syncthreads();
-    uint32_t run = s_prefix;
-#pragma unroll
-    for (int k = 0; k < LB_ROWS; ++k) {
-        const size_t i = tile0 + (size_t)k * (S360_BLOCK * 4) + (size_t)threadIdx.x * 4;
-        uint4 q;
-        q.x = run + row_ex[k] + v[k][0];
-        q.y = q.x + v[k][1];
-        q.z = q.y + v[k][2];
-        q.w = q.z + v[k][3];
-        if (i + 3 < n) {
-            *reinterpret_cast<uint4*>(out + i) = q;
-        } else {
-            const uint32_t qq[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (i + j < n) out[i + j] = qq[j];
-        }
-        run += row_tot[k];
-    }
-}
-
 // single block: tile_start[0..nt] = exclusive scan of tile_count; header bookkeeping.
 // Lists longer than SORT_SHORT keys are sorted as chunks of SORT_CHUNK keys (k_sort_stage1: one 512-thread
 // workgroup per chunk) followed, when there is more than one chunk, by global merge passes (k_merge_pass);
@@ -491,8 +399,11 @@ __global__ __launch_bounds__(S360_BLOCK) void k_emit(KParams kp, const uint32_t*
                                                     const float4* __restrict__ recA, const float4* __restrict__ recC,
                                                     const float* __restrict__ depths, const uint32_t* __restrict__ tile_start,
                                                     uint32_t* __restrict__ tile_cursor, uint64_t* __restrict__ keys,
-                                                    const uint32_t* __restrict__ offsets, uint32_t* __restrict__ slot_pair) {
+                                                    uint32_t* __restrict__ slot_base, uint32_t* __restrict__ slot_pair,
+                                                    uint32_t* __restrict__ slot_ticket) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_bin[];  // [T] counts/cursors, [T] bases
+    __shared__ uint32_t s_scan[S360_BLOCK / 64];
+    __shared__ uint32_t s_slot0;
     const int v = blockIdx.y;
     const int g0 = blockIdx.x * (S360_BLOCK * EMIT_PPT) + threadIdx.x;
     const size_t tb = (size_t)image_of_view(kp, v) * kp.T;
@@ -503,11 +414,27 @@ __global__ __launch_bounds__(S360_BLOCK) void k_emit(KParams kp, const uint32_t*
         __syncthreads();
     }
     // visible pairs of this thread (bit j: pair g0 + j*256); their rects are recomputed in the second phase
-    uint32_t vis = 0;
+    uint32_t vis = 0, tt[EMIT_PPT];
 #pragma unroll
     for (int j = 0; j < EMIT_PPT; ++j) {
         const int g = g0 + j * S360_BLOCK;
-        if (g < kp.P && tiles_touched[(size_t)v * kp.P + g] != 0) vis |= 1u << j;
+        tt[j] = g < kp.P ? tiles_touched[(size_t)v * kp.P + g] : 0u;
+        if (tt[j] != 0) vis |= 1u << j;
+    }
+    // Training calls: the pair's instance slots — where the backward composite leaves its partial gradients, one record
+    // per (pair, tile) — are `touched` consecutive slots reserved here: block total -> ONE returning atomic on the
+    // image's ticket (its slots start at tile_start[first tile of the image]; one ticket per image, 256 bytes apart:
+    // 14 000 returning atomics on a single address cost 20 us), exclusive scan inside the block.  Which block gets which
+    // range varies from run to run; nothing depends on it (k_gather_slots sums a pair's slots in slot order = the fixed
+    // tile order of its rectangle), and the upstream point_offsets scan over all V*P pairs (a 25 us kernel) is not needed.
+    uint32_t slot0 = 0, ticket = 0;
+    if (slot_pair) {
+        uint32_t mine = 0, tot;
+#pragma unroll
+        for (int j = 0; j < EMIT_PPT; ++j) mine += tt[j];
+        slot0 = block_exclusive_scan(mine, s_scan, tot);
+        // issued now, consumed after the counting phase
+        if (threadIdx.x == 0 && tot) ticket = tile_start[tb] + atomicAdd(&slot_ticket[image_of_view(kp, v) * 64], tot);
     }
     if (LDS_BIN) {
         for (uint32_t m = vis; m; m &= m - 1) {
@@ -527,7 +454,11 @@ __global__ __launch_bounds__(S360_BLOCK) void k_emit(KParams kp, const uint32_t*
                 cnt[i] = 0u;
             }
         }
+    }
+    if (slot_pair || LDS_BIN) {
+        if (slot_pair && threadIdx.x == 0) s_slot0 = ticket;
         __syncthreads();
+        if (slot_pair) slot0 += s_slot0;
     }
     for (uint32_t m = vis; m; m &= m - 1) {
         const size_t p = (size_t)v * kp.P + g0 + __builtin_ctz(m) * S360_BLOCK;
@@ -536,9 +467,15 @@ __global__ __launch_bounds__(S360_BLOCK) void k_emit(KParams kp, const uint32_t*
         int minx, miny, maxx, maxy;
         tile_rect(ra.x, ra.y, __float_as_int(rc.y), kp.gx, kp.gy, minx, miny, maxx, maxy);
         const uint64_t key = ((uint64_t)__float_as_uint(depths[p]) << 32) | (uint64_t)(uint32_t)p;
-        // training calls: owner table of the pair's instance slots (slot = offsets[p-1] + position inside the rectangle in
-        // this emission order — the slot the backward composite writes its partial gradients to)
-        uint32_t slot = slot_pair ? (p == 0 ? 0u : offsets[p - 1]) : 0u;
+        // owner table of the pair's instance slots (slot = slot_base[p] + position inside the rectangle in this emission order)
+        uint32_t slot = slot0;
+        if (slot_pair) {
+            const int j = __builtin_ctz(m);
+            slot_base[p] = slot0;
+#pragma unroll
+            for (int q = 0; q < EMIT_PPT; ++q)
+                if (q == j) slot0 += tt[q];
+        }
         for (int y = miny; y < maxy; ++y)
             for (int x = minx; x < maxx; ++x) {
                 const int t = y * kp.gx + x;
@@ -1116,14 +1053,14 @@ extern "C" int s360_layout(const S360Params* prm, S360Layout* out) {
     };
     out->header = take(64 * 4);
     out->tiles_touched = take(np * 4);
-    out->offsets = take(np * 4);
+    out->slot_base = take(np * 4);
     out->rec_a = take(np * 48);  // one 48-byte record per pair: rec_b / rec_c are the 2nd / 3rd float4 of it
     out->rec_b = out->rec_a + 16;
     out->rec_c = out->rec_a + 32;
     out->clamped = take(np);
     out->depths = take(np * 4);
     out->tile_count = take(nt * 4);
-    out->scan_scratch = take((np / LB_TILE + 2) * 8 + 16);  // look-back scan state + ticket; cleared with tile_count
+    out->slot_ticket = take((size_t)prm->V * 256);  // per-image instance-slot tickets, 256 B apart; cleared with tile_count
     out->tile_start = take((nt + 1) * 4);
     out->tile_cursor = take(nt * 4);
     out->chunk_start = take((nt + 1) * 4);
@@ -1184,8 +1121,8 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
 
     uint32_t* header = (uint32_t*)(ws + L.header);
     uint32_t* tiles_touched = (uint32_t*)(ws + L.tiles_touched);
-    uint32_t* offsets = (uint32_t*)(ws + L.offsets);
-    uint32_t* scratch = (uint32_t*)(ws + L.scan_scratch);
+    uint32_t* slot_base = (uint32_t*)(ws + L.slot_base);
+    uint32_t* slot_ticket = (uint32_t*)(ws + L.slot_ticket);
     float4* recA = (float4*)(ws + L.rec_a);
     float4* recB = (float4*)(ws + L.rec_b);
     float4* recC = (float4*)(ws + L.rec_c);
@@ -1204,7 +1141,7 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
     uint32_t* tile_max_contrib = (uint32_t*)(ws + L.tile_max_contrib);
     uint32_t* strip_last = (uint32_t*)(ws + L.strip_last);
 
-    // one clear for the tile histogram and the (adjacent) look-back scan state
+    // one clear for the tile histogram and the (adjacent) instance-slot ticket
     if (hipMemsetAsync(tile_count, 0, L.tile_start - L.tile_count, st) != hipSuccess) return S360_E_LAUNCH;
     if (kp.P > 0) {
         {
@@ -1246,14 +1183,6 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
         }
         }
         S360_CHECK_LAUNCH();
-        if (!(kp.flags & S360_FLAG_FORWARD_ONLY)) {  // offsets only feed the backward's instance slots
-        ProfScope ps(PS_SCAN, st);
-        const int sblk = (int)((np + LB_TILE - 1) / LB_TILE);
-        unsigned long long* lb_state = (unsigned long long*)scratch;
-        hipLaunchKernelGGL(k_scan_lookback, dim3(sblk), dim3(S360_BLOCK), 0, st, tiles_touched, offsets, np, lb_state,
-                           (uint32_t*)(lb_state + sblk + 1));
-        }
-        S360_CHECK_LAUNCH();
     }
     {
         ProfScope ps(PS_TILE_SCAN, st);
@@ -1268,10 +1197,10 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
         ProfScope ps(PS_EMIT, st);
         if ((size_t)kp.T * 8 <= 64 * 1024)
             hipLaunchKernelGGL(k_emit<true>, egrid, dim3(S360_BLOCK), (size_t)kp.T * 8, st, kp, tiles_touched, recA, recC,
-                               depths, tile_start, tile_cursor, keys, offsets, slot_pair);
+                               depths, tile_start, tile_cursor, keys, slot_base, slot_pair, slot_ticket);
         else
             hipLaunchKernelGGL(k_emit<false>, egrid, dim3(S360_BLOCK), 0, st, kp, tiles_touched, recA, recC, depths, tile_start,
-                               tile_cursor, keys, offsets, slot_pair);
+                               tile_cursor, keys, slot_base, slot_pair, slot_ticket);
         }
         S360_CHECK_LAUNCH();
         ProfScope ps(PS_SORT, st);

@@ -134,7 +134,8 @@ class RasterState:
         return dict(
             header=self.header(),
             tiles_touched=self._arr(l.tiles_touched, npair, torch.int32).view(p.V, p.P),
-            offsets=self._arr(l.offsets, npair, torch.int32).view(p.V, p.P),
+            slot_base=self._arr(l.slot_base, npair, torch.int32).view(p.V, p.P),
+            slot_pair=self._arr(l.slot_pair, cap, torch.int32),
             rec_a=self._arr(l.rec_a, npair * 12, torch.float32).view(p.V, p.P, 12)[..., 0:4],
             rec_b=self._arr(l.rec_a, npair * 12, torch.float32).view(p.V, p.P, 12)[..., 4:8],
             rec_c=self._arr(l.rec_a, npair * 12, torch.float32).view(p.V, p.P, 12)[..., 8:12],
@@ -208,7 +209,7 @@ class _RasterizeViews(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, cov6, views, cfg, mse_target=None):
-        (h, w, sh_degree, shared_campos, max_instances, check, want_radii, cov9, sh_channel_major, keep_offsets, depth_mode,
+        (h, w, sh_degree, shared_campos, max_instances, check, want_radii, cov9, sh_channel_major, keep_slots, depth_mode,
          defer_sh, mse_weight, mse_count, spherical) = cfg
         if spherical and (mse_target is not None or int(views.shape[0]) % 2):
             raise RuntimeError("spherical mode: views come in (camera, seam ghost) pairs; the fused loss epilogue is cube-face only")
@@ -233,7 +234,7 @@ class _RasterizeViews(torch.autograd.Function):
             needs_bwd = any(ctx.needs_input_grad[:6])  # (grad mode is off inside Function.forward; this reflects apply-time)
             prm.flags = (_lib.FLAG_SHARED_CAMPOS if (shared_campos or v == 1) else 0) | (
                 _lib.FLAG_COV9 if cov9 else 0) | (_lib.FLAG_SH_CHANNEL_MAJOR if sh_channel_major else 0) | (
-                0 if (needs_bwd or keep_offsets) else _lib.FLAG_FORWARD_ONLY) | (
+                0 if (needs_bwd or keep_slots) else _lib.FLAG_FORWARD_ONLY) | (
                 _lib.FLAG_SH_DEG4_IGNORED if SH_DEG4_IGNORED else 0) | (_lib.FLAG_SPHERICAL if spherical else 0)
             prm.max_instances = int(max_instances) if max_instances else default_capacity(p, v)
             mse = None
@@ -379,13 +380,13 @@ def rasterize_views(means3D: Tensor, cov6: Tensor, opacities: Tensor, shs: Optio
                     colors_precomp: Optional[Tensor] = None, *, views: Tensor, image_height: int, image_width: int,
                     sh_degree: int = 0, shared_campos: bool = False, max_instances: Optional[int] = None,
                     check: str = "sync", want_radii: bool = True, means2D: Optional[Tensor] = None,
-                    cov9: bool = False, sh_channel_major: bool = False, keep_offsets: bool = False,
+                    cov9: bool = False, sh_channel_major: bool = False, keep_slots: bool = False,
                     depth_mode: Optional[str] = None, defer_sh: bool = False, mse_target: Optional[Tensor] = None,
                     mse_weight: float = 1.0, mse_count: Optional[int] = None, spherical: bool = False):
     """Render V views ([V,44] packed, see pack_views) of one cloud.  cov9: cov6 is [P,3,3];
     sh_channel_major: shs is [P,3,M] (the reference's Gaussians layouts, consumed without copies).
-    When no input requires grad the per-pair offsets scan (backward-only state) is skipped unless
-    keep_offsets=True.  depth_mode ("depth" | "disparity" | "relative_disparity" | "log"): also return the
+    When no input requires grad the instance-slot tables (backward-only state) are skipped unless
+    keep_slots=True.  depth_mode ("depth" | "disparity" | "relative_disparity" | "log"): also return the
     fused depth map [V,H,W] of render_depth_cuda as a third result (differentiable; needs near / far in `views`).
     defer_sh=True (views sharing one camera centre): the backward skips the SH pass, returns no gradient for
     `shs` and leaves a DeferredSH (last_deferred()) for distributed.sync_gradients_factored.  Returns (images[V,3,H,W],
@@ -405,7 +406,7 @@ def rasterize_views(means3D: Tensor, cov6: Tensor, opacities: Tensor, shs: Optio
     if depth_mode is not None and depth_mode not in DEPTH_MODES:
         raise ValueError(f"depth_mode must be one of {sorted(DEPTH_MODES)}")
     cfg = (image_height, image_width, sh_degree, shared_campos, max_instances, check, want_radii, cov9,
-           sh_channel_major, keep_offsets, depth_mode, defer_sh, mse_weight, mse_count, bool(spherical))
+           sh_channel_major, keep_slots, depth_mode, defer_sh, mse_weight, mse_count, bool(spherical))
     images, radii, depth, loss, clipped = _RasterizeViews.apply(means3D, means2D, shs, colors_precomp, op2, cov6, views,
                                                                 cfg, mse_target)
     images.s360_deferred = _RasterizeViews.last_holder      # see deferred_of()

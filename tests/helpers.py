@@ -63,3 +63,21 @@ def small_front_scene(n=40, seed=0, h=64, w=64, d_sh=25, spread=0.6, zrange=(2.0
                     viewmatrix=view.T.copy(), projmatrix=(view.T @ proj.T).copy(), sh_degree=int(round(np.sqrt(d_sh))) - 1,
                     campos=np.zeros(3))
     return settings, means, cov6, shs, opac
+
+
+def check_instance_slots(slot_base, slot_pair, tiles_touched, L):
+    """Training state that replaces upstream's point_offsets scan: every visible pair owns `touched` consecutive
+    instance slots starting at slot_base[pair]; the ranges tile [0, L) exactly and slot_pair is their owner table.
+    (Which range a pair gets is run-dependent: k_emit reserves block-wise with one atomic per block.)"""
+    import numpy as np
+    base = np.asarray(slot_base).reshape(-1).astype(np.int64) & 0xFFFFFFFF
+    tt = np.asarray(tiles_touched).reshape(-1).astype(np.int64)
+    vis = np.nonzero(tt > 0)[0]
+    assert tt.sum() == L
+    if L == 0:
+        return
+    order = np.argsort(base[vis], kind="stable")
+    b, n = base[vis][order], tt[vis][order]
+    assert b[0] == 0 and (b[1:] == (b + n)[:-1]).all() and (b + n)[-1] == L
+    owner = np.repeat(vis[order], n)
+    np.testing.assert_array_equal(np.asarray(slot_pair).reshape(-1)[:L].astype(np.int64) & 0xFFFFFFFF, owner)

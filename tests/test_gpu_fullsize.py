@@ -23,16 +23,23 @@ def big(gpu):
 
 def test_binning_invariants_and_sortedness_at_1m(gpu, big):
     cloud, params, (ext, K, near, far) = big
-    params = [p.clone().requires_grad_(True) for p in params]   # training mode: the offsets scan is part of the state
+    params = [p.clone().requires_grad_(True) for p in params]   # training mode: the instance-slot tables are part of the state
     faces = decoder.render_views_fused(ext, K, near, far, (256, 256), torch.zeros(3, device=gpu), *params).detach()
     st = rasterizer.last_state()
     t = st.tensors()
     L = st.num_rendered()
     assert not st.overflowed() and torch.isfinite(faces).all()
     tt = t["tiles_touched"].view(-1).to(torch.int64)
-    off = t["offsets"].view(-1).to(torch.int64) & 0xFFFFFFFF
-    assert int(tt.sum()) == L == int(off[-1])
-    assert torch.equal(off, torch.cumsum(tt, 0))
+    assert int(tt.sum()) == L
+    # instance slots: every visible pair owns `touched` consecutive slots, the ranges tile [0, L) exactly, and the owner
+    # table agrees (which range a pair gets is run-dependent: block-wise reservation instead of upstream's offsets scan)
+    base = t["slot_base"].view(-1).to(torch.int64) & 0xFFFFFFFF
+    vis = tt > 0
+    order = torch.argsort(base[vis])
+    b, n = base[vis][order], tt[vis][order]
+    assert int(b[0]) == 0 and torch.equal(b[1:], (b + n)[:-1]) and int((b + n)[-1]) == L
+    owner = torch.repeat_interleave(torch.nonzero(vis).view(-1)[order], n)
+    assert torch.equal(owner.to(torch.int32), t["slot_pair"][:L])
     ts = t["tile_start"].to(torch.int64)
     assert int(ts[0]) == 0 and int(ts[-1]) == L and bool((ts[1:] >= ts[:-1]).all())
     assert torch.equal(ts[1:] - ts[:-1], t["tile_count"].to(torch.int64))
