@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define S360_ABI_VERSION 13
+#define S360_ABI_VERSION 14
 #define S360_MAX_VIEWS 8
 #define S360_TILE 16
 
@@ -183,18 +183,22 @@ int s360_forward_depth(const S360Params* prm, const S360View* views, const float
  * and the loss's autograd seed.  target[V,3,H,W]; d_images[V,3,H,W] = grad_scale * (image - target) (pass
  * grad_scale = 2*weight/N, N = elements averaged over); partials[V*tiles*4, 2] = per 8x8 quadrant of every tile (in
  * tile order) the sums of squared differences, plain and clipped — summed in a fixed order
- * by the caller (deterministic).  depth_maps may be null (no depth channel).
+ * by the caller, or (loss_out != NULL) by one more small launch of the same call: loss_out[0] = (grad_scale / 2) * sum
+ * of all plain partials (= weight * mean over the N elements), loss_out[1 + v] = clipped MSE of view v.  Deterministic
+ * either way.  depth_maps may be null (no depth channel).
  */
 int s360_forward_mse(const S360Params* prm, const S360View* views, const float* means3D,
                      const float* cov6, const float* opacities, const float* shs,
                      const float* colors_precomp, float* images, float* depth_maps, int32_t depth_mode,
                      int32_t* radii, const float* target, float grad_scale, float* d_images, float* partials,
-                     void* workspace, size_t workspace_bytes, void* stream);
+                     float* loss_out, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * Backward: replaces upstream `rasterize_gaussians_backward(...)` (autograd backward of the
  * call above).  `workspace` is the forward workspace, unmodified since s360_forward.
- *   dL_dimages[V,3,H,W]
+ *   dL_dimages[V,3,H,W]; dL_dimages_scale: NULL, or a DEVICE pointer to one float every element of dL_dimages is
+ *   multiplied by as it is read (the scalar autograd hands back for a loss whose seed is already stored — the
+ *   d_images of s360_forward_mse — or an AMP loss scale: no separate elementwise pass, no host read)
  *   dL_ddepth[V,H,W] / depth_mode: gradient of the fused depth map of s360_forward_depth (same depth_mode as the
  *   forward); NULL: no depth channel (e.g. the forward was s360_forward).
  * Outputs (all written, no accumulation into caller data):
@@ -207,7 +211,7 @@ int s360_forward_mse(const S360Params* prm, const S360View* views, const float* 
 int s360_backward(const S360Params* prm, const S360View* views, const float* means3D,
                   const float* cov6, const float* opacities, const float* shs,
                   const float* colors_precomp, const void* workspace, size_t workspace_bytes,
-                  const float* dL_dimages,
+                  const float* dL_dimages, const float* dL_dimages_scale,
                   const float* dL_ddepth, int32_t depth_mode, float* d_means3D, float* d_means2D,
                   float* d_cov6, float* d_opacities, float* d_shs, float* d_colors, void* bwd_workspace,
                   size_t bwd_workspace_bytes, void* stream);
@@ -227,7 +231,7 @@ int s360_backward(const S360Params* prm, const S360View* views, const float* mea
 int s360_backward_split(const S360Params* prm, const S360View* views, const float* means3D,
                         const float* cov6, const float* opacities, const float* shs,
                         const void* workspace, size_t workspace_bytes,
-                        const float* dL_dimages, const float* dL_ddepth,
+                        const float* dL_dimages, const float* dL_dimages_scale, const float* dL_ddepth,
                         int32_t depth_mode, float* d_means3D, float* d_means2D, float* d_cov6,
                         float* d_opacities, float* d_rgb_sum, void* bwd_workspace,
                         size_t bwd_workspace_bytes, void* stream);

@@ -26,7 +26,7 @@ FLAG_SH_CHANNEL_MAJOR = 4
 FLAG_FORWARD_ONLY = 8
 FLAG_SH_DEG4_IGNORED = 16
 FLAG_SPHERICAL = 32
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 class S360Params(C.Structure):
@@ -134,11 +134,11 @@ def lib() -> C.CDLL:
     l.s360_forward_depth.restype = C.c_int
     l.s360_forward_depth.argtypes = [C.POINTER(S360Params)] + [vp] * 8 + [i32, vp, vp, sz, vp]
     l.s360_forward_mse.restype = C.c_int
-    l.s360_forward_mse.argtypes = [C.POINTER(S360Params)] + [vp] * 8 + [i32, vp, vp, C.c_float, vp, vp, vp, sz, vp]
+    l.s360_forward_mse.argtypes = [C.POINTER(S360Params)] + [vp] * 8 + [i32, vp, vp, C.c_float, vp, vp, vp, vp, sz, vp]
     l.s360_backward.restype = C.c_int
-    l.s360_backward.argtypes = [C.POINTER(S360Params)] + [vp] * 7 + [sz] + [vp] * 2 + [i32] + [vp] * 7 + [sz, vp]
+    l.s360_backward.argtypes = [C.POINTER(S360Params)] + [vp] * 7 + [sz] + [vp] * 3 + [i32] + [vp] * 7 + [sz, vp]
     l.s360_backward_split.restype = C.c_int
-    l.s360_backward_split.argtypes = [C.POINTER(S360Params)] + [vp] * 6 + [sz] + [vp] * 2 + [i32] + [vp] * 6 + [sz, vp]
+    l.s360_backward_split.argtypes = [C.POINTER(S360Params)] + [vp] * 6 + [sz] + [vp] * 3 + [i32] + [vp] * 6 + [sz, vp]
     l.s360_sh_backward.restype = C.c_int
     l.s360_sh_backward.argtypes = [C.POINTER(S360Params), i32] + [vp] * 5
     l.s360_pack_views.restype = C.c_int

@@ -518,7 +518,7 @@ static int launch_sh_bwd(const KParams& kp, const S360View* views, const float* 
 static int backward_impl(const S360Params* prm, const S360View* views, const float* means3D, const float* cov6,
                          const float* opacities, const float* shs, const float* colors_precomp,
                          const void* workspace, size_t workspace_bytes, const float* dL_dimages,
-                         const float* dL_ddepth, int depth_mode, float* d_means3D,
+                         const float* dL_dimages_scale, const float* dL_ddepth, int depth_mode, float* d_means3D,
                          float* d_means2D, float* d_cov6, float* d_opacities, float* d_shs, float* d_colors,
                          float* d_rgb_sum, void* bwd_workspace, size_t bwd_workspace_bytes, void* stream_) {
     (void)opacities;
@@ -569,7 +569,7 @@ static int backward_impl(const S360Params* prm, const S360View* views, const flo
                        valid_words, header, kp.cap);
     const uint32_t* ord = use_order ? order : (const uint32_t*)nullptr;
     launch_render_bwd_em(with_depth, nt * 4, st, kp, views, tile_start, list, slot_base, recA, depths, final_T, n_contrib,
-                         dL_dimages, dL_ddepth, part, (uint8_t*)valid_words, ord, depth_mode);
+                         dL_dimages, dL_dimages_scale, dL_ddepth, part, (uint8_t*)valid_words, ord, depth_mode);
     }
     S360_CHECK_LAUNCH();
     ProfScope ps(PS_PREPROCESS_BWD, st);
@@ -620,23 +620,23 @@ static int backward_impl(const S360Params* prm, const S360View* views, const flo
 extern "C" int s360_backward(const S360Params* prm, const S360View* views, const float* means3D, const float* cov6,
                              const float* opacities, const float* shs, const float* colors_precomp,
                              const void* workspace, size_t workspace_bytes, const float* dL_dimages,
-                             const float* dL_ddepth, int32_t depth_mode, float* d_means3D,
+                             const float* dL_dimages_scale, const float* dL_ddepth, int32_t depth_mode, float* d_means3D,
                              float* d_means2D, float* d_cov6, float* d_opacities, float* d_shs, float* d_colors,
                              void* bwd_workspace, size_t bwd_workspace_bytes, void* stream_) {
     return backward_impl(prm, views, means3D, cov6, opacities, shs, colors_precomp, workspace, workspace_bytes,
-                         dL_dimages, dL_ddepth, depth_mode, d_means3D, d_means2D, d_cov6, d_opacities, d_shs,
+                         dL_dimages, dL_dimages_scale, dL_ddepth, depth_mode, d_means3D, d_means2D, d_cov6, d_opacities, d_shs,
                          d_colors, nullptr, bwd_workspace, bwd_workspace_bytes, stream_);
 }
 
 extern "C" int s360_backward_split(const S360Params* prm, const S360View* views, const float* means3D, const float* cov6,
                                    const float* opacities, const float* shs, const void* workspace, size_t workspace_bytes,
-                                   const float* dL_dimages,
+                                   const float* dL_dimages, const float* dL_dimages_scale,
                                    const float* dL_ddepth, int32_t depth_mode, float* d_means3D, float* d_means2D,
                                    float* d_cov6, float* d_opacities, float* d_rgb_sum, void* bwd_workspace,
                                    size_t bwd_workspace_bytes, void* stream_) {
     if (!shs || !d_rgb_sum) return S360_E_BADARG;
     return backward_impl(prm, views, means3D, cov6, opacities, shs, nullptr, workspace, workspace_bytes, dL_dimages,
-                         dL_ddepth, depth_mode, d_means3D, d_means2D, d_cov6, d_opacities, nullptr, nullptr,
+                         dL_dimages_scale, dL_ddepth, depth_mode, d_means3D, d_means2D, d_cov6, d_opacities, nullptr, nullptr,
                          d_rgb_sum, bwd_workspace, bwd_workspace_bytes, stream_);
 }
 

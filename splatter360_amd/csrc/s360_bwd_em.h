@@ -96,7 +96,8 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
     KParams kp, const S360View* __restrict__ views, const uint32_t* __restrict__ tile_start,
     const uint32_t* __restrict__ list, const uint32_t* __restrict__ slot_base, const float4* __restrict__ recA,
     const float* __restrict__ depths, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-    const float* __restrict__ dL_dimages, const float* __restrict__ dL_ddepth, float4* __restrict__ part,
+    const float* __restrict__ dL_dimages, const float* __restrict__ dL_dimages_scale, const float* __restrict__ dL_ddepth,
+    float4* __restrict__ part,
     uint8_t* __restrict__ valid, const uint32_t* __restrict__ order, int depth_mode) {
     static_assert(SUB_W == 8, "entry-major backward assumes 8x8 quadrants");
     __shared__ float4 s_q[EM_QCAP * 3];
@@ -123,9 +124,10 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
             const float T_final = final_T[(size_t)v * hw + pix];
             last = n_contrib[(size_t)v * hw + pix];
             const float* dimg = dL_dimages + (size_t)v * 3 * hw;
-            pa.x = dimg[pix];
-            pa.y = dimg[hw + pix];
-            pa.z = dimg[2 * hw + pix];
+            const float gs = dL_dimages_scale ? *dL_dimages_scale : 1.0f;  // scalar of a pre-stored loss seed (s360.h)
+            pa.x = dimg[pix] * gs;
+            pa.y = dimg[hw + pix] * gs;
+            pa.z = dimg[2 * hw + pix] * gs;
             if (WITH_DEPTH) pa.w = dL_ddepth[(size_t)v * hw + pix];  // depth background is 0: no background term
             pb.x = T_final;
             pb.z = T_final * (vw.bg[0] * pa.x + vw.bg[1] * pa.y + vw.bg[2] * pa.z);
@@ -324,6 +326,6 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
 void launch_render_bwd_em(bool with_depth, int n_units, hipStream_t st, const KParams& kp, const S360View* views,
                           const uint32_t* tile_start, const uint32_t* list, const uint32_t* slot_base, const float4* recA,
                           const float* depths, const float* final_T, const uint32_t* n_contrib, const float* dL_dimages,
-                          const float* dL_ddepth, float4* part, uint8_t* valid, const uint32_t* order, int depth_mode);
+                          const float* dL_dimages_scale, const float* dL_ddepth, float4* part, uint8_t* valid, const uint32_t* order, int depth_mode);
 
 }  // namespace s360

@@ -804,7 +804,56 @@ struct MseEp {
     float* d_images;      // [V,3,H,W]  grad_scale * (image - target)
     float* partials;      // [V*T*4, 2] per 8x8 quadrant: sum (image-target)^2, sum (clip01(image)-clip01(target))^2
     float grad_scale;
+    float* loss_out;      // [1 + V] or null: (grad_scale / 2) * sum of all plain partials, per-view clipped MSE
 };
+
+// Final reduction of the loss epilogue in one launch (torch needs four: two reductions and two scalings).  One workgroup;
+// fixed assignment of partials to threads, fixed shuffle tree, fixed wave order: deterministic.
+__global__ __launch_bounds__(S360_BLOCK) void k_mse_finish(const float* __restrict__ partials, int n_per_view, int V, float loss_scale,
+                                                          float inv_elems, float* __restrict__ out) {
+    constexpr int VG = 8;  // views per sweep
+    __shared__ float s_w[S360_BLOCK / 64][VG][2];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    float total = 0.f;
+    for (int v0 = 0; v0 < V; v0 += VG) {
+        float a[VG], b[VG];
+#pragma unroll
+        for (int j = 0; j < VG; ++j) {
+            a[j] = b[j] = 0.f;
+            if (v0 + j < V) {
+                const float2* p = reinterpret_cast<const float2*>(partials) + (size_t)(v0 + j) * n_per_view;
+                for (int i = threadIdx.x; i < n_per_view; i += S360_BLOCK) {
+                    const float2 q = p[i];
+                    a[j] += q.x;
+                    b[j] += q.y;
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                a[j] += __shfl_xor(a[j], o);
+                b[j] += __shfl_xor(b[j], o);
+            }
+            if (lane == 0) {
+                s_w[wave][j][0] = a[j];
+                s_w[wave][j][1] = b[j];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int j = 0; j < VG && v0 + j < V; ++j) {
+                float sa = 0.f, sb = 0.f;
+                for (int w = 0; w < S360_BLOCK / 64; ++w) {
+                    sa += s_w[w][j][0];
+                    sb += s_w[w][j][1];
+                }
+                total += sa;
+                out[1 + v0 + j] = sb * inv_elems;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = total * loss_scale;
+}
 
 template <bool WITH_DEPTH>
 __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_render(KParams kp, const S360View* __restrict__ views,
@@ -1095,7 +1144,7 @@ extern "C" int s360_layout(const S360Params* prm, S360Layout* out) {
 static int forward_impl(const S360Params* prm, const S360View* views, const float* means3D, const float* cov6,
                         const float* opacities, const float* shs, const float* colors_precomp, float* images,
                         float* depth_maps, int depth_mode, int32_t* radii, void* workspace, size_t workspace_bytes,
-                        void* stream_, MseEp ep = MseEp{nullptr, nullptr, nullptr, 0.f}) {
+                        void* stream_, MseEp ep = MseEp{nullptr, nullptr, nullptr, 0.f, nullptr}) {
     if (!prm || !views || !images || !workspace) return S360_E_BADARG;
     if (prm->P > 0 && (shs == nullptr) == (colors_precomp == nullptr)) return S360_E_BADARG;
     if (prm->P > 0 && (!means3D || !cov6 || !opacities)) return S360_E_BADARG;
@@ -1242,6 +1291,9 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
             hipLaunchKernelGGL(k_render<false>, rgrid, rblock, occupancy_cap_lds("S360_RENDER_LDS", 0), st, kp, views, tile_start,
                                list, recA, recB, recC, images, final_T, n_contrib, tile_max_contrib, strip_last, dbg,
                                depths, depth_maps, depth_mode, ep, kp.P > 0 ? tile_order : (const uint32_t*)nullptr);
+        if (ep.target && ep.loss_out)
+            hipLaunchKernelGGL(k_mse_finish, dim3(1), dim3(S360_BLOCK), 0, st, ep.partials, kp.T * 4, kp.V, 0.5f * ep.grad_scale,
+                               1.0f / (3.0f * (float)kp.H * (float)kp.W), ep.loss_out);
     }
     S360_CHECK_LAUNCH();
     return S360_OK;
@@ -1266,10 +1318,10 @@ extern "C" int s360_forward_depth(const S360Params* prm, const S360View* views, 
 extern "C" int s360_forward_mse(const S360Params* prm, const S360View* views, const float* means3D, const float* cov6,
                                 const float* opacities, const float* shs, const float* colors_precomp, float* images,
                                 float* depth_maps, int32_t depth_mode, int32_t* radii, const float* target,
-                                float grad_scale, float* d_images, float* partials, void* workspace,
+                                float grad_scale, float* d_images, float* partials, float* loss_out, void* workspace,
                                 size_t workspace_bytes, void* stream_) {
     if (!target || !d_images || !partials) return S360_E_BADARG;
     if (depth_maps && (depth_mode < 0 || depth_mode > 3)) return S360_E_BADARG;
     return forward_impl(prm, views, means3D, cov6, opacities, shs, colors_precomp, images, depth_maps, depth_mode, radii,
-                        workspace, workspace_bytes, stream_, s360::MseEp{target, d_images, partials, grad_scale});
+                        workspace, workspace_bytes, stream_, s360::MseEp{target, d_images, partials, grad_scale, loss_out});
 }

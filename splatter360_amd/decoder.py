@@ -162,8 +162,9 @@ def cube_cameras(pano_c2w: Tensor, near, far):
     dev = pano_c2w.device
     ext = cameras.cube_face_extrinsics(pano_c2w[None])[0]
     k = cameras.cube_face_intrinsics(1, device=dev)[0]
-    n = torch.as_tensor(near, dtype=torch.float32, device=dev).reshape(-1).expand(6)
-    f = torch.as_tensor(far, dtype=torch.float32, device=dev).reshape(-1).expand(6)
+    # materialised like the data loader's tensors (an expanded scalar would cost a copy kernel in every packing call)
+    n = torch.as_tensor(near, dtype=torch.float32, device=dev).reshape(-1).expand(6).contiguous()
+    f = torch.as_tensor(far, dtype=torch.float32, device=dev).reshape(-1).expand(6).contiguous()
     return ext, k, n, f
 
 

@@ -184,13 +184,14 @@ def _forward_call(prm, views, means3D, cov6, opac, shs, colors, want_radii: bool
         d_images = torch.empty_like(images)
         nquads = prm.V * ((prm.H + 15) // 16) * ((prm.W + 15) // 16) * 4   # one partial per wave footprint (8x8 px)
         partials = torch.empty((nquads, 2), dtype=torch.float32, device=dev)
+        loss_out = torch.empty((1 + prm.V,), dtype=torch.float32, device=dev)   # loss, clipped MSE per view (same call)
         rc = _lib.lib().s360_forward_mse(C.byref(prm), _ptr(views), _ptr(means3D), _ptr(cov6), _ptr(opac), _ptr(shs),
                                          _ptr(colors), _ptr(images), _ptr(depth), DEPTH_MODES.get(depth_mode, 0), _ptr(radii),
-                                         _ptr(target), C.c_float(grad_scale), _ptr(d_images), _ptr(partials),
+                                         _ptr(target), C.c_float(grad_scale), _ptr(d_images), _ptr(partials), _ptr(loss_out),
                                          _ptr(ws), lay.total_bytes, stream)
         _lib.check(rc, "s360_forward_mse")
         st = RasterState(prm, lay, ws)
-        st.d_images, st.mse_partials = d_images, partials
+        st.d_images, st.mse_partials, st.mse_out = d_images, partials, loss_out
         return images, radii, st, depth
     if depth_mode is None:
         rc = _lib.lib().s360_forward(C.byref(prm), _ptr(views), _ptr(means3D), _ptr(cov6), _ptr(opac), _ptr(shs),
@@ -249,9 +250,8 @@ class _RasterizeViews(torch.autograd.Function):
                 prm.max_instances = state.num_rendered()
                 images, radii, state, depth = _forward_call(prm, vw, m3, c6, op, sh, col, want_radii, depth_mode, mse)
             if mse is not None:
-                sums = state.mse_partials.view(v, -1, 2).sum(1)          # fixed order: deterministic
-                loss = sums[:, 0].sum() * (float(mse_weight) / n_mean)
-                clipped_mse = sums[:, 1] / float(3 * int(h) * int(w))
+                loss = state.mse_out[0]             # reduced by the call itself (k_mse_finish: fixed order, deterministic)
+                clipped_mse = state.mse_out[1:]
             else:
                 loss = torch.empty(0, dtype=torch.float32, device=images.device)
                 clipped_mse = loss
@@ -281,9 +281,14 @@ class _RasterizeViews(torch.autograd.Function):
         dev = m3.device
         with torch.cuda.device(dev):
             g = None if grad_images is None else grad_images.detach().float()
+            g_scale = None
             if grad_loss is not None and getattr(state, "d_images", None) is not None:
-                seed = state.d_images * grad_loss.detach().float()   # d_images = 2w/N (image - target) from the epilogue
-                g = seed if g is None else g + seed
+                # d_images = 2w/N (image - target) from the epilogue; the scalar autograd hands back multiplies it inside
+                # the composite's pixel load (dL_dimages_scale) unless an image gradient has to be added as well
+                if g is None:
+                    g, g_scale = state.d_images, grad_loss.detach().float().reshape(1).contiguous()
+                else:
+                    g = g + state.d_images * grad_loss.detach().float()
             if g is None:
                 n_img = prm.V // 2 if (prm.flags & _lib.FLAG_SPHERICAL) else prm.V
                 g = torch.zeros((n_img, 3, prm.H, prm.W), dtype=torch.float32, device=dev)
@@ -307,7 +312,7 @@ class _RasterizeViews(torch.autograd.Function):
                 d_rgb = torch.empty((p, 4), dtype=torch.float32, device=dev)
                 rc = _lib.lib().s360_backward_split(
                     C.byref(prm), _ptr(vw), _ptr(m3), _ptr(c6), _ptr(op), _ptr(sh), _ptr(state.workspace), lay.total_bytes,
-                    _ptr(g), _ptr(gd), dm, _ptr(d_m3), _ptr(d_m2), _ptr(d_c6), _ptr(d_op), _ptr(d_rgb),
+                    _ptr(g), _ptr(g_scale), _ptr(gd), dm, _ptr(d_m3), _ptr(d_m2), _ptr(d_c6), _ptr(d_op), _ptr(d_rgb),
                     _ptr(bws), lay.backward_bytes, stream)
                 _lib.check(rc, "s360_backward_split")
                 ctx.holder["deferred"] = _RasterizeViews.last_deferred = DeferredSH(prm, vw, m3, sh, d_rgb)
@@ -316,7 +321,7 @@ class _RasterizeViews(torch.autograd.Function):
                 return d_m3, d_m2, None, None, d_op.view(-1, 1), d_c6, None, None, None
             rc = _lib.lib().s360_backward(
                 C.byref(prm), _ptr(vw), _ptr(m3), _ptr(c6), _ptr(op), _ptr(sh), _ptr(col), _ptr(state.workspace),
-                lay.total_bytes, _ptr(g), _ptr(gd), dm, _ptr(d_m3), _ptr(d_m2), _ptr(d_c6),
+                lay.total_bytes, _ptr(g), _ptr(g_scale), _ptr(gd), dm, _ptr(d_m3), _ptr(d_m2), _ptr(d_c6),
                 _ptr(d_op), _ptr(d_sh), _ptr(d_col), _ptr(bws), lay.backward_bytes, stream)
             _lib.check(rc, "s360_backward")
         if d_m2 is not None:

@@ -4,7 +4,7 @@ torch: LossMse = weight * mean((color - target)^2) (src/loss/loss_mse.py:30-31) 
 import pytest
 import torch
 
-from splatter360_amd import decoder, synthetic
+from splatter360_amd import decoder, rasterizer, synthetic
 
 pytestmark = pytest.mark.gpu
 
@@ -65,6 +65,23 @@ def test_fused_mse_scaled_and_combined_with_image_gradient(gpu):
     for p, w in zip(ps, want):
         scale = w.abs().max().item() + 1e-20
         assert (p.grad - w).abs().max().item() / scale <= 2e-5   # g + seed is rounded once more than autograd's sum
+
+
+def test_fused_mse_loss_scalar_applied_inside_the_backward(gpu):
+    """A scaled loss alone (no image gradient): the scalar autograd hands back reaches the composite through
+    dL_dimages_scale (s360.h) — bit-identical to multiplying the stored seed in a separate elementwise pass."""
+    ps, (ext, K, near, far), gt = _setup(gpu, seed=3)
+    bg = torch.zeros(3, device=gpu)
+    faces, fm = decoder.render_views_fused(ext, K, near, far, (64, 64), bg, *ps, mse_target=gt)
+    seed = rasterizer.last_state().d_images.clone()
+    (3.25 * fm.loss).backward()
+    got = [p.grad.clone() for p in ps]
+    for p in ps:
+        p.grad = None
+    faces2 = decoder.render_views_fused(ext, K, near, far, (64, 64), bg, *ps)
+    faces2.backward(seed * 3.25)
+    for p, g in zip(ps, got):
+        assert torch.equal(p.grad, g)
 
 
 def test_fused_mse_ragged_image_and_no_grad(gpu):
