@@ -108,6 +108,156 @@ __global__ __launch_bounds__(S360_BLOCK) void k_sh_eval(KParams kp, const S360Vi
     }
 }
 
+// Channel-major slabs ([P,3,25], the reference's Gaussians.harmonics layout) at degree 4, inference form: ONE LANE PER
+// (Gaussian, colour channel).  The workgroup's 64 slabs are 19 200 contiguous bytes: coalesced 16-byte loads into LDS, then
+// thread t owns floats [25 t, 25 t + 25) (lane stride 25 words: conflict-free) — a lane keeps 25 coefficients instead of 75
+// (49 VGPRs against 126), the channel's sum is the same sequential sum (bit-identical colours), and the three channels meet
+// in LDS for the packed colour record.  63 us for 1 M Gaussians (343 MB: 5.4 TB/s) against 70 us one lane per Gaussian.
+// (Per-lane unaligned 16-byte loads of the 100-byte runs instead of the LDS stage: 112 us — at 8 waves per SIMD a lane's
+// lines are evicted from the 32-KB L1 between its successive loads.)
+constexpr int SHE3_G = 64;  // Gaussians per workgroup (192 threads)
+__global__ __launch_bounds__(SHE3_G * 3) void k_sh_eval3(KParams kp, const S360View* __restrict__ views, const float* __restrict__ means,
+                                                        const float* __restrict__ shs, float4* __restrict__ rgbc) {
+    __shared__ float s_rgb[SHE3_G * 3];
+    __shared__ __attribute__((aligned(16))) float s_sh[7 * SHE3_G * 3 * 4];  // the workgroup's 64 slabs (19 200 contiguous bytes) + pad
+    const int tid = threadIdx.x;
+    const int gl = tid / 3;
+    const int g0 = blockIdx.x * SHE3_G;
+    const int g = g0 + gl;
+    {
+        const float* src = shs + (size_t)g0 * 75;
+        const int nfl = min(SHE3_G, kp.P - g0) * 75;
+        if ((((uintptr_t)src) & 15) == 0 && nfl == SHE3_G * 75) {
+            // full workgroup: 1 200 float4 = 6.25 per thread.  Loads AND stores unconditional (the 7th round's surplus lanes
+            // re-read the last vector into the pad): a guarded load compiles to a branch with a full wait per round
+            const float4* s4 = reinterpret_cast<const float4*>(src);
+            float4* d4 = reinterpret_cast<float4*>(s_sh);
+            float4 q[7];
+#pragma unroll
+            for (int r = 0; r < 7; ++r) q[r] = s4[min(tid + r * (SHE3_G * 3), SHE3_G * 75 / 4 - 1)];
+#pragma unroll
+            for (int r = 0; r < 7; ++r) d4[tid + r * (SHE3_G * 3)] = q[r];
+        } else {
+            for (int i = tid; i < nfl; i += SHE3_G * 3) s_sh[i] = src[i];
+        }
+    }
+    __syncthreads();
+    if (g < kp.P) {
+        const S360View& vw = views[0];
+        const float sc = vw.scale;
+        const float dx = means[3 * g] * sc - vw.campos[0], dy = means[3 * g + 1] * sc - vw.campos[1], dz = means[3 * g + 2] * sc - vw.campos[2];
+        const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+        float Y[25];
+        sh_basis(4, dx * inv, dy * inv, dz * inv, Y);
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 25; ++k) acc += Y[k] * s_sh[tid * 25 + k];
+        s_rgb[tid] = acc + 0.5f;
+    }
+    __syncthreads();
+    if (tid < SHE3_G && g0 + tid < kp.P) {
+        const float a0 = s_rgb[3 * tid], a1 = s_rgb[3 * tid + 1], a2 = s_rgb[3 * tid + 2];
+        const uint32_t clampbits = (a0 < 0.f ? 1u : 0u) | (a1 < 0.f ? 2u : 0u) | (a2 < 0.f ? 4u : 0u);
+        rgbc[g0 + tid] = make_float4(fmaxf(a0, 0.f), fmaxf(a1, 0.f), fmaxf(a2, 0.f), __uint_as_float(clampbits));
+    }
+}
+
+// Training form of the kernel above (colours + J = d rgb / d mean).  With one lane per (Gaussian, channel) every lane would
+// evaluate all 75 basis derivatives (700 VALU instructions per lane).  Here WAVE d of the workgroup owns derivative component d (x, y, z) and colour channel
+// d of the 64 Gaussians: a lane evaluates the basis, ONE component of its gradient (the zero entries skipped), its
+// channel's colour sum (same sequential sum: bit-identical colours) and G[ch][d] = sum_k dY_k/dd sh[ch][k] for the three
+// channels, reading the 75 coefficients from the staged slab (lane stride 75 words: conflict-free).  The nine sums meet in
+// LDS; thread t then writes floats [3 t, 3 t + 3) of sh_jac (row t % 3 of Gaussian t / 3).
+// In a training loop this kernel measures ~100 us although it runs 72 us on its own (first step of a run): it follows the
+// previous step's k_sh_bwd, whose 315 MB of dL/dSH are still being written back from the L2 / Infinity Cache while it reads
+// (ablations: without the jacobian stores 96 us, without the gradient evaluation 99 us — neither is the cost).
+constexpr uint32_t SHG_NZ_X = 0x1E7FFD8u, SHG_NZ_Y = 0x1CFFF72u, SHG_NZ_Z = 0x0FE7CE4u;  // non-zero entries of sh_basis_grad's dx / dy / dz at degree 4
+template <int D>
+__device__ __forceinline__ void sh_jac_component(float x, float y, float z, const float* __restrict__ slab, float* G) {
+    float b0[25], b1[25], b2[25];
+    sh_basis_grad(4, x, y, z, b0, b1, b2);
+    const float* b = D == 0 ? b0 : (D == 1 ? b1 : b2);
+    constexpr uint32_t NZ = D == 0 ? SHG_NZ_X : (D == 1 ? SHG_NZ_Y : SHG_NZ_Z);
+    G[0] = G[1] = G[2] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 25; ++k) {
+        if (!((NZ >> k) & 1u)) continue;  // fma(0, c, G) == G
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) G[ch] = __builtin_fmaf(b[k], slab[25 * ch + k], G[ch]);
+    }
+}
+
+__global__ __launch_bounds__(SHE3_G * 3) void k_sh_eval3_jac(KParams kp, const S360View* __restrict__ views, const float* __restrict__ means,
+                                                            const float* __restrict__ shs, float4* __restrict__ rgbc,
+                                                            float* __restrict__ sh_jac) {
+    __shared__ float s_rgb[SHE3_G * 3];
+    __shared__ float s_G[9 * SHE3_G];   // [ch][d][Gaussian]
+    __shared__ float4 s_dir[SHE3_G];    // (x, y, z, scale / |d|)
+    __shared__ __attribute__((aligned(16))) float s_sh[7 * SHE3_G * 3 * 4];
+    const int tid = threadIdx.x;
+    const int g0 = blockIdx.x * SHE3_G;
+    {
+        const float* src = shs + (size_t)g0 * 75;
+        const int nfl = min(SHE3_G, kp.P - g0) * 75;
+        if ((((uintptr_t)src) & 15) == 0 && nfl == SHE3_G * 75) {
+            const float4* s4 = reinterpret_cast<const float4*>(src);
+            float4* d4 = reinterpret_cast<float4*>(s_sh);
+            float4 q[7];
+#pragma unroll
+            for (int r = 0; r < 7; ++r) q[r] = s4[min(tid + r * (SHE3_G * 3), SHE3_G * 75 / 4 - 1)];
+#pragma unroll
+            for (int r = 0; r < 7; ++r) d4[tid + r * (SHE3_G * 3)] = q[r];
+        } else {
+            for (int i = tid; i < nfl; i += SHE3_G * 3) s_sh[i] = src[i];
+        }
+    }
+    const int d = tid >> 6, l = tid & 63;  // wave d: derivative component / colour channel d
+    const int g = g0 + l;
+    const S360View& vw = views[0];
+    const float sc = vw.scale;
+    float x = 0.f, y = 0.f, z = 1.f, inv = 0.f;
+    if (g < kp.P) {
+        const float dx = means[3 * g] * sc - vw.campos[0], dy = means[3 * g + 1] * sc - vw.campos[1], dz = means[3 * g + 2] * sc - vw.campos[2];
+        inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+        x = dx * inv; y = dy * inv; z = dz * inv;
+    }
+    __syncthreads();
+    if (g < kp.P) {
+        const float* slab = s_sh + l * 75;
+        float Y[25];
+        sh_basis(4, x, y, z, Y);
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 25; ++k) acc += Y[k] * slab[25 * d + k];
+        s_rgb[3 * l + d] = acc + 0.5f;
+        float G[3];
+        if (d == 0) sh_jac_component<0>(x, y, z, slab, G);
+        else if (d == 1) sh_jac_component<1>(x, y, z, slab, G);
+        else sh_jac_component<2>(x, y, z, slab, G);
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) s_G[(3 * ch + d) * SHE3_G + l] = G[ch];
+        if (d == 0) s_dir[l] = make_float4(x, y, z, sc * inv);
+    }
+    __syncthreads();
+    {
+        const int gl = tid / 3, ch = tid - 3 * gl;
+        if (g0 + gl < kp.P) {
+            const float G0 = s_G[(3 * ch) * SHE3_G + gl], G1 = s_G[(3 * ch + 1) * SHE3_G + gl], G2 = s_G[(3 * ch + 2) * SHE3_G + gl];
+            const float4 dr = s_dir[gl];
+            const float dot = dr.x * G0 + dr.y * G1 + dr.z * G2;
+            float* o = sh_jac + 3 * ((size_t)g0 * 3 + tid);
+            o[0] = (G0 - dr.x * dot) * dr.w;
+            o[1] = (G1 - dr.y * dot) * dr.w;
+            o[2] = (G2 - dr.z * dot) * dr.w;
+        }
+    }
+    if (tid < SHE3_G && g0 + tid < kp.P) {
+        const float a0 = s_rgb[3 * tid], a1 = s_rgb[3 * tid + 1], a2 = s_rgb[3 * tid + 2];
+        const uint32_t clampbits = (a0 < 0.f ? 1u : 0u) | (a1 < 0.f ? 2u : 0u) | (a2 < 0.f ? 4u : 0u);
+        rgbc[g0 + tid] = make_float4(fmaxf(a0, 0.f), fmaxf(a1, 0.f), fmaxf(a2, 0.f), __uint_as_float(clampbits));
+    }
+}
+
 // ------------------------------------------------------------------------------ preprocess
 template <bool USE_SH, bool CH_MAJOR, bool EAGER = false>  // EAGER: colours come from k_sh_eval (rgbc), no slab code here
 __global__ __launch_bounds__(S360_BLOCK) void k_preprocess(
@@ -809,25 +959,30 @@ struct MseEp {
 
 // Final reduction of the loss epilogue in one launch (torch needs four: two reductions and two scalings).  One workgroup;
 // fixed assignment of partials to threads, fixed shuffle tree, fixed wave order: deterministic.
-__global__ __launch_bounds__(S360_BLOCK) void k_mse_finish(const float* __restrict__ partials, int n_per_view, int V, float loss_scale,
-                                                          float inv_elems, float* __restrict__ out) {
-    constexpr int VG = 8;  // views per sweep
-    __shared__ float s_w[S360_BLOCK / 64][VG][2];
+constexpr int MSE_BLOCK = 1024;
+__global__ __launch_bounds__(MSE_BLOCK) void k_mse_finish(const float* __restrict__ partials, int n_per_view, int V, float loss_scale,
+                                                         float inv_elems, float* __restrict__ out) {
+    constexpr int VG = 8;  // views per sweep: their loads are independent, one round trip per 1024 partials of each
+    __shared__ float s_w[MSE_BLOCK / 64][VG][2];
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     float total = 0.f;
     for (int v0 = 0; v0 < V; v0 += VG) {
         float a[VG], b[VG];
 #pragma unroll
-        for (int j = 0; j < VG; ++j) {
-            a[j] = b[j] = 0.f;
-            if (v0 + j < V) {
-                const float2* p = reinterpret_cast<const float2*>(partials) + (size_t)(v0 + j) * n_per_view;
-                for (int i = threadIdx.x; i < n_per_view; i += S360_BLOCK) {
-                    const float2 q = p[i];
-                    a[j] += q.x;
-                    b[j] += q.y;
-                }
+        for (int j = 0; j < VG; ++j) a[j] = b[j] = 0.f;
+        for (int i = threadIdx.x; i < n_per_view; i += MSE_BLOCK) {
+            float2 q[VG];
+#pragma unroll
+            for (int j = 0; j < VG; ++j)
+                q[j] = v0 + j < V ? reinterpret_cast<const float2*>(partials)[(size_t)(v0 + j) * n_per_view + i] : make_float2(0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < VG; ++j) {
+                a[j] += q[j].x;
+                b[j] += q[j].y;
             }
+        }
+#pragma unroll
+        for (int j = 0; j < VG; ++j) {
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
                 a[j] += __shfl_xor(a[j], o);
@@ -842,7 +997,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_mse_finish(const float* __restri
         if (threadIdx.x == 0) {
             for (int j = 0; j < VG && v0 + j < V; ++j) {
                 float sa = 0.f, sb = 0.f;
-                for (int w = 0; w < S360_BLOCK / 64; ++w) {
+                for (int w = 0; w < MSE_BLOCK / 64; ++w) {
                     sa += s_w[w][j][0];
                     sb += s_w[w][j][1];
                 }
@@ -1208,7 +1363,11 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
             const bool jac = !(kp.flags & S360_FLAG_FORWARD_ONLY);
             const bool chm = (kp.flags & S360_FLAG_SH_CHANNEL_MAJOR) != 0;
 #define S360_SHE(A, B) hipLaunchKernelGGL((k_sh_eval<A, B>), dim3(nblk), dim3(S360_BLOCK), 0, st, kp, views, means3D, shs, rgbc, sh_jac)
-            if (chm && jac) S360_SHE(true, true); else if (chm) S360_SHE(true, false); else if (jac) S360_SHE(false, true); else S360_SHE(false, false);
+            if (chm && kp.M == 25 && kp.deg == 4) {  // the reference's harmonics: one lane per (Gaussian, channel)
+                const int nb3 = (kp.P + SHE3_G - 1) / SHE3_G;
+                if (jac) hipLaunchKernelGGL(k_sh_eval3_jac, dim3(nb3), dim3(SHE3_G * 3), 0, st, kp, views, means3D, shs, rgbc, sh_jac);
+                else hipLaunchKernelGGL(k_sh_eval3, dim3(nb3), dim3(SHE3_G * 3), 0, st, kp, views, means3D, shs, rgbc);
+            } else if (chm && jac) S360_SHE(true, true); else if (chm) S360_SHE(true, false); else if (jac) S360_SHE(false, true); else S360_SHE(false, false);
 #undef S360_SHE
         }
         if (shs) {
@@ -1292,7 +1451,7 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
                                list, recA, recB, recC, images, final_T, n_contrib, tile_max_contrib, strip_last, dbg,
                                depths, depth_maps, depth_mode, ep, kp.P > 0 ? tile_order : (const uint32_t*)nullptr);
         if (ep.target && ep.loss_out)
-            hipLaunchKernelGGL(k_mse_finish, dim3(1), dim3(S360_BLOCK), 0, st, ep.partials, kp.T * 4, kp.V, 0.5f * ep.grad_scale,
+            hipLaunchKernelGGL(k_mse_finish, dim3(1), dim3(MSE_BLOCK), 0, st, ep.partials, kp.T * 4, kp.V, 0.5f * ep.grad_scale,
                                1.0f / (3.0f * (float)kp.H * (float)kp.W), ep.loss_out);
     }
     S360_CHECK_LAUNCH();
