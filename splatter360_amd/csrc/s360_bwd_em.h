@@ -31,6 +31,9 @@ namespace s360 {
 
 constexpr int EM_QCAP = 128;  // survivor queue slots per wave (<= 63 left over + 64 appended)
 
+typedef float f2 __attribute__((ext_vector_type(2)));  // a register pair: operand of v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
 #define S360_SCAN4_STEP(op, ctrl)                                                                      \
     op " %0, %0, %0 " ctrl "\n" op " %1, %1, %1 " ctrl "\n" op " %2, %2, %2 " ctrl "\n" op " %3, %3, %3 " ctrl "\n"
 // Four independent inclusive wave64 scans (lane j <- op over lanes 0..j), interleaved so that the three other chains
@@ -101,8 +104,12 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
     uint8_t* __restrict__ valid, const uint32_t* __restrict__ order, int depth_mode) {
     static_assert(SUB_W == 8, "entry-major backward assumes 8x8 quadrants");
     __shared__ float4 s_q[EM_QCAP * 3];
-    __shared__ float4 s_pa[64];  // dL/dpixel (r, g, b, depth)
-    __shared__ float4 s_pb[64];  // T_run, R_run (behind the entries processed so far), T_final * (bg . dL/dpixel), n_contrib bits
+    // per-pixel tables, one array per quantity (pixel-contiguous: a 16-byte read hands a four-pixel run to the lanes as two
+    // register PAIRS — the operands of the packed v_pk_* arithmetic below)
+    __shared__ __attribute__((aligned(16))) float s_gr[64], s_gg[64], s_gb[64], s_gd[64];  // dL/dpixel (r, g, b, depth)
+    __shared__ __attribute__((aligned(16))) float s_T[64], s_R[64];  // T_run, R_run behind the entries processed so far
+    __shared__ __attribute__((aligned(16))) float s_B[64];           // T_final * (bg . dL/dpixel)
+    __shared__ __attribute__((aligned(16))) uint32_t s_last[64];     // n_contrib
 
     const uint32_t unit = order ? order[blockIdx.x] : blockIdx.x;  // tile*4 + quadrant
     const int t = (int)(unit >> 2), wave = (int)(unit & 3u), lane = threadIdx.x;
@@ -132,15 +139,16 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
             pb.x = T_final;
             pb.z = T_final * (vw.bg[0] * pa.x + vw.bg[1] * pa.y + vw.bg[2] * pa.z);
         }
-        pb.w = __uint_as_float(last);
-        s_pa[lane] = pa;
-        s_pb[lane] = pb;
+        s_gr[lane] = pa.x; s_gg[lane] = pa.y; s_gb[lane] = pa.z;
+        if (WITH_DEPTH) s_gd[lane] = pa.w;
+        s_T[lane] = pb.x; s_R[lane] = 0.f; s_B[lane] = pb.z;
+        s_last[lane] = last;
     }
     const uint32_t wave_last = wave_max_u32(last);  // entries [0, wave_last) can matter to this quadrant
     if (wave_last == 0) return;
-    float pxc[8];
+    f2 pxc[4];  // pixel-centre x of the row's four pixel pairs
 #pragma unroll
-    for (int c = 0; c < 8; ++c) pxc[c] = (float)(qx + c);
+    for (int c = 0; c < 4; ++c) pxc[c] = f2{(float)(qx + 2 * c), (float)(qx + 2 * c + 1)};
     const float inv_scale = WITH_DEPTH ? 1.0f / vw.scale : 0.f;
     const float v_near = WITH_DEPTH ? vw.near_plane : 0.f, v_far = WITH_DEPTH ? vw.far_plane : 0.f;
 
@@ -152,22 +160,31 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
         const float ex = qa.x, ey = qa.y, cA = qa.z, cB = qa.w, cC = qb.x, op = qb.y, c0 = qb.z, c1 = qb.w, c2 = qc.x,
                     zv = qc.y;
         const uint32_t pos = lane_ok ? __float_as_uint(qc.z) : 0xFFFFFFFFu;  // list position; idle lanes never contribute
-        const uint32_t inst = __float_as_uint(qc.w);
+        // the entry's instance slot (where its partial record goes) is only needed at the very end: its two gathers — the
+        // pair's first slot and the splat radius for the tile rectangle — fly during the pixel loop, and only SURVIVORS pay
+        // for them (as part of the walk, slot_base[pair] was a 4-byte gather per list entry: one 64-byte sector each)
+        const uint32_t pair = __float_as_uint(qc.w);
+        uint32_t sbase = 0;
+        int erad = 0;
+        if (lane_ok) {
+            sbase = slot_base[pair];
+            erad = __float_as_int(reinterpret_cast<const float*>(recA + 3 * (size_t)pair + 2)[1]);
+        }
         // positions descend with the lane: the group's frontmost entry sits in lane n - 1
         const uint32_t pos_min = (uint32_t)__builtin_amdgcn_readlane((int)pos, (int)n - 1);
-        float g_op = 0.f, X = 0.f, Y = 0.f, XX = 0.f, XY = 0.f, YY = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f, g_z = 0.f;
+        // every per-entry sum is kept as a PAIR (even / odd pixels of the runs), added up once at the end
+        f2 g_op = f2{0.f, 0.f}, X = g_op, Y = g_op, XX = g_op, XY = g_op, YY = g_op, g_r = g_op, g_g = g_op, g_b = g_op, g_z = g_op;
         bool anyc = false;
         // which of the 16 four-pixel runs can still receive anything from this group (some pixel's last contributor lies at
         // or in front of the group's frontmost entry): one LDS pass up front, so that the loop below branches on a scalar bit
         // instead of waiting for the pixel table before it can decide
         uint32_t qmask;
         {
-            const int ql = lane & 15;
-            const int qp = (ql >> 1) * 8 + (ql & 1) * 4;
-            const uint32_t lm = max(max(__float_as_uint(s_pb[qp].w), __float_as_uint(s_pb[qp + 1].w)),
-                                    max(__float_as_uint(s_pb[qp + 2].w), __float_as_uint(s_pb[qp + 3].w)));
-            qmask = (uint32_t)__ballot(lm > pos_min) & 0xFFFFu;
+            const uint4 l4 = *reinterpret_cast<const uint4*>(&s_last[(lane & 15) * 4]);
+            qmask = (uint32_t)__ballot(max(max(l4.x, l4.y), max(l4.z, l4.w)) > pos_min) & 0xFFFFu;
         }
+        const f2 ex2 = f2{ex, ex}, cA2 = f2{cA, cA}, cB2 = f2{cB, cB}, op2 = f2{op, op}, c02 = f2{c0, c0}, c12 = f2{c1, c1},
+                 c22 = f2{c2, c2}, zv2 = f2{zv, zv}, one2 = f2{1.0f, 1.0f};
 #pragma unroll 1
         for (int row = 0; row < 8; ++row) {
             const float pyf = (float)(qy + row);
@@ -175,88 +192,109 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
             const float cdy = cC * dy;
             const float cdy2 = cdy * dy;  // shared by the row's pixels: power2() = fma(fma(b,dy,a*dx), dx, (c*dy)*dy)
             const float cdy_2 = 2.0f * cdy;
+            const f2 dy2 = f2{dy, dy}, cdy2_2 = f2{cdy2, cdy2}, cdy_22 = f2{cdy_2, cdy_2};
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int p0 = row * 8 + half * 4;
                 if (!((qmask >> (row * 2 + half)) & 1u)) continue;  // none of the four pixels reaches back to this group
-                float4 pa[4], pb[4];
+                const float4 vr = *reinterpret_cast<const float4*>(&s_gr[p0]), vg = *reinterpret_cast<const float4*>(&s_gg[p0]),
+                             vb = *reinterpret_cast<const float4*>(&s_gb[p0]), vT = *reinterpret_cast<const float4*>(&s_T[p0]),
+                             vR = *reinterpret_cast<const float4*>(&s_R[p0]), vB = *reinterpret_cast<const float4*>(&s_B[p0]);
+                const uint4 vL = *reinterpret_cast<const uint4*>(&s_last[p0]);
+                float4 vd = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (WITH_DEPTH) vd = *reinterpret_cast<const float4*>(&s_gd[p0]);
+                const f2 gr[2] = {f2{vr.x, vr.y}, f2{vr.z, vr.w}}, gg[2] = {f2{vg.x, vg.y}, f2{vg.z, vg.w}},
+                         gb[2] = {f2{vb.x, vb.y}, f2{vb.z, vb.w}}, gd[2] = {f2{vd.x, vd.y}, f2{vd.z, vd.w}},
+                         Tr[2] = {f2{vT.x, vT.y}, f2{vT.z, vT.w}}, Rr[2] = {f2{vR.x, vR.y}, f2{vR.z, vR.w}},
+                         Bg[2] = {f2{vB.x, vB.y}, f2{vB.z, vB.w}};
+                const uint32_t lastk[4] = {vL.x, vL.y, vL.z, vL.w};
+                f2 dx[2], pxd[2], Gm[2], a2[2];
+                float a[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    pa[k] = s_pa[p0 + k];
-                    pb[k] = s_pb[p0 + k];
-                }
-                float dx[4], a[4], Gm[4], om[4], Qx[4], px_[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    dx[k] = ex - pxc[half * 4 + k];
-                    const float adx = cA * dx[k];
-                    const float tq = __builtin_fmaf(cB, dy, adx);
-                    px_[k] = tq + adx;  // d(power)/d(dx) = 2 a' dx + b' dy
-                    const float pw = __builtin_fmaf(tq, dx[k], cdy2);
-                    const float G = __builtin_amdgcn_exp2f(pw);
-                    const float al = fminf(0.99f, op * G);
-                    const bool act = pos < __float_as_uint(pb[k].w) && !(pw > 0.0f) && !(al < 1.0f / 255.0f);
-                    anyc = anyc || act;
-                    a[k] = act ? al : 0.0f;
-                    Gm[k] = act ? G : 0.0f;
-                    om[k] = 1.0f - a[k];
+                for (int j = 0; j < 2; ++j) {
+                    dx[j] = ex2 - pxc[half * 2 + j];
+                    const f2 adx = cA2 * dx[j];
+                    const f2 tq = pk_fma(cB2, dy2, adx);
+                    pxd[j] = tq + adx;  // d(power)/d(dx) = 2 a' dx + b' dy
+                    const f2 pw = pk_fma(tq, dx[j], cdy2_2);
+                    const f2 G = f2{__builtin_amdgcn_exp2f(pw.x), __builtin_amdgcn_exp2f(pw.y)};
+                    const f2 og = op2 * G;
+                    const float al0 = fminf(0.99f, og.x), al1 = fminf(0.99f, og.y);
+                    const bool act0 = pos < lastk[2 * j] && !(pw.x > 0.0f) && !(al0 < 1.0f / 255.0f);
+                    const bool act1 = pos < lastk[2 * j + 1] && !(pw.y > 0.0f) && !(al1 < 1.0f / 255.0f);
+                    anyc = anyc || act0 || act1;
+                    a[2 * j] = act0 ? al0 : 0.0f;
+                    a[2 * j + 1] = act1 ? al1 : 0.0f;
+                    Gm[j] = f2{act0 ? G.x : 0.0f, act1 ? G.y : 0.0f};
+                    a2[j] = f2{a[2 * j], a[2 * j + 1]};
                 }
                 // Qx_j = prod of (1 - alpha) over the entries strictly BEHIND j (lanes below j), Q_j includes j
+                float Qx[4];
                 wave_one_minus_shr1x4(a[0], a[1], a[2], a[3], Qx[0], Qx[1], Qx[2], Qx[3]);
                 wave_scan4_mul(Qx[0], Qx[1], Qx[2], Qx[3]);
-                float rc[4], Tj[4], cdp[4], w[4], S[4];
+                f2 Tj[2], rc[2], cdp[2], w[2];
+                float S[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float Q = Qx[k] * om[k];
-                    float r = __builtin_amdgcn_rcpf(Q);
-                    r = __builtin_fmaf(__builtin_fmaf(-Q, r, 1.0f), r, r);  // Newton step: dL/dalpha below is a difference of two
-                                                                             // nearly equal terms whenever an entry's colour is close to
-                                                                             // the colour behind it; without it the fuzz suite measures
-                                                                             // 2.7x the float32 oracle's distance from the float64 one
-                    Tj[k] = pb[k].x * r;   // transmittance in front of entry j = T behind the group / Q_j
-                    rc[k] = Qx[k] * r;     // 1 / (1 - alpha_j)
-                    float d = __builtin_fmaf(c2, pa[k].z, __builtin_fmaf(c1, pa[k].y, c0 * pa[k].x));
-                    if (WITH_DEPTH) d = __builtin_fmaf(zv, pa[k].w, d);
-                    cdp[k] = d;
-                    w[k] = a[k] * Tj[k];
-                    S[k] = w[k] * d;
+                for (int j = 0; j < 2; ++j) {
+                    const f2 Qx2 = f2{Qx[2 * j], Qx[2 * j + 1]};
+                    const f2 Q = Qx2 * (one2 - a2[j]);
+                    f2 r = f2{__builtin_amdgcn_rcpf(Q.x), __builtin_amdgcn_rcpf(Q.y)};
+                    r = pk_fma(pk_fma(-Q, r, one2), r, r);  // Newton step: dL/dalpha below is a difference of two nearly equal
+                                                            // terms whenever an entry's colour is close to the colour behind
+                                                            // it; without it the fuzz suite measures 2.7x the float32 oracle's
+                                                            // distance from the float64 one
+                    Tj[j] = Tr[j] * r;   // transmittance in front of entry j = T behind the group / Q_j
+                    rc[j] = Qx2 * r;     // 1 / (1 - alpha_j)
+                    f2 d = pk_fma(c22, gb[j], pk_fma(c12, gg[j], c02 * gr[j]));
+                    if (WITH_DEPTH) d = pk_fma(zv2, gd[j], d);
+                    cdp[j] = d;
+                    w[j] = a2[j] * Tj[j];
+                    const f2 s2 = w[j] * d;
+                    S[2 * j] = s2.x;
+                    S[2 * j + 1] = s2.y;
                 }
                 wave_scan4_add(S[0], S[1], S[2], S[3]);  // sum over the entries at or behind j of alpha_i T_i (c_i . dL/dpixel)
                 float Sx[4] = {S[0], S[1], S[2], S[3]};
                 wave_shr1x4_zero(Sx[0], Sx[1], Sx[2], Sx[3]);  // ... strictly behind j
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float Rj = pb[k].y + Sx[k];  // colour (. dL/dpixel) behind entry j
-                    const float dLda = __builtin_fmaf(Tj[k], cdp[k], -((Rj + pb[k].z) * rc[k]));
-                    g_op = __builtin_fmaf(Gm[k], dLda, g_op);
-                    const float h = (op * dLda) * Gm[k];  // dL/dG * G
-                    const float hx = h * dx[k], hy = h * dy;
+                for (int j = 0; j < 2; ++j) {
+                    const f2 Rj = Rr[j] + f2{Sx[2 * j], Sx[2 * j + 1]};  // colour (. dL/dpixel) behind entry j
+                    const f2 dLda = pk_fma(Tj[j], cdp[j], -((Rj + Bg[j]) * rc[j]));
+                    g_op = pk_fma(Gm[j], dLda, g_op);
+                    const f2 h = (op2 * dLda) * Gm[j];  // dL/dG * G
+                    const f2 hx = h * dx[j], hy = h * dy2;
                     // centre gradient per pixel (NOT 2 a' sum(h dx) + b' sum(h dy) afterwards: for an elongated splat the two
                     // sums cancel along the ridge and their rounding errors do not — 8x the float32 oracle's error on
                     // the fuzz suite's most anisotropic splat)
-                    X = __builtin_fmaf(h, px_[k], X);
-                    Y = __builtin_fmaf(h, __builtin_fmaf(cB, dx[k], cdy_2), Y);
-                    XX = __builtin_fmaf(hx, dx[k], XX);
-                    XY = __builtin_fmaf(hx, dy, XY);
-                    YY = __builtin_fmaf(hy, dy, YY);
-                    g_r = __builtin_fmaf(w[k], pa[k].x, g_r);
-                    g_g = __builtin_fmaf(w[k], pa[k].y, g_g);
-                    g_b = __builtin_fmaf(w[k], pa[k].z, g_b);
-                    if (WITH_DEPTH) g_z = __builtin_fmaf(w[k], pa[k].w, g_z);
+                    X = pk_fma(h, pxd[j], X);
+                    Y = pk_fma(h, pk_fma(cB2, dx[j], cdy_22), Y);
+                    XX = pk_fma(hx, dx[j], XX);
+                    XY = pk_fma(hx, dy2, XY);
+                    YY = pk_fma(hy, dy2, YY);
+                    g_r = pk_fma(w[j], gr[j], g_r);
+                    g_g = pk_fma(w[j], gg[j], g_g);
+                    g_b = pk_fma(w[j], gb[j], g_b);
+                    if (WITH_DEPTH) g_z = pk_fma(w[j], gd[j], g_z);
                 }
                 if (lane == 63) {  // lane 63 sees the whole group: the pixels' running state for the next (nearer) group
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) *reinterpret_cast<float2*>(&s_pb[p0 + k]) = make_float2(Tj[k], pb[k].y + S[k]);
+                    *reinterpret_cast<float4*>(&s_T[p0]) = make_float4(Tj[0].x, Tj[0].y, Tj[1].x, Tj[1].y);
+                    *reinterpret_cast<float4*>(&s_R[p0]) = make_float4(vR.x + S[0], vR.y + S[1], vR.z + S[2], vR.w + S[3]);
                 }
             }
+        }
+        uint32_t inst = 0xFFFFFFFFu;
+        if (lane_ok && anyc) {  // position of tile (tx,ty) inside the splat's tile rectangle, in emission order
+            int minx, miny, maxx, maxy;
+            tile_rect(ex, ey, erad, kp.gx, kp.gy, minx, miny, maxx, maxy);
+            inst = sbase + (uint32_t)((ty - miny) * (maxx - minx) + (tx - minx));
         }
         if (lane_ok && anyc && inst < kp.cap) {
             const float ln2 = 0.6931471805599453f;
             // dG/d(centre) = ln2 G (2 a' dx + b' dy) with the pre-scaled conic; dG/d(conic a) = -G dx^2 / 2 ...
             float4* o = part + ((size_t)inst * 4 + wave) * 3;
-            o[0] = make_float4(ln2 * X, ln2 * Y, -0.5f * XX, -XY);
-            o[1] = make_float4(-0.5f * YY, g_op, g_r, g_g);
-            o[2] = make_float4(g_b, g_z, 0.f, 0.f);
+            o[0] = make_float4(ln2 * (X.x + X.y), ln2 * (Y.x + Y.y), -0.5f * (XX.x + XX.y), -(XY.x + XY.y));
+            o[1] = make_float4(-0.5f * (YY.x + YY.y), g_op.x + g_op.y, g_r.x + g_r.y, g_g.x + g_g.y);
+            o[2] = make_float4(g_b.x + g_b.y, g_z.x + g_z.y, 0.f, 0.f);
             valid[(size_t)inst * 4 + wave] = 1;
         }
     };
@@ -264,33 +302,32 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
     // ---- walk the list back to front, 64 entries per chunk (lane l <-> list position hi - l); survivors go to the queue ----
     uint32_t qhead = 0, qcount = 0;
     const int64_t hi0 = (int64_t)wave_last - 1;
+    // software pipeline of the gather chain list -> record: the next chunk's records and the list indices of the one after
+    // are in flight while the current chunk is culled.  (A second chunk of records in flight changed nothing: the walk is
+    // bound by the memory system's throughput on these 48-byte gathers, not by their latency.)
     uint32_t p_n1 = 0, p_n2 = 0;
     if (hi0 - lane >= 0) p_n1 = list[start + (uint32_t)(hi0 - lane)];
     if (hi0 - 64 - lane >= 0) p_n2 = list[start + (uint32_t)(hi0 - 64 - lane)];
     float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na, nc = na;
-    uint32_t nbase = 0;
     float nz = 0.f;
     if (hi0 - lane >= 0) {
         na = recA[3 * (size_t)p_n1];
         nb = recA[3 * (size_t)p_n1 + 1];
         nc = recA[3 * (size_t)p_n1 + 2];
-        nbase = slot_base[p_n1];
         if (WITH_DEPTH) nz = depths[p_n1];
     }
     for (int64_t hi = hi0; hi >= 0; hi -= 64) {
         const float4 ea = na, eb = nb;
         const float ec = nc.x, eka = nc.z, ekb = nc.w;
-        const int erad = __float_as_int(nc.y);
-        const uint32_t ebase = nbase;
         float ez = 0.f;
         if (WITH_DEPTH) ez = depth_value(nz * inv_scale, v_near, v_far, depth_mode);
         const bool ev = hi - lane >= 0;
+        const uint32_t epair = p_n1;
         p_n1 = p_n2;
         if (hi - 64 - lane >= 0) {
             na = recA[3 * (size_t)p_n1];
             nb = recA[3 * (size_t)p_n1 + 1];
             nc = recA[3 * (size_t)p_n1 + 2];
-            nbase = slot_base[p_n1];
             if (WITH_DEPTH) nz = depths[p_n1];
         }
         if (hi - 128 - lane >= 0) p_n2 = list[start + (uint32_t)(hi - 128 - lane)];
@@ -300,14 +337,10 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
         if (m == 0ull) continue;
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
         if (hit) {
-            // slot of this entry: position of tile (tx,ty) inside the splat's tile rectangle, in emission order
-            int minx, miny, maxx, maxy;
-            tile_rect(ea.x, ea.y, erad, kp.gx, kp.gy, minx, miny, maxx, maxy);
-            const uint32_t einst = ebase + (uint32_t)((ty - miny) * (maxx - minx) + (tx - minx));
             const uint32_t idx = (qhead + qcount + rank) & (EM_QCAP - 1);
             s_q[3 * idx] = ea;
             s_q[3 * idx + 1] = eb;
-            s_q[3 * idx + 2] = make_float4(ec, ez, __uint_as_float((uint32_t)(hi - lane)), __uint_as_float(einst));
+            s_q[3 * idx + 2] = make_float4(ec, ez, __uint_as_float((uint32_t)(hi - lane)), __uint_as_float(epair));
         }
         qcount += (uint32_t)__popcll(m);
         while (qcount >= 64) {
@@ -321,8 +354,8 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
 #endif  // S360_EM_KERNEL_TU
 
 // Launcher (this kernel lives in its own translation unit, s360_backward_em.hip, which is compiled with
-// -fno-slp-vectorize: the SLP vectoriser packs pairs of the four pixel chains into v_pk_* instructions but pays for it
-// with 23 register moves per half row and 14 more VGPRs — 138 instead of 125, i.e. 3 instead of 4 waves per SIMD).
+// -fno-slp-vectorize: the pixel pairs are packed by hand above — pixel-contiguous LDS tables, pair accumulators — which
+// costs no register moves; the SLP vectoriser's own pairing of the scalar formulation paid 23 moves per half row).
 void launch_render_bwd_em(bool with_depth, int n_units, hipStream_t st, const KParams& kp, const S360View* views,
                           const uint32_t* tile_start, const uint32_t* list, const uint32_t* slot_base, const float4* recA,
                           const float* depths, const float* final_T, const uint32_t* n_contrib, const float* dL_dimages,
