@@ -569,7 +569,12 @@ static int backward_impl(const S360Params* prm, const S360View* views, const flo
                        valid_words, header, kp.cap);
     const uint32_t* ord = use_order ? order : (const uint32_t*)nullptr;
     launch_render_bwd_em(with_depth, nt * 4, st, kp, views, tile_start, list, slot_base, recA, depths, final_T, n_contrib,
-                         dL_dimages, dL_dimages_scale, dL_ddepth, part, (uint8_t*)valid_words, ord, depth_mode);
+                         dL_dimages, dL_dimages_scale, dL_ddepth, part, (uint8_t*)valid_words, ord, depth_mode,
+#ifdef S360_DBG_TIMING
+                         (uint32_t*)(ws + L.keys_alt));  // the forward's merge buffer is free by now
+#else
+                         (uint32_t*)nullptr);
+#endif
     }
     S360_CHECK_LAUNCH();
     ProfScope ps(PS_PREPROCESS_BWD, st);

@@ -101,7 +101,10 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
     const float* __restrict__ depths, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dimages, const float* __restrict__ dL_dimages_scale, const float* __restrict__ dL_ddepth,
     float4* __restrict__ part,
-    uint8_t* __restrict__ valid, const uint32_t* __restrict__ order, int depth_mode) {
+    uint8_t* __restrict__ valid, const uint32_t* __restrict__ order, int depth_mode, uint32_t* __restrict__ dbg) {
+#ifdef S360_DBG_TIMING
+    const long long t_begin = wall_clock64();
+#endif
     static_assert(SUB_W == 8, "entry-major backward assumes 8x8 quadrants");
     __shared__ float4 s_q[EM_QCAP * 3];
     // per-pixel tables, one array per quantity (pixel-contiguous: a 16-byte read hands a four-pixel run to the lanes as two
@@ -152,6 +155,9 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
     const float inv_scale = WITH_DEPTH ? 1.0f / vw.scale : 0.f;
     const float v_near = WITH_DEPTH ? vw.near_plane : 0.f, v_far = WITH_DEPTH ? vw.far_plane : 0.f;
 
+#ifdef S360_DBG_TIMING
+    uint32_t dbg_halves = 0, dbg_surv = 0;
+#endif
     // ---- one group: up to 64 queued survivors in the lanes (descending list position), loop over the 64 pixels ----
     auto process_group = [&](uint32_t head, uint32_t n) __attribute__((always_inline)) {
         const uint32_t idx = (head + (uint32_t)lane) & (EM_QCAP - 1);
@@ -197,6 +203,9 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
             for (int half = 0; half < 2; ++half) {
                 const int p0 = row * 8 + half * 4;
                 if (!((qmask >> (row * 2 + half)) & 1u)) continue;  // none of the four pixels reaches back to this group
+#ifdef S360_DBG_TIMING
+                ++dbg_halves;
+#endif
                 const float4 vr = *reinterpret_cast<const float4*>(&s_gr[p0]), vg = *reinterpret_cast<const float4*>(&s_gg[p0]),
                              vb = *reinterpret_cast<const float4*>(&s_gb[p0]), vT = *reinterpret_cast<const float4*>(&s_T[p0]),
                              vR = *reinterpret_cast<const float4*>(&s_R[p0]), vB = *reinterpret_cast<const float4*>(&s_B[p0]);
@@ -343,6 +352,9 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
             s_q[3 * idx + 2] = make_float4(ec, ez, __uint_as_float((uint32_t)(hi - lane)), __uint_as_float(epair));
         }
         qcount += (uint32_t)__popcll(m);
+#ifdef S360_DBG_TIMING
+        dbg_surv += (uint32_t)__popcll(m);
+#endif
         while (qcount >= 64) {
             process_group(qhead, 64);
             qhead = (qhead + 64) & (EM_QCAP - 1);
@@ -350,6 +362,14 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
         }
     }
     if (qcount) process_group(qhead, qcount);
+#ifdef S360_DBG_TIMING
+    if (lane == 0 && dbg) {  // per-unit (start, duration) in 100-MHz ticks + walk length (scripts/bwdtiming.py)
+        dbg[4 * unit] = (uint32_t)t_begin;
+        dbg[4 * unit + 1] = (uint32_t)(wall_clock64() - t_begin);
+        dbg[4 * unit + 2] = wave_last;
+        dbg[4 * unit + 3] = (dbg_halves << 16) | min(dbg_surv, 65535u);
+    }
+#endif
 }
 #endif  // S360_EM_KERNEL_TU
 
@@ -359,6 +379,6 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
 void launch_render_bwd_em(bool with_depth, int n_units, hipStream_t st, const KParams& kp, const S360View* views,
                           const uint32_t* tile_start, const uint32_t* list, const uint32_t* slot_base, const float4* recA,
                           const float* depths, const float* final_T, const uint32_t* n_contrib, const float* dL_dimages,
-                          const float* dL_dimages_scale, const float* dL_ddepth, float4* part, uint8_t* valid, const uint32_t* order, int depth_mode);
+                          const float* dL_dimages_scale, const float* dL_ddepth, float4* part, uint8_t* valid, const uint32_t* order, int depth_mode, uint32_t* dbg);
 
 }  // namespace s360
