@@ -100,7 +100,10 @@ def cpu_baseline_torch():
     import numpy as np
     from helpers import boundary_tensors, face_settings
     from oracle import torch_ref
-    cores = os.cpu_count() or 1
+    # 8 threads: these are thousands of small tensor ops — with one thread per core of a 256-core host the intra-op pool's
+    # fork/join cost dominates (measured: 1 137 s with 256 threads against 1.6 s with 8)
+    cores = min(8, os.cpu_count() or 1)
+    prev_threads = torch.get_num_threads()
     torch.set_num_threads(cores)
     cloud = synthetic.uniform_cloud(10_000, seed=0, extent=3.0, scale_range=(0.02, 0.3))
     t0 = time.time()
@@ -112,6 +115,7 @@ def cpu_baseline_torch():
         img = torch_ref.render(S, m, c, o, shs=s_)
         ((img - 0.5) ** 2).mean().backward()
     dt = time.time() - t0
+    torch.set_num_threads(prev_threads)
     return dict(value=10_000 / dt / 1e6, unit="Msplats/s", cores=cores, kind="port",
                 sample=f"BASELINE configs[0]: 10000 Gaussians, 256x128 ERP (6 faces 64x64), fwd+bwd, oracle/torch_ref.py "
                        f"(PyTorch CPU, {cores} threads), {dt:.1f} s")
