@@ -158,6 +158,7 @@ def main():
             out["erp"] = c2e.stitch_rendered(col)
             out["faces"] = col
 
+    one = torch.ones((), device=dev)
     pending = [None]   # the previous micro-batch's gradient exchange, still in flight (N > 1)
 
     def finish_pending():
@@ -182,7 +183,7 @@ def main():
         # stream (gradient accumulation over micro-batches: SURVEY.md 8(e) "overlap with the next view's forward")
         finish_pending()
         if a.mode == "fwdbwd":
-            loss.backward()
+            loss.backward(one)   # the seed autograd would otherwise allocate and fill every step
             if factored:   # all-reduce 40 B/Gaussian (one packed buffer) + all-gather 16 B/Gaussian/rank, SH gradient rebuilt locally
                 pending[0] = distributed.start_factored_exchange(*params, rasterizer.deferred_of(faces))
                 if not a.overlap_exchange:

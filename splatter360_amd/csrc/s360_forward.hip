@@ -36,8 +36,10 @@ namespace s360 {
 template <bool CH_MAJOR, bool JAC>
 __global__ __launch_bounds__(S360_BLOCK) void k_sh_eval(KParams kp, const S360View* __restrict__ views,
                                                        const float* __restrict__ means, const float* __restrict__ shs,
-                                                       float4* __restrict__ rgbc, float* __restrict__ sh_jac) {
+                                                       float4* __restrict__ rgbc, float* __restrict__ sh_jac,
+                                                       uint32_t* __restrict__ zero_ptr, int zero_words) {
     const int g = blockIdx.x * S360_BLOCK + threadIdx.x;
+    if (g < zero_words) zero_ptr[g] = 0u;  // the call's tile histogram + slot tickets (first kernel of the call: no memset node)
     if (g >= kp.P) return;
     const bool fast = kp.M == 25 && kp.deg == 4;
     const float* sh = shs + (size_t)g * kp.M * 3;
@@ -117,8 +119,10 @@ __global__ __launch_bounds__(S360_BLOCK) void k_sh_eval(KParams kp, const S360Vi
 // lines are evicted from the 32-KB L1 between its successive loads.)
 constexpr int SHE3_G = 64;  // Gaussians per workgroup (192 threads)
 __global__ __launch_bounds__(SHE3_G * 3) void k_sh_eval3(KParams kp, const S360View* __restrict__ views, const float* __restrict__ means,
-                                                        const float* __restrict__ shs, float4* __restrict__ rgbc) {
+                                                        const float* __restrict__ shs, float4* __restrict__ rgbc,
+                                                        uint32_t* __restrict__ zero_ptr, int zero_words) {
     __shared__ float s_rgb[SHE3_G * 3];
+    if ((int)(blockIdx.x * (SHE3_G * 3) + threadIdx.x) < zero_words) zero_ptr[blockIdx.x * (SHE3_G * 3) + threadIdx.x] = 0u;
     __shared__ __attribute__((aligned(16))) float s_sh[7 * SHE3_G * 3 * 4];  // the workgroup's 64 slabs (19 200 contiguous bytes) + pad
     const int tid = threadIdx.x;
     const int gl = tid / 3;
@@ -189,9 +193,10 @@ __device__ __forceinline__ void sh_jac_component(float x, float y, float z, cons
 
 __global__ __launch_bounds__(SHE3_G * 3) void k_sh_eval3_jac(KParams kp, const S360View* __restrict__ views, const float* __restrict__ means,
                                                             const float* __restrict__ shs, float4* __restrict__ rgbc,
-                                                            float* __restrict__ sh_jac) {
+                                                            float* __restrict__ sh_jac, uint32_t* __restrict__ zero_ptr, int zero_words) {
     __shared__ float s_rgb[SHE3_G * 3];
     __shared__ float s_G[9 * SHE3_G];   // [ch][d][Gaussian]
+    if ((int)(blockIdx.x * (SHE3_G * 3) + threadIdx.x) < zero_words) zero_ptr[blockIdx.x * (SHE3_G * 3) + threadIdx.x] = 0u;
     __shared__ float4 s_dir[SHE3_G];    // (x, y, z, scale / |d|)
     __shared__ __attribute__((aligned(16))) float s_sh[7 * SHE3_G * 3 * 4];
     const int tid = threadIdx.x;
@@ -958,7 +963,10 @@ struct MseEp {
 };
 
 // Final reduction of the loss epilogue in one launch (torch needs four: two reductions and two scalings).  One workgroup;
-// fixed assignment of partials to threads, fixed shuffle tree, fixed wave order: deterministic.
+// fixed assignment of partials to threads, fixed shuffle tree, fixed wave order: deterministic.  Its ~9 us are a chain of
+// ~2-us memory round trips after a launch (the partials were just written behind other XCDs' L2s); running the same
+// reduction in the LAST workgroup of k_render instead (write-through partials, one device-scope count per workgroup) measured
+// exactly the same 9 us at the end of k_render — built, parity-green, not kept.
 constexpr int MSE_BLOCK = 1024;
 __global__ __launch_bounds__(MSE_BLOCK) void k_mse_finish(const float* __restrict__ partials, int n_per_view, int V, float loss_scale,
                                                          float inv_elems, float* __restrict__ out) {
@@ -1345,8 +1353,14 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
     uint32_t* tile_max_contrib = (uint32_t*)(ws + L.tile_max_contrib);
     uint32_t* strip_last = (uint32_t*)(ws + L.strip_last);
 
-    // one clear for the tile histogram and the (adjacent) instance-slot ticket
-    if (hipMemsetAsync(tile_count, 0, L.tile_start - L.tile_count, st) != hipSuccess) return S360_E_LAUNCH;
+    // one clear for the tile histogram and the (adjacent) instance-slot tickets: done by the call's first kernel when that is
+    // the SH colour kernel (no memset node: 4 us), else by a memset
+    const bool eager_sh = kp.P > 0 && shs && (kp.flags & S360_FLAG_SHARED_CAMPOS) && (!(kp.flags & S360_FLAG_FORWARD_ONLY) || kp.V >= 2);
+    const size_t zero_words_sz = (L.tile_start - L.tile_count) / 4;
+    const bool fold_clear = eager_sh && zero_words_sz <= (size_t)kp.P;
+    uint32_t* zero_ptr = fold_clear ? tile_count : (uint32_t*)nullptr;
+    const int zero_words = fold_clear ? (int)zero_words_sz : 0;
+    if (!fold_clear && hipMemsetAsync(tile_count, 0, L.tile_start - L.tile_count, st) != hipSuccess) return S360_E_LAUNCH;
     if (kp.P > 0) {
         {
         ProfScope ps(PS_PREPROCESS, st);
@@ -1356,17 +1370,17 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
         // views sharing one camera centre: SH colours once per Gaussian in their own streaming kernel.  Always in training
         // calls (the backward relies on sh_jac); in inference calls only when several views amortise the full-cloud read
         // (a single-face drop-in call sees ~17 % of the cloud and keeps the lazy in-kernel evaluation).
-        const bool eager = shs && (kp.flags & S360_FLAG_SHARED_CAMPOS) && (!(kp.flags & S360_FLAG_FORWARD_ONLY) || kp.V >= 2);
+        const bool eager = eager_sh;
         float4* rgbc = (float4*)(ws + L.rgbc);
         if (eager) {
             float* sh_jac = (float*)(ws + L.sh_jac);
             const bool jac = !(kp.flags & S360_FLAG_FORWARD_ONLY);
             const bool chm = (kp.flags & S360_FLAG_SH_CHANNEL_MAJOR) != 0;
-#define S360_SHE(A, B) hipLaunchKernelGGL((k_sh_eval<A, B>), dim3(nblk), dim3(S360_BLOCK), 0, st, kp, views, means3D, shs, rgbc, sh_jac)
+#define S360_SHE(A, B) hipLaunchKernelGGL((k_sh_eval<A, B>), dim3(nblk), dim3(S360_BLOCK), 0, st, kp, views, means3D, shs, rgbc, sh_jac, zero_ptr, zero_words)
             if (chm && kp.M == 25 && kp.deg == 4) {  // the reference's harmonics: one lane per (Gaussian, channel)
                 const int nb3 = (kp.P + SHE3_G - 1) / SHE3_G;
-                if (jac) hipLaunchKernelGGL(k_sh_eval3_jac, dim3(nb3), dim3(SHE3_G * 3), 0, st, kp, views, means3D, shs, rgbc, sh_jac);
-                else hipLaunchKernelGGL(k_sh_eval3, dim3(nb3), dim3(SHE3_G * 3), 0, st, kp, views, means3D, shs, rgbc);
+                if (jac) hipLaunchKernelGGL(k_sh_eval3_jac, dim3(nb3), dim3(SHE3_G * 3), 0, st, kp, views, means3D, shs, rgbc, sh_jac, zero_ptr, zero_words);
+                else hipLaunchKernelGGL(k_sh_eval3, dim3(nb3), dim3(SHE3_G * 3), 0, st, kp, views, means3D, shs, rgbc, zero_ptr, zero_words);
             } else if (chm && jac) S360_SHE(true, true); else if (chm) S360_SHE(true, false); else if (jac) S360_SHE(false, true); else S360_SHE(false, false);
 #undef S360_SHE
         }
