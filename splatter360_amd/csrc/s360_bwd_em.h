@@ -31,8 +31,6 @@ namespace s360 {
 
 constexpr int EM_QCAP = 128;  // survivor queue slots per wave (<= 63 left over + 64 appended)
 
-typedef float f2 __attribute__((ext_vector_type(2)));  // a register pair: operand of v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32
-__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
 #define S360_SCAN4_STEP(op, ctrl)                                                                      \
     op " %0, %0, %0 " ctrl "\n" op " %1, %1, %1 " ctrl "\n" op " %2, %2, %2 " ctrl "\n" op " %3, %3, %3 " ctrl "\n"

@@ -314,6 +314,9 @@ __device__ __forceinline__ void geo_sph(const float* V, int W, int H, float mx, 
 __device__ __forceinline__ int image_of_view(const KParams& kp, int v) { return (kp.flags & S360_FLAG_SPHERICAL) ? (v >> 1) : v; }
 __device__ __forceinline__ int view_of_image(const KParams& kp, int img) { return (kp.flags & S360_FLAG_SPHERICAL) ? 2 * img : img; }
 
+typedef float f2 __attribute__((ext_vector_type(2)));  // a register pair: operand of v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
 // Composite exponent.  Records hold the conic pre-scaled (a' = -log2(e)/2 * a, b' = -log2(e) * b,
 // c' = -log2(e)/2 * c) so that  log2 G = a' dx^2 + b' dx dy + c' dy^2  is three FMAs + two multiplies
 // and G = v_exp_f32(.) with no extra multiply.  Forward and backward share this function, so both

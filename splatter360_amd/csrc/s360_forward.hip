@@ -1031,7 +1031,13 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
 #ifdef S360_DBG_TIMING
     const long long t_begin = wall_clock64();
 #endif
-    __shared__ float4 s_rec[S360_BLOCK / 64][68][3];  // per wave: the current chunk's culled records (+ padding), read as uniform-address broadcasts
+    // per wave: the current chunk's culled records (+ padding), one array per quantity (entry-contiguous: a uniform-address
+    // 16-byte read hands FOUR entries to every lane as two register pairs — the operands of the packed v_pk_* arithmetic);
+    // the colours are kept as (r, g) and (b, depth value) pairs per entry for the packed accumulation
+    __shared__ __attribute__((aligned(16))) float s_x[S360_BLOCK / 64][68], s_y[S360_BLOCK / 64][68], s_a[S360_BLOCK / 64][68],
+        s_b[S360_BLOCK / 64][68], s_c[S360_BLOCK / 64][68], s_o[S360_BLOCK / 64][68];
+    __shared__ __attribute__((aligned(16))) float2 s_rg[S360_BLOCK / 64][68], s_bz[S360_BLOCK / 64][68];
+    __shared__ __attribute__((aligned(16))) uint32_t s_pos[S360_BLOCK / 64][68];
     // tiles are dealt longest list first (LPT: the sequential per-pixel chains of the long polar lists would
     // otherwise form the tail of the kernel): 249 -> 224 us.  (Single-wave workgroups per (tile, quadrant), as in
     // the backward, bring nothing more here: 229 us.)
@@ -1046,7 +1052,8 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
     const float x0 = (float)(tx * 16 + sub_ox(wave)), ys0 = (float)(ty * 16 + sub_oy(wave));  // footprint origin
 
     const uint32_t start = min(tile_start[t], kp.cap), end = min(tile_start[t + 1], kp.cap);
-    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
+    float T = 1.0f;
+    f2 C01 = f2{0.f, 0.f}, C2D = f2{0.f, 0.f};  // (r, g) and (b, depth) accumulators
     uint32_t last = 0;
     bool done = !inside;
     const int vcam = view_of_image(kp, v);  // v = image index
@@ -1097,61 +1104,79 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
         if (__popcll(act) > SPARSE_PIXELS) {
             // Survivors are COMPACTED into the wave's LDS slice (rank = prefix count of the cull ballot) and padded with
             // null records (opacity 0 => alpha 0 => rejected like any other miss) to a multiple of four, so the loop below is
-            // a plain counted loop over consecutive 48-byte records: no bit scanning on the scalar unit, uniform-address
+            // a plain counted loop over consecutive records: no bit scanning on the scalar unit, uniform-address
             // ds_read_b128 broadcasts instead of 9 v_readlane per entry, and the alpha evaluations of FOUR entries per
-            // iteration are independent instruction chains; the T / colour updates stay strictly sequential.
+            // iteration are two packed (v_pk_*) chains over entry pairs; the T / colour updates stay strictly sequential
+            // (colour accumulators as (r, g) / (b, depth) pairs).  Same operations in the same order as the scalar form:
+            // bit-identical images (148 -> 142 us).
             const uint32_t cnt = (uint32_t)__popcll(m);
             {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                 if (hit) {
-                    s_rec[wave][rank][0] = ea;
-                    s_rec[wave][rank][1] = eb;
-                    s_rec[wave][rank][2] = make_float4(ec, ez, __uint_as_float(rel + (uint32_t)lane + 1u), 0.f);
+                    s_x[wave][rank] = ea.x; s_y[wave][rank] = ea.y; s_a[wave][rank] = ea.z; s_b[wave][rank] = ea.w;
+                    s_c[wave][rank] = eb.x; s_o[wave][rank] = eb.y;
+                    s_rg[wave][rank] = make_float2(eb.z, eb.w);
+                    s_bz[wave][rank] = make_float2(ec, ez);
+                    s_pos[wave][rank] = rel + (uint32_t)lane + 1u;
                 }
-                if (lane < 3) {
-                    s_rec[wave][cnt + lane][0] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    s_rec[wave][cnt + lane][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    s_rec[wave][cnt + lane][2] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (lane < 3) {  // null records: opacity 0
+                    s_x[wave][cnt + lane] = 0.f; s_y[wave][cnt + lane] = 0.f; s_a[wave][cnt + lane] = 0.f; s_b[wave][cnt + lane] = 0.f;
+                    s_c[wave][cnt + lane] = 0.f; s_o[wave][cnt + lane] = 0.f;
+                    s_rg[wave][cnt + lane] = make_float2(0.f, 0.f);
+                    s_bz[wave][cnt + lane] = make_float2(0.f, 0.f);
+                    s_pos[wave][cnt + lane] = 0u;
                 }
             }
+            const f2 pxf2 = f2{pxf, pxf}, pyf2 = f2{pyf, pyf};
             for (uint32_t i = 0; i < cnt; i += 4) {
-                const float4* r = &s_rec[wave][i][0];
-                float4 A[4], B[4], K[4];
-                float al[4];
+                const float4 vx = *reinterpret_cast<const float4*>(&s_x[wave][i]), vy = *reinterpret_cast<const float4*>(&s_y[wave][i]),
+                             va = *reinterpret_cast<const float4*>(&s_a[wave][i]), vb = *reinterpret_cast<const float4*>(&s_b[wave][i]),
+                             vc = *reinterpret_cast<const float4*>(&s_c[wave][i]), vo = *reinterpret_cast<const float4*>(&s_o[wave][i]);
+                const float4 rg01 = *reinterpret_cast<const float4*>(&s_rg[wave][i]), rg23 = *reinterpret_cast<const float4*>(&s_rg[wave][i + 2]);
+                const float4 bz01 = *reinterpret_cast<const float4*>(&s_bz[wave][i]), bz23 = *reinterpret_cast<const float4*>(&s_bz[wave][i + 2]);
+                const uint4 vp = *reinterpret_cast<const uint4*>(&s_pos[wave][i]);
+                float al[4], om[4];
                 bool ok[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    A[e] = r[3 * e];
-                    B[e] = r[3 * e + 1];
-                    K[e] = r[3 * e + 2];
-                }
                 bool any_ok = false;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float dx = A[e].x - pxf, dy = A[e].y - pyf;
-                    const float pw = power2(A[e].z, A[e].w, B[e].x, dx, dy);
-                    al[e] = fminf(0.99f, B[e].y * __builtin_amdgcn_exp2f(pw));
-                    ok[e] = !done && !(pw > 0.0f) && !(al[e] < 1.0f / 255.0f);
-                    any_ok = any_ok || ok[e];
+                for (int j = 0; j < 2; ++j) {  // entries 2j, 2j+1 as one register pair
+                    const f2 X = j ? f2{vx.z, vx.w} : f2{vx.x, vx.y}, Y = j ? f2{vy.z, vy.w} : f2{vy.x, vy.y};
+                    const f2 A = j ? f2{va.z, va.w} : f2{va.x, va.y}, B = j ? f2{vb.z, vb.w} : f2{vb.x, vb.y};
+                    const f2 Cc = j ? f2{vc.z, vc.w} : f2{vc.x, vc.y}, O = j ? f2{vo.z, vo.w} : f2{vo.x, vo.y};
+                    const f2 dx = X - pxf2, dy = Y - pyf2;
+                    const f2 t = pk_fma(B, dy, A * dx);            // power2(): fma(fma(b, dy, a dx), dx, (c dy) dy)
+                    const f2 pw = pk_fma(t, dx, (Cc * dy) * dy);
+                    const f2 og = O * f2{__builtin_amdgcn_exp2f(pw.x), __builtin_amdgcn_exp2f(pw.y)};
+                    al[2 * j] = fminf(0.99f, og.x);
+                    al[2 * j + 1] = fminf(0.99f, og.y);
+                    const f2 o2 = f2{1.0f, 1.0f} - f2{al[2 * j], al[2 * j + 1]};
+                    om[2 * j] = o2.x;
+                    om[2 * j + 1] = o2.y;
+                    ok[2 * j] = !done && !(pw.x > 0.0f) && !(al[2 * j] < 1.0f / 255.0f);
+                    ok[2 * j + 1] = !done && !(pw.y > 0.0f) && !(al[2 * j + 1] < 1.0f / 255.0f);
+                    any_ok = any_ok || ok[2 * j] || ok[2 * j + 1];
                 }
 #ifdef S360_DBG_COUNT
                 if (lane == 0) atomicAdd(&dbg[0], min(4u, cnt - i));
 #endif
                 if (__ballot(any_ok) == 0ull) continue;  // wave-uniform
+                const f2 rg[4] = {f2{rg01.x, rg01.y}, f2{rg01.z, rg01.w}, f2{rg23.x, rg23.y}, f2{rg23.z, rg23.w}};
+                const f2 bz[4] = {f2{bz01.x, bz01.y}, f2{bz01.z, bz01.w}, f2{bz23.x, bz23.y}, f2{bz23.z, bz23.w}};
+                const uint32_t posk[4] = {vp.x, vp.y, vp.z, vp.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const bool v = ok[e] && !done;
-                    const float test_T = T * (1.0f - al[e]);
+                    const float test_T = T * om[e];
                     const bool stop = v && test_T < 0.0001f;
                     const bool contrib = v && !stop;
                     done = done || stop;
                     const float w = contrib ? al[e] * T : 0.0f;
-                    C0 += B[e].z * w;
-                    C1 += B[e].w * w;
-                    C2 += K[e].x * w;
-                    if (WITH_DEPTH) D += K[e].y * w;
+                    const f2 w2 = f2{w, w};
+                    C01 = C01 + rg[e] * w2;   // unfused multiply-add, like the scalar form (the oracle's rounding)
+                    if (WITH_DEPTH) C2D = C2D + bz[e] * w2;
+                    else C2D.x = C2D.x + bz[e].x * w;
                     T = contrib ? test_T : T;
-                    last = contrib ? __float_as_uint(K[e].z) : last;
+                    last = contrib ? posk[e] : last;
                 }
             }
         } else {
@@ -1173,10 +1198,10 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
                     const bool stop = mine && test_T < 0.0001f;
                     const bool contrib = mine && !stop;
                     const float w = contrib ? a_s * T : 0.0f;
-                    C0 += rl(eb.z, eb_) * w;
-                    C1 += rl(eb.w, eb_) * w;
-                    C2 += rl(ec, eb_) * w;
-                    if (WITH_DEPTH) D += rl(ez, eb_) * w;
+                    C01.x += rl(eb.z, eb_) * w;
+                    C01.y += rl(eb.w, eb_) * w;
+                    C2D.x += rl(ec, eb_) * w;
+                    if (WITH_DEPTH) C2D.y += rl(ez, eb_) * w;
                     T = contrib ? test_T : T;
                     last = contrib ? rel + (uint32_t)eb_ + 1u : last;
                     done = done || stop;
@@ -1191,7 +1216,7 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
         const size_t hw = (size_t)kp.H * kp.W;
         const size_t pix = (size_t)py * kp.W + px;
         float* img = images + (size_t)v * 3 * hw;
-        const float o0 = C0 + T * vw.bg[0], o1 = C1 + T * vw.bg[1], o2 = C2 + T * vw.bg[2];
+        const float o0 = C01.x + T * vw.bg[0], o1 = C01.y + T * vw.bg[1], o2 = C2D.x + T * vw.bg[2];
         img[pix] = o0;
         img[hw + pix] = o1;
         img[2 * hw + pix] = o2;
@@ -1211,7 +1236,7 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
         }
         final_T[(size_t)v * hw + pix] = T;
         n_contrib[(size_t)v * hw + pix] = last;
-        if (WITH_DEPTH) depth_maps[(size_t)v * hw + pix] = D;  // background depth is 0 (cuda_splatting.py:258)
+        if (WITH_DEPTH) depth_maps[(size_t)v * hw + pix] = C2D.y;  // background depth is 0 (cuda_splatting.py:258)
     }
     if (ep.target) {  // wave-uniform
         const float s0 = wave_sum1_lane63(sq), s1 = wave_sum1_lane63(sqc);
