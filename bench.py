@@ -39,7 +39,7 @@ import torch  # noqa: E402
 from splatter360_amd import _lib, decoder, distributed, rasterizer, stitch, synthetic  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 measured-achievable
-FWD_KERNELS = ("preprocess", "scan", "tile_scan", "emit", "sort_tiles", "render", "cube2erp")
+FWD_KERNELS = ("preprocess", "tile_scan", "emit", "sort_tiles", "render", "cube2erp")
 
 
 def parse():

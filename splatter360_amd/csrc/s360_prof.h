@@ -7,7 +7,6 @@ namespace s360 {
 
 enum ProfSlot {
     PS_PREPROCESS = 0,
-    PS_SCAN,
     PS_TILE_SCAN,
     PS_EMIT,
     PS_SORT,

@@ -182,7 +182,7 @@ void prof_mark(int slot, hipStream_t st, bool end) {
 }
 }  // namespace s360
 
-static const char* kSlotNames[PS_NSLOTS] = {"preprocess", "scan", "tile_scan", "emit", "sort_tiles", "render",
+static const char* kSlotNames[PS_NSLOTS] = {"preprocess", "tile_scan", "emit", "sort_tiles", "render",
                                             "render_bwd", "preprocess_bwd", "cube2erp", "cube2erp_bwd"};
 
 extern "C" int s360_profile_slots(void) { return PS_NSLOTS; }

@@ -79,3 +79,33 @@ def test_header_is_plain_c_and_a_c_program_can_call_the_library(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert f"abi {_lib.ABI_VERSION} " in r.stdout and "bad V -> -1" in r.stdout
+
+
+def test_ctypes_argtypes_match_the_header_prototypes():
+    """Every entry point's ctypes argtypes (splatter360_amd/_lib.py) has as many parameters as its prototype in
+    include/s360.h, pointers where the header has pointers and sizes / integers / floats where it has those: a
+    signature changed on one side only (the ABI moved twice in round 2) fails here, on CPU."""
+    import ctypes as C
+    text = re.sub(r"/\*.*?\*/", " ", (ROOT / "include" / "s360.h").read_text(), flags=re.S)
+    lib = _lib.lib()
+    checked = 0
+    for m in re.finditer(r"\b(?:int|const char\s*\*)\s+(s360_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        name, params = m.group(1), m.group(2).strip()
+        fn = getattr(lib, name)
+        if fn.argtypes is None:
+            continue
+        plist = [] if params in ("", "void") else [p.strip() for p in params.split(",")]
+        assert len(plist) == len(fn.argtypes), f"{name}: header has {len(plist)} parameters, ctypes {len(fn.argtypes)}"
+        for p, a in zip(plist, fn.argtypes):
+            is_ptr_h = "*" in p
+            is_ptr_c = a in (C.c_void_p, C.c_char_p) or hasattr(a, "_type_") and isinstance(a._type_, type) and issubclass(a, C._Pointer)
+            assert is_ptr_h == bool(is_ptr_c), f"{name}: parameter '{p}' vs ctypes {a}"
+            if not is_ptr_h:
+                if "float" in p:
+                    assert a is C.c_float, f"{name}: '{p}' vs {a}"
+                elif "size_t" in p:
+                    assert a in (C.c_size_t, C.c_uint64), f"{name}: '{p}' vs {a}"
+                else:
+                    assert a in (C.c_int, C.c_int32, C.c_uint32), f"{name}: '{p}' vs {a}"
+        checked += 1
+    assert checked >= 12
