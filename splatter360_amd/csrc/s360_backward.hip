@@ -1,7 +1,7 @@
 // s360_backward.hip — backward kernels.  gfx950 / wave64 only.
 //
-//   k_order_units      work units (tile, quadrant) in descending order of their replay length; the same launch
-//                      clears the validity flags of the partial-record slots
+//   k_order_units      launch order of the work units (tile, quadrant): tiles in descending order of their replay length,
+//                      sibling quadrants on the same XCD; the same launch clears the validity flags of the partial-record slots
 //   k_render_bwd_em    (s360_bwd_em.h / s360_backward_em.hip) one autonomous wave per (tile, 8x8 quadrant): entry-major
 //                      back-to-front replay from final_T / n_contrib — 64 culled list entries in the lanes, the
 //                      pixels looped, two DPP scans per pixel; ONE partial record per (instance, quadrant) is written —
@@ -11,7 +11,8 @@
 //   k_preprocess_bwd   1 thread per Gaussian: chains conic -> cov2D -> cov3D / mean, projection -> mean, sums the
 //                      V views in registers; with per-view camera centres also SH -> dL/dSH (slab through LDS)
 //   k_sh_bwd           streaming SH backward for views sharing one camera centre (and for the N gathered
-//                      factors of the multi-GPU exchange): dL/dSH = Y (x) dRGB, view-direction term of dL/dmean
+//                      factors of the multi-GPU exchange): dL/dSH = Y (x) dRGB (the view-direction term of dL/dmean comes
+//                      from the forward's sh_jac inside k_preprocess_bwd)
 // No float atomics anywhere: gradients are bit-reproducible run to run.
 #include "s360_device.h"
 #include "s360_prof.h"

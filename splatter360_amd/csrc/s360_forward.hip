@@ -23,16 +23,15 @@ namespace s360 {
 
 // ------------------------------------------------------------------------------ SH -> RGB (shared camera centre)
 // When all views of a call share one camera centre (the six faces of a panorama) the colour of a Gaussian does not
-// depend on the view: this streaming kernel evaluates it ONCE per Gaussian ahead of the geometry pass — each lane reads
-// its own 300-byte slab one colour channel (25 floats, 16-byte loads) at a time, so nothing but the SH basis is live and
-// the geometry kernel (k_preprocess<.., EAGER = true>) no longer carries the slab code.  Training calls (JAC) also store
+// depend on the view: a streaming kernel evaluates it ONCE per Gaussian ahead of the geometry pass, and the geometry
+// kernel (k_preprocess<.., EAGER = true>) carries no slab code.  Training calls (JAC) also store
 // J_c = d(rgb_c)/d(mean) through the view direction — (G_c - dir (dir . G_c)) * scale / |d| with
 // G_c = sum_k grad Y_k(dir) sh_kc — 36 bytes with which the backward adds that term to dL/dmean and never re-reads the slab.
-// Each lane streams its own slab with 16-byte loads, ALL of them (19 for the reference's 75 coefficients) in flight before
-// the first use: every byte of every cache line is consumed by the same lane within a few instructions, so HBM traffic stays
-// 1x whatever the occupancy (loading one colour channel at a time, the round-1 form, re-fetched every line three times once
-// occupancy let a CU's slabs outgrow its share of the L2: 365 us for the forward's SH + geometry pair instead of 140 us;
-// staging the wave's 19.2 KB through LDS with coalesced loads measured 156 us for this kernel: 8 waves per CU is too few).
+// k_sh_eval is the general form (either layout, any degree): one lane per Gaussian streams its own slab with 16-byte loads,
+// ALL of them (19 for 75 coefficients) in flight before the first use — every byte of every cache line is consumed by the
+// same lane within a few instructions, so HBM traffic stays 1x whatever the occupancy (loading one colour channel at a
+// time, the round-1 form, re-fetched every line three times: 365 us for the forward's SH + geometry pair instead of 140).
+// The reference's own layout (channel-major, degree 4) takes k_sh_eval3 / k_sh_eval3_jac below.
 template <bool CH_MAJOR, bool JAC>
 __global__ __launch_bounds__(S360_BLOCK) void k_sh_eval(KParams kp, const S360View* __restrict__ views,
                                                        const float* __restrict__ means, const float* __restrict__ shs,
