@@ -38,6 +38,18 @@ def test_ragged_sizes(gpu, n, h, w):
     check_grads(hh["grads"], og, rtol=5e-4)
 
 
+def test_image_with_more_tiles_than_the_lds_binning_holds(gpu):
+    """2064 x 2056 pixels = 16 641 tiles: k_emit takes its global-atomic form (the per-block LDS histogram holds 8 192 tiles)
+    including the block-wise instance-slot reservation; forward state and gradients against the oracle."""
+    n, h, w = 700, 2056, 2064
+    S, means, cov6, shs, opac = small_front_scene(n=n, seed=5, h=h, w=w, spread=0.95, srange=(0.01, 0.08))
+    gimg = np.random.default_rng(5).standard_normal((3, h, w)).astype(np.float32)
+    f, og = _orc(S, means, cov6, shs, opac, gimg)
+    hh = run_hip(S, means, cov6, shs, opac, gpu, grad_image=gimg)
+    check_forward(hh, f, n, h, w)
+    check_grads(hh["grads"], og, rtol=5e-4)
+
+
 def test_huge_splats_cover_every_tile(gpu):
     """A few hundred splats, each covering the whole 128x128 image: tiles_touched = 64 per splat."""
     S, means, cov6, shs, opac = small_front_scene(n=300, seed=2, h=128, w=128, srange=(1.0, 2.5), spread=0.3)
