@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define S360_ABI_VERSION 14
+#define S360_ABI_VERSION 15
 #define S360_MAX_VIEWS 8
 #define S360_TILE 16
 
@@ -105,6 +105,8 @@ typedef struct S360Layout {
     size_t total_bytes;         /* forward workspace size */
     size_t header;              /* uint32[64]: [0]=num_instances [1]=overflow flag [2]=max tile list length */
     size_t tiles_touched;       /* uint32[V*P] */
+    size_t vis_mask;            /* uint8[P]  bit v set: Gaussian visible in view v (V <= 8).  tiles_touched is written for
+                                   visible pairs only; the kernels test visibility on this byte, not on V words */
     size_t slot_base;           /* uint32[V*P]  training calls: first instance slot of a visible pair (it owns `tiles_touched`
                                    consecutive slots; upstream's point_offsets scan is replaced by a block-wise reservation,
                                    so which range a pair gets is run-dependent — the ranges tile [0, num_instances)) */

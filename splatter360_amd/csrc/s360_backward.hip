@@ -98,7 +98,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_gather_slots(uint32_t cap, const
 template <bool USE_SH, bool SH_PASS>
 __global__ __launch_bounds__(S360_BLOCK) void k_preprocess_bwd(
     KParams kp, const S360View* __restrict__ views, const float* __restrict__ means, const float* __restrict__ cov6,
-    const float* __restrict__ shs, const uint32_t* __restrict__ tiles_touched,
+    const float* __restrict__ shs, const uint8_t* __restrict__ vis_mask,
     const uint8_t* __restrict__ clamped, const float4* __restrict__ pairgrad, float* __restrict__ d_means3D,
     float* __restrict__ d_means2D, float* __restrict__ d_cov6, float* __restrict__ d_opac, float* __restrict__ d_shs,
     float* __restrict__ d_colors, float4* __restrict__ drgb_out, int depth_mode, const float* __restrict__ sh_jac) {
@@ -142,6 +142,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess_bwd(
         float dcol_sum[3] = {0.f, 0.f, 0.f};  // colors_precomp gradient
         bool any_visible = false;
         int first_visible = -1;
+        const uint32_t vis = vis_mask[g];  // bit v: visible in view v (one byte instead of V tiles_touched words)
 
         for (int v = 0; v < kp.V; ++v) {
             const size_t p = (size_t)v * P + g;
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess_bwd(
             for (int k = 0; k < 6; ++k) c6[k] = c60[k] * sc2;
             float dmv0 = 0.f, dmv1 = 0.f, dmv2 = 0.f;
             float dcv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (tiles_touched[p] != 0) {
+            if ((vis >> v) & 1u) {
                 any_visible = true;
                 if (first_visible < 0) first_visible = v;
                 const float4 r0 = pairgrad[p * 3], r1 = pairgrad[p * 3 + 1], r2 = pairgrad[p * 3 + 2];
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess_bwd(
                 // view-direction term per view (campos differs); dRGB kept for the dSH pass
                 float* dr = lds_drgb + (tid * kp.V + v) * 3;
                 dr[0] = drgb_v[0]; dr[1] = drgb_v[1]; dr[2] = drgb_v[2];
-                if (tiles_touched[p] != 0) {
+                if ((vis >> v) & 1u) {
                     const S360View& vw = views[v];
                     const float ddx = mx - vw.campos[0], ddy = my - vw.campos[1], ddz = mz - vw.campos[2];
                     const float inv = 1.f / sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess_bwd(
                 for (int k = 0; k < kp.M * 3; ++k) sh[k] = 0.f;
                 for (int v = 0; v < kp.V; ++v) {
                     const size_t p = (size_t)v * P + g;
-                    if (tiles_touched[p] == 0) continue;
+                    if (!((vis >> v) & 1u)) continue;
                     const S360View& vw = views[v];
                     const float sc = vw.scale;
                     const float ddx = mx0 * sc - vw.campos[0], ddy = my0 * sc - vw.campos[1], ddz = mz0 * sc - vw.campos[2];
@@ -546,7 +547,7 @@ static int backward_impl(const S360Params* prm, const S360View* views, const flo
     const int nt = (sph ? kp.V / 2 : kp.V) * kp.T;
 
     const uint32_t* header = (const uint32_t*)(ws + L.header);
-    const uint32_t* tiles_touched = (const uint32_t*)(ws + L.tiles_touched);
+    const uint8_t* vis_mask = (const uint8_t*)(ws + L.vis_mask);
     const uint32_t* slot_base = (const uint32_t*)(ws + L.slot_base);
     const float4* recA = (const float4*)(ws + L.rec_a);
     const float4* recB = (const float4*)(ws + L.rec_b);
@@ -592,7 +593,7 @@ static int backward_impl(const S360Params* prm, const S360View* views, const flo
             // dRGB/d(view direction) reaches dL/dmean here (from the forward's sh_jac), whether or not dL/dSH is wanted
             // (harmonics frozen: d_shs == NULL), as upstream does
             hipLaunchKernelGGL((k_preprocess_bwd<true, false>), dim3(nblk), dim3(S360_BLOCK), 0, st, kp, views, means3D, cov6, shs,
-                               tiles_touched, clamped, pairgrad, d_means3D, d_means2D, d_cov6, d_opacities, d_shs,
+                               vis_mask, clamped, pairgrad, d_means3D, d_means2D, d_cov6, d_opacities, d_shs,
                                d_colors, drgb, dmode, (const float*)(ws + L.sh_jac));
             if (!d_rgb_sum && d_shs) {
                 const int rc2 = launch_sh_bwd(kp, views, means3D, drgb, 1, d_shs, st);
@@ -611,12 +612,12 @@ static int backward_impl(const S360Params* prm, const S360View* views, const flo
                 }
             }
             hipLaunchKernelGGL((k_preprocess_bwd<true, true>), dim3(nblk), dim3(S360_BLOCK), lds, st, kp, views, means3D, cov6, shs,
-                               tiles_touched, clamped, pairgrad, d_means3D, d_means2D, d_cov6, d_opacities, d_shs,
+                               vis_mask, clamped, pairgrad, d_means3D, d_means2D, d_cov6, d_opacities, d_shs,
                                d_colors, (float4*)nullptr, dmode, (const float*)nullptr);
         }
     } else {
         hipLaunchKernelGGL((k_preprocess_bwd<false, false>), dim3(nblk), dim3(S360_BLOCK), 0, st, kp, views, means3D, cov6, shs,
-                           tiles_touched, clamped, pairgrad, d_means3D, d_means2D, d_cov6, d_opacities, d_shs,
+                           vis_mask, clamped, pairgrad, d_means3D, d_means2D, d_cov6, d_opacities, d_shs,
                            d_colors, (float4*)nullptr, dmode, (const float*)nullptr);
     }
     S360_CHECK_LAUNCH();

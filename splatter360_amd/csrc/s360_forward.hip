@@ -270,7 +270,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess(
     const float* __restrict__ colors, int32_t* __restrict__ radii, uint32_t* __restrict__ tiles_touched,
     float4* __restrict__ recA, float4* __restrict__ recB, float4* __restrict__ recC,
     uint8_t* __restrict__ clamped, float* __restrict__ depths, uint32_t* __restrict__ tile_count, int lds_hist,
-    const float4* __restrict__ rgbc) {
+    const float4* __restrict__ rgbc, uint8_t* __restrict__ vis_mask) {
     // dynamic LDS: tile histogram V*T uint32 (lds_hist).  SH coefficients are NOT staged: every lane
     // streams its own Gaussian's 300-byte slab with 16-byte loads (all bytes of every cache line are
     // consumed by the same lane within a few instructions, so HBM traffic stays 1x) — this keeps the
@@ -304,6 +304,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess(
         have_rgb = true;
     }
 
+    uint32_t vis = 0;
     for (int v = 0; v < kp.V; ++v) {
         const S360View& vw = views[v];
         const size_t p = (size_t)v * P + g;
@@ -446,8 +447,14 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess(
             }
         }
         if (radii) radii[p] = radius;
-        tiles_touched[p] = touched;
+        // visibility of the V (<= 8) views in ONE byte per Gaussian: k_emit and the backward test that instead of V words
+        // (24 MB written here and read twice for six views of 1 M Gaussians); tiles_touched only exists for visible pairs
+        if (touched) {
+            tiles_touched[p] = touched;
+            vis |= 1u << v;
+        }
     }
+    vis_mask[g] = (uint8_t)vis;
     }  // g < P
     if (lds_hist) {
         __syncthreads();
@@ -550,7 +557,7 @@ constexpr int EMIT_PPT = S360_EMIT_PPT;  // pairs per thread: more instances per
 
 template <bool LDS_BIN>
 __global__ __launch_bounds__(S360_BLOCK) void k_emit(KParams kp, const uint32_t* __restrict__ tiles_touched,
-                                                    const float4* __restrict__ recA, const float4* __restrict__ recC,
+                                                    const uint8_t* __restrict__ vis_mask, const float4* __restrict__ recA, const float4* __restrict__ recC,
                                                     const float* __restrict__ depths, const uint32_t* __restrict__ tile_start,
                                                     uint32_t* __restrict__ tile_cursor, uint64_t* __restrict__ keys,
                                                     uint32_t* __restrict__ slot_base, uint32_t* __restrict__ slot_pair,
@@ -572,8 +579,10 @@ __global__ __launch_bounds__(S360_BLOCK) void k_emit(KParams kp, const uint32_t*
 #pragma unroll
     for (int j = 0; j < EMIT_PPT; ++j) {
         const int g = g0 + j * S360_BLOCK;
-        tt[j] = g < kp.P ? tiles_touched[(size_t)v * kp.P + g] : 0u;
-        if (tt[j] != 0) vis |= 1u << j;
+        // one visibility byte per Gaussian, then the count of the visible pairs only (instead of a word per pair)
+        const bool seen = g < kp.P && ((vis_mask[g] >> v) & 1u);
+        tt[j] = seen ? tiles_touched[(size_t)v * kp.P + g] : 0u;
+        if (seen) vis |= 1u << j;
     }
     // Training calls: the pair's instance slots — where the backward composite leaves its partial gradients, one record
     // per (pair, tile) — are `touched` consecutive slots reserved here: block total -> ONE returning atomic on the
@@ -1289,6 +1298,7 @@ extern "C" int s360_layout(const S360Params* prm, S360Layout* out) {
     };
     out->header = take(64 * 4);
     out->tiles_touched = take(np * 4);
+    out->vis_mask = take((size_t)(prm->P > 0 ? prm->P : 1));
     out->slot_base = take(np * 4);
     out->rec_a = take(np * 48);  // one 48-byte record per pair: rec_b / rec_c are the 2nd / 3rd float4 of it
     out->rec_b = out->rec_a + 16;
@@ -1357,6 +1367,7 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
 
     uint32_t* header = (uint32_t*)(ws + L.header);
     uint32_t* tiles_touched = (uint32_t*)(ws + L.tiles_touched);
+    uint8_t* vis_mask = (uint8_t*)(ws + L.vis_mask);
     uint32_t* slot_base = (uint32_t*)(ws + L.slot_base);
     uint32_t* slot_ticket = (uint32_t*)(ws + L.slot_ticket);
     float4* recA = (float4*)(ws + L.rec_a);
@@ -1413,19 +1424,19 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
             if (eager)
                 hipLaunchKernelGGL((k_preprocess<true, true, true>), dim3(nblk), dim3(S360_BLOCK), lds, st, kp, views, means3D, cov6,
                                    opacities, shs, colors_precomp, radii, tiles_touched, recA, recB, recC, clamped, depths,
-                                   tile_count, lds_hist, rgbc);
+                                   tile_count, lds_hist, rgbc, vis_mask);
             else if (kp.flags & S360_FLAG_SH_CHANNEL_MAJOR)
                 hipLaunchKernelGGL((k_preprocess<true, true>), dim3(nblk), dim3(S360_BLOCK), lds, st, kp, views, means3D, cov6,
                                    opacities, shs, colors_precomp, radii, tiles_touched, recA, recB, recC, clamped, depths,
-                                   tile_count, lds_hist, rgbc);
+                                   tile_count, lds_hist, rgbc, vis_mask);
             else
                 hipLaunchKernelGGL((k_preprocess<true, false>), dim3(nblk), dim3(S360_BLOCK), lds, st, kp, views, means3D, cov6,
                                    opacities, shs, colors_precomp, radii, tiles_touched, recA, recB, recC, clamped, depths,
-                                   tile_count, lds_hist, rgbc);
+                                   tile_count, lds_hist, rgbc, vis_mask);
         } else {
             hipLaunchKernelGGL((k_preprocess<false, false>), dim3(nblk), dim3(S360_BLOCK), lds_hist ? hist_bytes : 0, st, kp, views,
                                means3D, cov6, opacities, shs, colors_precomp, radii, tiles_touched, recA, recB, recC, clamped,
-                               depths, tile_count, lds_hist, rgbc);
+                               depths, tile_count, lds_hist, rgbc, vis_mask);
         }
         }
         S360_CHECK_LAUNCH();
@@ -1442,10 +1453,10 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
         {
         ProfScope ps(PS_EMIT, st);
         if ((size_t)kp.T * 8 <= 64 * 1024)
-            hipLaunchKernelGGL(k_emit<true>, egrid, dim3(S360_BLOCK), (size_t)kp.T * 8, st, kp, tiles_touched, recA, recC,
+            hipLaunchKernelGGL(k_emit<true>, egrid, dim3(S360_BLOCK), (size_t)kp.T * 8, st, kp, tiles_touched, vis_mask, recA, recC,
                                depths, tile_start, tile_cursor, keys, slot_base, slot_pair, slot_ticket);
         else
-            hipLaunchKernelGGL(k_emit<false>, egrid, dim3(S360_BLOCK), 0, st, kp, tiles_touched, recA, recC, depths, tile_start,
+            hipLaunchKernelGGL(k_emit<false>, egrid, dim3(S360_BLOCK), 0, st, kp, tiles_touched, vis_mask, recA, recC, depths, tile_start,
                                tile_cursor, keys, slot_base, slot_pair, slot_ticket);
         }
         S360_CHECK_LAUNCH();

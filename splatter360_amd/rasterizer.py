@@ -133,7 +133,8 @@ class RasterState:
         cap = p.max_instances
         return dict(
             header=self.header(),
-            tiles_touched=self._arr(l.tiles_touched, npair, torch.int32).view(p.V, p.P),
+            tiles_touched=self._tiles_touched(),
+            vis_mask=self._arr(l.vis_mask, p.P, torch.uint8),
             slot_base=self._arr(l.slot_base, npair, torch.int32).view(p.V, p.P),
             slot_pair=self._arr(l.slot_pair, cap, torch.int32),
             rec_a=self._arr(l.rec_a, npair * 12, torch.float32).view(p.V, p.P, 12)[..., 0:4],
@@ -149,6 +150,14 @@ class RasterState:
             n_contrib=self._arr(l.n_contrib, p.V * p.H * p.W, torch.int32).view(p.V, p.H, p.W),
             tile_max_contrib=self._arr(l.tile_max_contrib, nt, torch.int32),
         )
+
+    def _tiles_touched(self) -> Tensor:
+        """[V,P] tile counts: the kernels write them for visible pairs only (vis_mask bit v of Gaussian g), the rest reads 0."""
+        p, l = self.prm, self.layout
+        raw = self._arr(l.tiles_touched, p.V * p.P, torch.int32).view(p.V, p.P)
+        vis = self._arr(l.vis_mask, p.P, torch.uint8).to(torch.int32)
+        bits = (vis[None, :] >> torch.arange(p.V, device=vis.device, dtype=torch.int32)[:, None]) & 1
+        return torch.where(bits.bool(), raw, torch.zeros_like(raw))
 
     def num_rendered(self) -> int:
         """Host read of num_instances (synchronises)."""
