@@ -118,6 +118,10 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch FIRST: its wheel bundles its own libamdhip64; if this library were loaded before torch, the system HIP runtime
+    # it links against would come up as a second runtime in the process and every launch on torch's streams / memory would
+    # fail (seen as "HIP launch / runtime error" when build() and smoke() ran in one process)
+    import torch  # noqa: F401
     if not LIB_PATH.exists():
         raise RuntimeError(
             f"{LIB_PATH} is missing: the HIP rasteriser was not built. Run "
