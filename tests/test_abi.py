@@ -109,3 +109,15 @@ def test_ctypes_argtypes_match_the_header_prototypes():
                     assert a in (C.c_int, C.c_int32, C.c_uint32), f"{name}: '{p}' vs {a}"
         checked += 1
     assert checked >= 12
+
+
+def test_loading_the_library_brings_torch_in_first():
+    """libs360.so links the system libamdhip64; torch's wheel bundles its own.  Loaded before torch, the library would start
+    a second HIP runtime in the process and every later launch on torch's streams fails (build() + smoke() in one process
+    did exactly that).  lib() therefore imports torch before dlopen — checked in a fresh interpreter."""
+    import subprocess
+    import sys
+    code = ("import sys; from splatter360_amd import _lib; assert 'torch' not in sys.modules; "
+            "_lib.lib(); assert 'torch' in sys.modules; print('ok')")
+    r = subprocess.run([sys.executable, "-c", code], cwd=str(ROOT), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
