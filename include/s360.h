@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define S360_ABI_VERSION 15
+#define S360_ABI_VERSION 16
 #define S360_MAX_VIEWS 8
 #define S360_TILE 16
 
@@ -135,6 +135,12 @@ typedef struct S360Layout {
                                    centre: evaluated once per call by a streaming kernel ahead of the geometry pass */
     size_t sh_jac;              /* float[P,3,3] d(rgb_c)/d(mean) through the view direction (training calls only): lets the
                                    backward add that term to dL/dmean without re-reading the 300-byte SH slab */
+    size_t surv;                /* training calls: 48-byte records of the list entries that survive the exact cull of each
+                                   8x8 quadrant, in list order, written by the forward composite (centre, conic, opacity,
+                                   colour, radius, list position, pair): unit (tile t, quadrant q) owns records
+                                   [4 start_t + q n_t, ... + n_t), n_t = the tile's list length.  The backward composite
+                                   streams them back to front instead of walking and culling the tile list a second time */
+    size_t surv_count;          /* uint32[V*T*4] survivor records of a unit that lie in front of its last contributor */
     size_t backward_bytes;      /* size of the separate backward scratch workspace */
 } S360Layout;
 

@@ -26,7 +26,7 @@ FLAG_SH_CHANNEL_MAJOR = 4
 FLAG_FORWARD_ONLY = 8
 FLAG_SH_DEG4_IGNORED = 16
 FLAG_SPHERICAL = 32
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 class S360Params(C.Structure):
@@ -39,7 +39,7 @@ class S360Layout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in (
         "total_bytes", "header", "tiles_touched", "vis_mask", "slot_base", "rec_a", "rec_b", "rec_c",
         "clamped", "depths", "tile_count", "slot_ticket", "tile_start", "tile_cursor", "chunk_start", "tile_order", "keys", "keys_alt", "list", "final_T", "n_contrib",
-        "tile_max_contrib", "strip_last", "slot_pair", "rgbc", "sh_jac", "backward_bytes")]
+        "tile_max_contrib", "strip_last", "slot_pair", "rgbc", "sh_jac", "surv", "surv_count", "backward_bytes")]
 
 
 EXPORTS = ("s360_abi_version", "s360_error_string", "s360_layout", "s360_forward", "s360_forward_depth", "s360_forward_mse", "s360_backward", "s360_backward_split", "s360_sh_backward", "s360_pack_views", "s360_adapter_forward", "s360_adapter_backward",

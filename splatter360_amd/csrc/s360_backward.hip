@@ -483,9 +483,11 @@ __global__ __launch_bounds__(64) void k_sh_bwd(KParams kp, const S360View* __res
     float* dst = d_shs + (size_t)g0 * slab;
     if ((((uintptr_t)dst) & 15) == 0) {
         const int n4 = nfl >> 2;
-        float4* o4 = reinterpret_cast<float4*>(dst);
-        const float4* l4 = reinterpret_cast<const float4*>(lds_o);
-        for (int i = lane; i < n4; i += 64) o4[i] = l4[i];
+        // non-temporal stores: the 315 MB of dL/dSH are consumed by the optimiser / the exchange, never by this library — kept
+        // out of L2 / Infinity Cache they no longer sit, dirty, in front of the next step's SH read (k_sh_eval3_jac measured
+        // 98 us right behind this kernel's plain stores, 72 us on its own)
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        for (int i = lane; i < n4; i += 64) __builtin_nontemporal_store(reinterpret_cast<const f4v*>(lds_o)[i], reinterpret_cast<f4v*>(dst) + i);
         for (int i = (n4 << 2) + lane; i < nfl; i += 64) dst[i] = lds_o[i];
     } else {
         for (int i = lane; i < nfl; i += 64) dst[i] = lds_o[i];
@@ -563,14 +565,14 @@ static int backward_impl(const S360Params* prm, const S360View* views, const flo
     uint32_t* valid_words = (uint32_t*)((char*)bwd_workspace + (size_t)kp.cap * 4 * GREC * 4);
 
     uint32_t* order = valid_words + kp.cap;  // [nt*4] after the validity words
-    const uint32_t* strip_last = (const uint32_t*)(ws + L.strip_last);
+    const uint32_t* surv_count = (const uint32_t*)(ws + L.surv_count);  // per-unit replay length: also the work estimate
     const bool use_order = !getenv("S360_NO_ORDER");
     {
     ProfScope ps(PS_RENDER_BWD, st);
-    hipLaunchKernelGGL(k_order_units, dim3(1 + 512), dim3(1024), 0, st, strip_last, use_order ? order : (uint32_t*)nullptr, nt * 4,
+    hipLaunchKernelGGL(k_order_units, dim3(1 + 512), dim3(1024), 0, st, surv_count, use_order ? order : (uint32_t*)nullptr, nt * 4,
                        valid_words, header, kp.cap);
     const uint32_t* ord = use_order ? order : (const uint32_t*)nullptr;
-    launch_render_bwd_em(with_depth, nt * 4, st, kp, views, tile_start, list, slot_base, recA, depths, final_T, n_contrib,
+    launch_render_bwd_em(with_depth, nt * 4, st, kp, views, tile_start, (const float4*)(ws + L.surv), surv_count, slot_base, depths, final_T, n_contrib,
                          dL_dimages, dL_dimages_scale, dL_ddepth, part, (uint8_t*)valid_words, ord, depth_mode,
 #ifdef S360_DBG_TIMING
                          (uint32_t*)(ws + L.keys_alt));  // the forward's merge buffer is free by now

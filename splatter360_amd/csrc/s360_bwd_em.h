@@ -98,7 +98,7 @@ __device__ __forceinline__ float depth_value_grad(float z, float nearp, float fa
 template <bool WITH_DEPTH>
 __global__ __launch_bounds__(64) void k_render_bwd_em(
     KParams kp, const S360View* __restrict__ views, const uint32_t* __restrict__ tile_start,
-    const uint32_t* __restrict__ list, const uint32_t* __restrict__ slot_base, const float4* __restrict__ recA,
+    const float4* __restrict__ surv, const uint32_t* __restrict__ surv_count, const uint32_t* __restrict__ slot_base,
     const float* __restrict__ depths, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dimages, const float* __restrict__ dL_dimages_scale, const float* __restrict__ dL_ddepth,
     float4* __restrict__ part,
@@ -107,7 +107,6 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
     const long long t_begin = wall_clock64();
 #endif
     static_assert(SUB_W == 8, "entry-major backward assumes 8x8 quadrants");
-    __shared__ float4 s_q[EM_QCAP * 3];
     // per-pixel tables, one array per quantity (pixel-contiguous: a 16-byte read hands a four-pixel run to the lanes as two
     // register PAIRS — the operands of the packed v_pk_* arithmetic below)
     __shared__ __attribute__((aligned(16))) float s_gr[64], s_gg[64], s_gb[64], s_gd[64];  // dL/dpixel (r, g, b, depth)
@@ -116,20 +115,30 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
     __shared__ __attribute__((aligned(16))) uint32_t s_last[64];     // n_contrib
 
     const uint32_t unit = order ? order[blockIdx.x] : blockIdx.x;  // tile*4 + quadrant
+    const uint32_t n_surv = surv_count[unit];  // survivor records in front of the quadrant's last contributor
+    if (n_surv == 0) return;                   // nothing reaches any pixel of this quadrant
     const int t = (int)(unit >> 2), wave = (int)(unit & 3u), lane = threadIdx.x;
     const int v = t / kp.T, rem = t - v * kp.T;
     const int ty = rem / kp.gx, tx = rem - ty * kp.gx;
     const int qx = tx * 16 + sub_ox(wave), qy = ty * 16 + sub_oy(wave);
-    const float x0 = (float)qx, ys0 = (float)qy;
-    const uint32_t start = min(tile_start[t], kp.cap);
+    const uint32_t start = min(tile_start[t], kp.cap), end = min(tile_start[t + 1], kp.cap);
+    const float4* const sv = surv + 3 * ((size_t)4 * start + (size_t)wave * (end - start));  // this unit's records
     const S360View& vw = views[view_of_image(kp, v)];  // v = image index
 
+    // the first group's records: in flight while the pixel tables are set up
+    int64_t top = (int64_t)n_surv - 1;  // lane l of a group holds record top - l (descending list position)
+    float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na, nc = na;
+    if (top - lane >= 0) {
+        const float4* r = sv + 3 * (size_t)(top - lane);
+        na = r[0]; nb = r[1]; nc = r[2];
+    }
+
     // ---- per-pixel constants (lane = pixel of the quadrant) ----
-    uint32_t last = 0;
     {
         const int px = qx + (lane & 7), py = qy + (lane >> 3);
         const size_t hw = (size_t)kp.H * kp.W;
         float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = make_float4(1.0f, 0.f, 0.f, 0.f);
+        uint32_t last = 0;
         if (px < kp.W && py < kp.H) {
             const size_t pix = (size_t)py * kp.W + px;
             const float T_final = final_T[(size_t)v * hw + pix];
@@ -148,8 +157,6 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
         s_T[lane] = pb.x; s_R[lane] = 0.f; s_B[lane] = pb.z;
         s_last[lane] = last;
     }
-    const uint32_t wave_last = wave_max_u32(last);  // entries [0, wave_last) can matter to this quadrant
-    if (wave_last == 0) return;
     f2 pxc[4];  // pixel-centre x of the row's four pixel pairs
 #pragma unroll
     for (int c = 0; c < 4; ++c) pxc[c] = f2{(float)(qx + 2 * c), (float)(qx + 2 * c + 1)};
@@ -157,25 +164,28 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
     const float v_near = WITH_DEPTH ? vw.near_plane : 0.f, v_far = WITH_DEPTH ? vw.far_plane : 0.f;
 
 #ifdef S360_DBG_TIMING
-    uint32_t dbg_halves = 0, dbg_surv = 0;
+    uint32_t dbg_halves = 0;
 #endif
-    // ---- one group: up to 64 queued survivors in the lanes (descending list position), loop over the 64 pixels ----
-    auto process_group = [&](uint32_t head, uint32_t n) __attribute__((always_inline)) {
-        const uint32_t idx = (head + (uint32_t)lane) & (EM_QCAP - 1);
-        const float4 qa = s_q[3 * idx], qb = s_q[3 * idx + 1], qc = s_q[3 * idx + 2];
+    // ---- groups of up to 64 survivors in the lanes (descending list position); per group a loop over the 64 pixels ----
+    for (; top >= 0; top -= 64) {
+        const uint32_t n = (uint32_t)(top + 1 < 64 ? top + 1 : 64);
+        const float4 qa = na, qb = nb, qc = nc;
+        if (top - 64 - lane >= 0) {  // the next (nearer) group's records fly during this group's pixel loop
+            const float4* r = sv + 3 * (size_t)(top - 64 - lane);
+            na = r[0]; nb = r[1]; nc = r[2];
+        }
         const bool lane_ok = (uint32_t)lane < n;
-        const float ex = qa.x, ey = qa.y, cA = qa.z, cB = qa.w, cC = qb.x, op = qb.y, c0 = qb.z, c1 = qb.w, c2 = qc.x,
-                    zv = qc.y;
+        const float ex = qa.x, ey = qa.y, cA = qa.z, cB = qa.w, cC = qb.x, op = qb.y, c0 = qb.z, c1 = qb.w, c2 = qc.x;
+        const int erad = __float_as_int(qc.y);
         const uint32_t pos = lane_ok ? __float_as_uint(qc.z) : 0xFFFFFFFFu;  // list position; idle lanes never contribute
-        // the entry's instance slot (where its partial record goes) is only needed at the very end: its two gathers — the
-        // pair's first slot and the splat radius for the tile rectangle — fly during the pixel loop, and only SURVIVORS pay
-        // for them (as part of the walk, slot_base[pair] was a 4-byte gather per list entry: one 64-byte sector each)
+        // the entry's instance slot (where its partial record goes) is only needed at the very end: the gather of the pair's
+        // first slot flies during the pixel loop, and only SURVIVORS pay for it
         const uint32_t pair = __float_as_uint(qc.w);
         uint32_t sbase = 0;
-        int erad = 0;
+        float zv = 0.f;
         if (lane_ok) {
             sbase = slot_base[pair];
-            erad = __float_as_int(reinterpret_cast<const float*>(recA + 3 * (size_t)pair + 2)[1]);
+            if (WITH_DEPTH) zv = depth_value(depths[pair] * inv_scale, v_near, v_far, depth_mode);
         }
         // positions descend with the lane: the group's frontmost entry sits in lane n - 1
         const uint32_t pos_min = (uint32_t)__builtin_amdgcn_readlane((int)pos, (int)n - 1);
@@ -307,68 +317,13 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
             o[2] = make_float4(g_b.x + g_b.y, g_z.x + g_z.y, 0.f, 0.f);
             valid[(size_t)inst * 4 + wave] = 1;
         }
-    };
-
-    // ---- walk the list back to front, 64 entries per chunk (lane l <-> list position hi - l); survivors go to the queue ----
-    uint32_t qhead = 0, qcount = 0;
-    const int64_t hi0 = (int64_t)wave_last - 1;
-    // software pipeline of the gather chain list -> record: the next chunk's records and the list indices of the one after
-    // are in flight while the current chunk is culled.  (A second chunk of records in flight changed nothing: the walk is
-    // bound by the memory system's throughput on these 48-byte gathers, not by their latency.)
-    uint32_t p_n1 = 0, p_n2 = 0;
-    if (hi0 - lane >= 0) p_n1 = list[start + (uint32_t)(hi0 - lane)];
-    if (hi0 - 64 - lane >= 0) p_n2 = list[start + (uint32_t)(hi0 - 64 - lane)];
-    float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na, nc = na;
-    float nz = 0.f;
-    if (hi0 - lane >= 0) {
-        na = recA[3 * (size_t)p_n1];
-        nb = recA[3 * (size_t)p_n1 + 1];
-        nc = recA[3 * (size_t)p_n1 + 2];
-        if (WITH_DEPTH) nz = depths[p_n1];
     }
-    for (int64_t hi = hi0; hi >= 0; hi -= 64) {
-        const float4 ea = na, eb = nb;
-        const float ec = nc.x, eka = nc.z, ekb = nc.w;
-        float ez = 0.f;
-        if (WITH_DEPTH) ez = depth_value(nz * inv_scale, v_near, v_far, depth_mode);
-        const bool ev = hi - lane >= 0;
-        const uint32_t epair = p_n1;
-        p_n1 = p_n2;
-        if (hi - 64 - lane >= 0) {
-            na = recA[3 * (size_t)p_n1];
-            nb = recA[3 * (size_t)p_n1 + 1];
-            nc = recA[3 * (size_t)p_n1 + 2];
-            if (WITH_DEPTH) nz = depths[p_n1];
-        }
-        if (hi - 128 - lane >= 0) p_n2 = list[start + (uint32_t)(hi - 128 - lane)];
-
-        const bool hit = ev && quadrant_hit(ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, eka, ekb, x0, ys0);
-        const unsigned long long m = __ballot(hit);
-        if (m == 0ull) continue;
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        if (hit) {
-            const uint32_t idx = (qhead + qcount + rank) & (EM_QCAP - 1);
-            s_q[3 * idx] = ea;
-            s_q[3 * idx + 1] = eb;
-            s_q[3 * idx + 2] = make_float4(ec, ez, __uint_as_float((uint32_t)(hi - lane)), __uint_as_float(epair));
-        }
-        qcount += (uint32_t)__popcll(m);
 #ifdef S360_DBG_TIMING
-        dbg_surv += (uint32_t)__popcll(m);
-#endif
-        while (qcount >= 64) {
-            process_group(qhead, 64);
-            qhead = (qhead + 64) & (EM_QCAP - 1);
-            qcount -= 64;
-        }
-    }
-    if (qcount) process_group(qhead, qcount);
-#ifdef S360_DBG_TIMING
-    if (lane == 0 && dbg) {  // per-unit (start, duration) in 100-MHz ticks + walk length (scripts/bwdtiming.py)
+    if (lane == 0 && dbg) {  // per-unit (start, duration) in 100-MHz ticks + replay length (scripts/bwdtiming.py)
         dbg[4 * unit] = (uint32_t)t_begin;
         dbg[4 * unit + 1] = (uint32_t)(wall_clock64() - t_begin);
-        dbg[4 * unit + 2] = wave_last;
-        dbg[4 * unit + 3] = (dbg_halves << 16) | min(dbg_surv, 65535u);
+        dbg[4 * unit + 2] = n_surv;
+        dbg[4 * unit + 3] = (dbg_halves << 16) | min(n_surv, 65535u);
     }
 #endif
 }
@@ -378,7 +333,7 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
 // -fno-slp-vectorize: the pixel pairs are packed by hand above — pixel-contiguous LDS tables, pair accumulators — which
 // costs no register moves; the SLP vectoriser's own pairing of the scalar formulation paid 23 moves per half row).
 void launch_render_bwd_em(bool with_depth, int n_units, hipStream_t st, const KParams& kp, const S360View* views,
-                          const uint32_t* tile_start, const uint32_t* list, const uint32_t* slot_base, const float4* recA,
+                          const uint32_t* tile_start, const float4* surv, const uint32_t* surv_count, const uint32_t* slot_base,
                           const float* depths, const float* final_T, const uint32_t* n_contrib, const float* dL_dimages,
                           const float* dL_dimages_scale, const float* dL_ddepth, float4* part, uint8_t* valid, const uint32_t* order, int depth_mode, uint32_t* dbg);
 

@@ -204,11 +204,15 @@ __global__ __launch_bounds__(SHE3_G * 3) void k_sh_eval3_jac(KParams kp, const S
         const float* src = shs + (size_t)g0 * 75;
         const int nfl = min(SHE3_G, kp.P - g0) * 75;
         if ((((uintptr_t)src) & 15) == 0 && nfl == SHE3_G * 75) {
-            const float4* s4 = reinterpret_cast<const float4*>(src);
             float4* d4 = reinterpret_cast<float4*>(s_sh);
             float4 q[7];
+            // non-temporal loads: every slab byte is read exactly once per call
+            typedef float f4v __attribute__((ext_vector_type(4)));
 #pragma unroll
-            for (int r = 0; r < 7; ++r) q[r] = s4[min(tid + r * (SHE3_G * 3), SHE3_G * 75 / 4 - 1)];
+            for (int r = 0; r < 7; ++r) {
+                const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(src) + min(tid + r * (SHE3_G * 3), SHE3_G * 75 / 4 - 1));
+                q[r] = make_float4(t.x, t.y, t.z, t.w);
+            }
 #pragma unroll
             for (int r = 0; r < 7; ++r) d4[tid + r * (SHE3_G * 3)] = q[r];
         } else {
@@ -1035,7 +1039,8 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
                                                       uint32_t* __restrict__ tile_max_contrib, uint32_t* __restrict__ strip_last,
                                                       uint32_t* __restrict__ dbg, const float* __restrict__ depths,
                                                       float* __restrict__ depth_maps, int depth_mode, MseEp ep,
-                                                      const uint32_t* __restrict__ tile_order) {
+                                                      const uint32_t* __restrict__ tile_order, float4* __restrict__ surv,
+                                                      uint32_t* __restrict__ surv_count) {
 #ifdef S360_DBG_TIMING
     const long long t_begin = wall_clock64();
 #endif
@@ -1064,6 +1069,14 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
     f2 C01 = f2{0.f, 0.f}, C2D = f2{0.f, 0.f};  // (r, g) and (b, depth) accumulators
     uint32_t last = 0;
     bool done = !inside;
+    // Training calls: every entry that survives this quadrant's exact cull is appended (48-byte record, list order) to the
+    // unit's slice of `surv`; the backward composite streams those records back to front instead of walking and culling the
+    // tile list again (its walk was a third of its time: 48-byte gathers through L2 for three entries in four that it then
+    // dropped).  sv_* remember the last chunk in which any pixel of the quadrant took a contribution: its cull ballot turns the
+    // quadrant's final replay length (a list position) into a count of survivor records.
+    float4* const sv = surv ? surv + 3 * ((size_t)4 * start + (size_t)wave * (end - start)) : nullptr;
+    uint32_t scount = 0, sv_cnt = 0, sv_rel = 0;
+    unsigned long long sv_m = 0ull;
     const int vcam = view_of_image(kp, v);  // v = image index
     const float inv_scale = WITH_DEPTH ? 1.0f / views[vcam].scale : 0.f;
     const float v_near = WITH_DEPTH ? views[vcam].near_plane : 0.f, v_far = WITH_DEPTH ? views[vcam].far_plane : 0.f;
@@ -1086,8 +1099,9 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
         // fused depth "colour" of this lane's entry: camera z in unscaled units, then the reference's mode
         float ez = 0.f;
         if (WITH_DEPTH) ez = depth_value(nz * inv_scale, v_near, v_far, depth_mode);
-        const float ec = nc.x, eka = nc.z, ekb = nc.w;
+        const float ec = nc.x, erad = nc.y, eka = nc.z, ekb = nc.w;
         const bool ev = b + lane < end;
+        const uint32_t epair = p_n1;
         // issue the next chunk's loads before touching this one
         p_n1 = p_n2;
         if (b + 64 + lane < end) {
@@ -1108,6 +1122,13 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
 #endif
         if (m == 0ull) continue;
         const uint32_t rel = b - start;  // list position of this chunk's lane 0
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (sv && hit) {
+            float4* o = sv + 3 * (size_t)(scount + rank);
+            o[0] = ea;
+            o[1] = eb;
+            o[2] = make_float4(ec, erad, __uint_as_float(rel + (uint32_t)lane), __uint_as_float(epair));
+        }
         const unsigned long long act = __ballot(!done);
         if (__popcll(act) > SPARSE_PIXELS) {
             // Survivors are COMPACTED into the wave's LDS slice (rank = prefix count of the cull ballot) and padded with
@@ -1119,7 +1140,6 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
             // bit-identical images (148 -> 142 us).
             const uint32_t cnt = (uint32_t)__popcll(m);
             {
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                 if (hit) {
                     s_x[wave][rank] = ea.x; s_y[wave][rank] = ea.y; s_a[wave][rank] = ea.z; s_b[wave][rank] = ea.w;
                     s_c[wave][rank] = eb.x; s_o[wave][rank] = eb.y;
@@ -1217,6 +1237,14 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
                 }
             }
         }
+        if (sv) {  // wave-uniform
+            if (__ballot(last > rel) != 0ull) {  // some pixel's last contributor (so far) lies in this chunk
+                sv_m = m;
+                sv_cnt = scount;
+                sv_rel = rel;
+            }
+            scount += (uint32_t)__popcll(m);
+        }
     }
     float sq = 0.f, sqc = 0.f;
     if (inside) {
@@ -1255,8 +1283,11 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
     }
     const uint32_t wm = wave_max_u32(inside ? last : 0u);
     if (lane == 0) {
-        strip_last[4 * t + wave] = wm;  // per-strip replay length: the backward's work estimate
+        strip_last[4 * t + wave] = wm;  // per-quadrant replay length (list positions)
         if (wm) atomicMax(&tile_max_contrib[t], wm);  // zeroed by k_tile_scan
+        // survivor records in front of the quadrant's last contributor (list position wm - 1, itself a survivor of chunk
+        // sv_rel): what the backward replays, and its work estimate
+        if (surv_count) surv_count[4 * t + wave] = wm ? sv_cnt + (uint32_t)__popcll(sv_m & ((2ull << (wm - 1u - sv_rel)) - 1ull)) : 0u;
     }
 #ifdef S360_DBG_TIMING
     if (lane == 0) {
@@ -1321,6 +1352,9 @@ extern "C" int s360_layout(const S360Params* prm, S360Layout* out) {
     out->slot_pair = take(cap * 4);
     out->rgbc = take((size_t)(prm->P > 0 ? prm->P : 1) * 16);
     out->sh_jac = take((size_t)(prm->P > 0 ? prm->P : 1) * 36);
+    const bool fwd_only = (prm->flags & S360_FLAG_FORWARD_ONLY) != 0;  // inference calls keep no survivor records
+    out->surv = take(fwd_only ? 16 : cap * 4 * 48);
+    out->surv_count = take(nt * 4 * 4);
     out->total_bytes = o;
     // backward scratch: 4 quadrant-partial raster-gradient records (12 floats) + 4 validity bytes per instance
     // ... + tile order [V*T] + one gathered 48-byte record per (view, Gaussian) pair
@@ -1486,6 +1520,9 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
     {
         ProfScope ps(PS_RENDER, st);
         const dim3 rgrid(nt), rblock(S360_BLOCK);
+        const bool training = !(kp.flags & S360_FLAG_FORWARD_ONLY);
+        float4* surv = training ? (float4*)(ws + L.surv) : nullptr;
+        uint32_t* surv_count = training ? (uint32_t*)(ws + L.surv_count) : nullptr;
 #ifdef S360_DBG_TIMING
         uint32_t* dbg = (uint32_t*)keys_alt;  // [4 * nt * 4] per-wave (start, duration ticks, HW_ID, XCC_ID): the merge buffer is free by now
 #else
@@ -1494,11 +1531,11 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
         if (depth_maps)
             hipLaunchKernelGGL(k_render<true>, rgrid, rblock, occupancy_cap_lds("S360_RENDER_LDS", 0), st, kp, views, tile_start,
                                list, recA, recB, recC, images, final_T, n_contrib, tile_max_contrib, strip_last, dbg,
-                               depths, depth_maps, depth_mode, ep, kp.P > 0 ? tile_order : (const uint32_t*)nullptr);
+                               depths, depth_maps, depth_mode, ep, kp.P > 0 ? tile_order : (const uint32_t*)nullptr, surv, surv_count);
         else
             hipLaunchKernelGGL(k_render<false>, rgrid, rblock, occupancy_cap_lds("S360_RENDER_LDS", 0), st, kp, views, tile_start,
                                list, recA, recB, recC, images, final_T, n_contrib, tile_max_contrib, strip_last, dbg,
-                               depths, depth_maps, depth_mode, ep, kp.P > 0 ? tile_order : (const uint32_t*)nullptr);
+                               depths, depth_maps, depth_mode, ep, kp.P > 0 ? tile_order : (const uint32_t*)nullptr, surv, surv_count);
         if (ep.target && ep.loss_out)
             hipLaunchKernelGGL(k_mse_finish, dim3(1), dim3(MSE_BLOCK), 0, st, ep.partials, kp.T * 4, kp.V, 0.5f * ep.grad_scale,
                                1.0f / (3.0f * (float)kp.H * (float)kp.W), ep.loss_out);
