@@ -63,7 +63,51 @@ def parse():
                          "has been queued (it overlaps with that forward); 0 = finished right after its own backward")
     ap.add_argument("--grad-sync", choices=("factored", "allreduce"), default="factored",
                     help="N>1 gradient exchange: factored (default) or one all-reduce of the full 352 B/Gaussian set")
+    ap.add_argument("--dry-run", type=int, default=0,
+                    help="1: launch / rendezvous / collectives only (no GPU work, value = null): lets the CPU test suite exercise "
+                         "`python bench.py --gpus N` end to end with the gloo backend")
     return ap.parse_args()
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` started plainly (no torchrun environment): become the launcher — one process per GPU under
+    torch.distributed.run on 127.0.0.1 (the driver's own N>1 command line), rank 0's JSON line passes through on stdout.
+    Reference behaviour: Lightning starts one DDP process per device itself (/root/reference/src/main.py:117-130)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+def dry_run(a, rank, local_rank, world):
+    """Everything around the hot path, nothing of it: rendezvous, one gradient-shaped all-reduce through the product's own
+    helper, the barrier + max-over-ranks timing protocol, the JSON line."""
+    import torch.distributed as dist
+    dev = torch.device("cpu")
+    g = [torch.full((1000, k), float(rank + 1)) for k in (3, 9, 75, 1)]
+    distributed.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        distributed.allreduce_gradients(g)
+    distributed.barrier()
+    dt = distributed.max_over_ranks(time.perf_counter() - t0, dev)
+    ok = all(abs(float(t[0, 0]) - sum(range(1, world + 1)) * (world ** (a.steps - 1))) < 1e-3 * world ** a.steps for t in g) if world > 1 else True
+    info = distributed.rank_report(dev)
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (no GPU work)", "value": None, "unit": "Msplats/s", "n_gpus": world, "steps": a.steps,
+                          "warmup": a.warmup, "ms_per_step": dt / max(a.steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True, "allreduce_ok": bool(ok),
+                          "config": {"workload": "dry run"}, **info}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def cpu_baseline(cloud, face_w, near, far, mode):
@@ -123,12 +167,17 @@ def cpu_baseline_torch():
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a)      # does not return
     rank, local_rank, world = distributed.init()
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {a.gpus} but the launcher started {world} rank(s)")
+    if a.dry_run:
+        return dry_run(a, rank, local_rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
+    if world > 1 and "S360_FORCE_DEVICE" not in os.environ and torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} GPU(s) are visible")
     dev = torch.device("cuda", torch.cuda.current_device())  # distributed.init() pinned cuda:LOCAL_RANK
     _lib.lib()
 

@@ -275,7 +275,21 @@ int s360_pack_views(const float* extrinsics, const float* intrinsics, const floa
  * cov3D_precomp layout), harmonics[V*Gv,3,d_sh]; optional scales_out[V*Gv,3] / rotations_out[V*Gv,4] (the adapter's
  * export-only fields).  Opacities pass through the adapter unchanged and are not touched here.
  * s360_adapter_backward: gradients of (means, covariances, harmonics) -> d_depths[V,Gv], d_raw_gaussians (same layout).
+ *   d_means == NULL (the reference's behaviour): the means are detached — the reference un-projects under torch.no_grad()
+ *   (src/geometry/sphere_projection.py:14-86), so depth receives gradient through the scales only; a non-NULL d_means adds
+ *   the un-projection's own term (this project's opt-in deviation).
  */
+/*
+ * The matrices of rotate_sh (src/misc/sh_rotation.py:10-30: per degree l, e3nn.o3.wigner_D(l, *matrix_to_angles(R)), applied to
+ * the SH coefficient blocks at gaussian_adapter_erp.py:113 with R = the context view's camera-to-world rotation).
+ *   rotations: n_views row-major 3x3 matrices, row_major_stride = 9 ([n,3,3]) or 16 (the rotation part of [n,4,4] poses);
+ *   sh_rotation_out[n_views, d_sh, d_sh]: block-diagonal, block l = D^l(R) with Y^l(R d) = D^l(R) Y^l(d) in e3nn's real basis
+ *   (polar axis y, azimuth from z towards x, m = -l..l, no Condon-Shortley phase; D^1 = R) — the `sh_rotation` argument of
+ *   s360_adapter_forward / backward.  e3nn itself is not available where this was written: the convention is restated from its
+ *   documentation and pinned by properties only (oracle/adapter_ref.py).
+ */
+int s360_sh_rotation_blocks(const float* rotations, int32_t row_major_stride, int32_t n_views, int32_t d_sh,
+                            float* sh_rotation_out, void* stream);
 int s360_adapter_forward(const float* extrinsics, const float* depths, const float* raw_gaussians,
                          const float* sh_rotation, int32_t n_views, int32_t per_view, int32_t H, int32_t W,
                          int32_t per_ray, int32_t d_sh, float scale_min, float scale_max, float eps, float* means,

@@ -42,7 +42,7 @@ class S360Layout(C.Structure):
         "tile_max_contrib", "strip_last", "slot_pair", "rgbc", "sh_jac", "surv", "surv_count", "backward_bytes")]
 
 
-EXPORTS = ("s360_abi_version", "s360_error_string", "s360_layout", "s360_forward", "s360_forward_depth", "s360_forward_mse", "s360_backward", "s360_backward_split", "s360_sh_backward", "s360_pack_views", "s360_adapter_forward", "s360_adapter_backward",
+EXPORTS = ("s360_abi_version", "s360_error_string", "s360_layout", "s360_forward", "s360_forward_depth", "s360_forward_mse", "s360_backward", "s360_backward_split", "s360_sh_backward", "s360_pack_views", "s360_adapter_forward", "s360_adapter_backward", "s360_sh_rotation_blocks",
            "s360_cube2erp_forward", "s360_cube2erp_backward", "s360_profile_slots", "s360_profile_slot_name",
            "s360_profile_enable", "s360_profile_collect")
 
@@ -152,6 +152,8 @@ def lib() -> C.CDLL:
     l.s360_adapter_forward.argtypes = [vp] * 4 + [i32] * 6 + [f32] * 3 + [vp, vp, i32, vp, vp, vp, vp]
     l.s360_adapter_backward.restype = C.c_int
     l.s360_adapter_backward.argtypes = [vp] * 4 + [i32] * 6 + [f32] * 3 + [vp, vp, i32, vp, vp, vp, vp]
+    l.s360_sh_rotation_blocks.restype = C.c_int
+    l.s360_sh_rotation_blocks.argtypes = [vp, i32, i32, i32, vp, vp]
     l.s360_cube2erp_forward.restype = C.c_int
     l.s360_cube2erp_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(C.c_int64), vp]
     l.s360_cube2erp_backward.restype = C.c_int

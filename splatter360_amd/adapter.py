@@ -1,6 +1,7 @@
 """The Gaussian-adapter tail of the splatter360 encoder — the step that PRODUCES the 340 B/Gaussian the
-rasteriser reads — as one fused HIP kernel pair (forward + backward) and, beside it, a plain
-torch restatement that runs on CPU and is pinned against a golden capture of the reference module.
+rasteriser reads — as one fused HIP kernel pair (forward + backward).  GPU only: a CPU tensor raises (the
+plain-torch restatement that checks these kernels lives in oracle/adapter_ref.py, test infrastructure, pinned against a
+golden capture of the reference module).
 
 Reference behaviour mirrored (file:line under /root/reference):
   * GaussianAdapterERP.forward            src/model/encoder/common/gaussian_adapter_erp.py:50-119
@@ -8,11 +9,12 @@ Reference behaviour mirrored (file:line under /root/reference):
   * build_covariance / quaternion_to_matrix  src/model/encoder/common/gaussians.py:8-44  (xyzw order)
   * sphere un-projection                  src/geometry/sphere_projection.py:6-86 with the 'hm3d' / 'replica' ERP
                                           convention of src/geometry/utils360.py:93-104,148-153
-  * rotate_sh                             src/misc/sh_rotation.py:10-30 — block-diagonal Wigner-D product.  e3nn (which
-                                          builds the D matrices) is not installed in this image, so the per-view
-                                          matrices are an INPUT here (`sh_rotation[V, d_sh, d_sh]`, only the
-                                          (2l+1)x(2l+1) diagonal blocks are read; None = identity); with e3nn present,
-                                          wigner_blocks_e3nn() produces them exactly as the reference does.
+  * rotate_sh                             src/misc/sh_rotation.py:10-30 — block-diagonal Wigner-D product.  The per-view
+                                          matrices (`sh_rotation[V, d_sh, d_sh]`, only the (2l+1)x(2l+1) diagonal blocks
+                                          are read; None = identity) come from sh_rotation_blocks() — one small kernel,
+                                          s360_sh_rotation_blocks, in e3nn's documented convention (e3nn is not installed in
+                                          this image: that convention is pinned by properties only) — or, where e3nn exists,
+                                          from wigner_blocks_e3nn(), which builds them exactly as the reference does.
 
 What the fused form saves: ~20 elementwise / matmul launches with their intermediates, and — with cov6=True — the
 [G,3,3] covariance materialisation (the rasteriser reads the 6 unique entries).
@@ -60,54 +62,6 @@ def erp_directions(h: int, w: int, device=None) -> Tensor:
     return torch.stack([torch.cos(phi) * torch.sin(theta), torch.sin(phi), torch.cos(phi) * torch.cos(theta)], -1).reshape(-1, 3)
 
 
-def quaternion_to_matrix(q: Tensor, eps: float = 1e-8) -> Tensor:
-    """gaussians.py:8-31 (xyzw order, normalised by 2 / (|q|^2 + eps))."""
-    i, j, k, r = torch.unbind(q, dim=-1)
-    two_s = 2 / ((q * q).sum(dim=-1) + eps)
-    o = torch.stack((1 - two_s * (j * j + k * k), two_s * (i * j - k * r), two_s * (i * k + j * r),
-                     two_s * (i * j + k * r), 1 - two_s * (i * i + k * k), two_s * (j * k - i * r),
-                     two_s * (i * k - j * r), two_s * (j * k + i * r), 1 - two_s * (i * i + j * j)), -1)
-    return o.reshape(*q.shape[:-1], 3, 3)
-
-
-def rotate_sh_blocks(sh: Tensor, rot: Optional[Tensor]) -> Tensor:
-    """sh[..., d_sh] -> block-diagonal product with rot[..., d_sh, d_sh] (only the (2l+1)^2 diagonal blocks are used)."""
-    if rot is None:
-        return sh
-    d_sh = sh.shape[-1]
-    out = []
-    for l in range(math.isqrt(d_sh)):
-        s = slice(l * l, (l + 1) * (l + 1))
-        out.append(torch.einsum("...ij,...j->...i", rot[..., s, s], sh[..., s]))
-    return torch.cat(out, dim=-1)
-
-
-def adapter_tail_torch(extrinsics: Tensor, depths: Tensor, opacities: Tensor, raw_gaussians: Tensor, image_shape,
-                       scale_min: float, scale_max: float, sh_rotation: Optional[Tensor] = None, eps: float = 1e-8,
-                       per_ray: int = 1) -> AdapterGaussians:
-    """Plain-torch restatement of GaussianAdapterERP.forward on flat tensors: extrinsics[V,4,4] (context panorama
-    c2w), depths / opacities[V,Gv] (Gv = h*w*per_ray, ray-major), raw_gaussians[V,Gv,7+3*d_sh] = (3 scale logits,
-    4 quaternion xyzw, 3*d_sh SH as (xyz d_sh)).  Returns tensors with leading dims [V,Gv]."""
-    h, w = image_shape
-    v, gv = depths.shape
-    d_sh = (raw_gaussians.shape[-1] - 7) // 3
-    scales, rot, sh = raw_gaussians.split((3, 4, 3 * d_sh), dim=-1)
-    scales = scale_min + (scale_max - scale_min) * scales.sigmoid()
-    scales = scales * depths[..., None] * (1 / max(w, h))
-    rot = rot / (rot.norm(dim=-1, keepdim=True) + eps)
-    sh = sh.reshape(v, gv, 3, d_sh) * sh_mask(d_sh).to(sh.device)
-    r = quaternion_to_matrix(rot)
-    s = scales.diag_embed()
-    cov = r @ s @ s.transpose(-1, -2) @ r.transpose(-1, -2)
-    c2w = extrinsics[:, None, :3, :3]
-    cov = c2w @ cov @ c2w.transpose(-1, -2)
-    dirs = erp_directions(h, w, depths.device).repeat_interleave(per_ray, 0)          # [Gv,3]
-    pts = dirs[None] * depths[..., None]
-    means = torch.einsum("vij,vgj->vgi", extrinsics[:, :3, :3], pts) + extrinsics[:, None, :3, 3]
-    harm = rotate_sh_blocks(sh, None if sh_rotation is None else sh_rotation[:, None, None])
-    return AdapterGaussians(means, cov, scales, rot, harm, opacities)
-
-
 def wigner_blocks_e3nn(c2w_rotations: Tensor, d_sh: int) -> Tensor:
     """[V,3,3] -> [V,d_sh,d_sh] block-diagonal Wigner-D matrices exactly as rotate_sh builds them
     (sh_rotation.py:19-24: matrix_to_angles + wigner_D per degree).  Needs e3nn (absent from this image)."""
@@ -124,12 +78,31 @@ def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+def sh_rotation_blocks(rotations: Tensor, d_sh: int) -> Tensor:
+    """[V,3,3] rotations (or [V,4,4] poses: their rotation part) -> [V,d_sh,d_sh] block-diagonal matrices of rotate_sh
+    (sh_rotation.py:19-24) from s360_sh_rotation_blocks: one launch, no host synchronisation, no e3nn.  Not differentiable
+    (the reference's poses carry no gradient)."""
+    if not rotations.is_cuda:
+        raise RuntimeError("sh_rotation_blocks runs on the GPU only (oracle/adapter_ref.py holds the CPU checker)")
+    r = rotations.detach().float().contiguous()
+    if r.dim() != 3 or tuple(r.shape[-2:]) not in ((3, 3), (4, 4)):
+        raise RuntimeError(f"rotations must be [V,3,3] or [V,4,4], got {tuple(r.shape)}")
+    v = int(r.shape[0])
+    out = torch.empty((v, d_sh, d_sh), dtype=torch.float32, device=r.device)
+    with torch.cuda.device(r.device):
+        stream = C.c_void_p(torch.cuda.current_stream(r.device).cuda_stream)
+        rc = _lib.lib().s360_sh_rotation_blocks(_ptr(r), 9 if r.shape[-1] == 3 else 16, v, int(d_sh), _ptr(out), stream)
+    _lib.check(rc, "s360_sh_rotation_blocks")
+    return out
+
+
 class _AdapterTail(torch.autograd.Function):
     @staticmethod
     def forward(ctx, extrinsics, depths, raw, sh_rot, cfg):
-        h, w, per_ray, smin, smax, eps, cov6 = cfg
+        h, w, per_ray, smin, smax, eps, cov6, diff_means = cfg
         if not depths.is_cuda:
-            raise RuntimeError("the fused adapter tail runs on the GPU only (adapter_tail_torch is the CPU restatement)")
+            raise RuntimeError("the fused adapter tail runs on the GPU only: depths is a CPU tensor (no CPU path; "
+                               "oracle/adapter_ref.py is the checker the tests use)")
         ext = extrinsics.detach().float().contiguous()
         dep = depths.detach().float().contiguous()
         rw = raw.detach().float().contiguous()
@@ -150,18 +123,21 @@ class _AdapterTail(torch.autograd.Function):
                                                  C.c_float(smin), C.c_float(smax), C.c_float(eps), _ptr(means), _ptr(cov),
                                                  int(not cov6), _ptr(harm), _ptr(scales), _ptr(rots), stream)
         _lib.check(rc, "s360_adapter_forward")
-        ctx.cfg = (h, w, per_ray, smin, smax, eps, cov6, v, gv, d_sh)
+        ctx.cfg = (h, w, per_ray, smin, smax, eps, cov6, v, gv, d_sh, diff_means)
         ctx.save_for_backward(ext, dep, rw, rot)
-        ctx.mark_non_differentiable(scales, rots)
+        if diff_means:
+            ctx.mark_non_differentiable(scales, rots)
+        else:   # the reference un-projects under torch.no_grad(): its means are detached (sphere_projection.py:14-86)
+            ctx.mark_non_differentiable(means, scales, rots)
         return means, cov, harm, scales, rots
 
     @staticmethod
     def backward(ctx, d_means, d_cov, d_harm, _ds, _dr):
         ext, dep, rw, rot = ctx.saved_tensors
-        h, w, per_ray, smin, smax, eps, cov6, v, gv, d_sh = ctx.cfg
+        h, w, per_ray, smin, smax, eps, cov6, v, gv, d_sh, diff_means = ctx.cfg
         dev = dep.device
         z = lambda t, shape: torch.zeros(shape, dtype=torch.float32, device=dev) if t is None else t.detach().float().contiguous()
-        d_means = z(d_means, (v, gv, 3))
+        d_means = z(d_means, (v, gv, 3)) if diff_means else None   # NULL at the ABI: means detached like the reference's
         d_cov = z(d_cov, (v, gv, 6) if cov6 else (v, gv, 3, 3))
         d_harm = z(d_harm, (v, gv, 3, d_sh))
         d_dep = torch.empty_like(dep)
@@ -177,26 +153,34 @@ class _AdapterTail(torch.autograd.Function):
 
 def adapter_tail(extrinsics: Tensor, depths: Tensor, opacities: Tensor, raw_gaussians: Tensor, image_shape,
                  scale_min: float, scale_max: float, sh_rotation: Optional[Tensor] = None, eps: float = 1e-8,
-                 per_ray: int = 1, cov6: bool = False) -> AdapterGaussians:
-    """Fused HIP form of adapter_tail_torch (same arguments / results; differentiable w.r.t. depths and raw_gaussians,
-    opacities pass through).  cov6=True returns the covariance as its 6 unique entries (00,01,02,11,12,22) — the
+                 per_ray: int = 1, cov6: bool = False, differentiable_means: bool = False) -> AdapterGaussians:
+    """The fused adapter tail (s360_adapter_forward / backward): extrinsics[V,4,4] (context panorama c2w), depths /
+    opacities[V,Gv] (Gv = h*w*per_ray, ray-major), raw_gaussians[V,Gv,7+3*d_sh] = (3 scale logits, 4 quaternion xyzw, 3*d_sh SH
+    as (xyz d_sh)); differentiable w.r.t. depths and raw_gaussians, opacities pass through.  Like the reference, whose sphere
+    un-projection runs under torch.no_grad() (src/geometry/sphere_projection.py:14-86), the returned means are DETACHED: depth
+    receives gradient through the scales only.  differentiable_means=True is this project's opt-in deviation (the
+    un-projection's own term is added).  cov6=True returns the covariance as its 6 unique entries (00,01,02,11,12,22) — the
     rasteriser's cov3D_precomp layout — instead of [.,3,3]."""
     h, w = image_shape
     means, cov, harm, scales, rots = _AdapterTail.apply(extrinsics, depths, raw_gaussians, sh_rotation,
                                                         (int(h), int(w), int(per_ray), float(scale_min), float(scale_max),
-                                                         float(eps), bool(cov6)))
+                                                         float(eps), bool(cov6), bool(differentiable_means)))
     return AdapterGaussians(means, cov, scales, rots, harm, opacities)
 
 
 class GaussianAdapterERP(torch.nn.Module):
     """Drop-in for the reference module (gaussian_adapter_erp.py:31-137): same constructor fields and forward
     arguments (dataset_name, extrinsics[b,v,1,1,1,4,4], depths[b,v,r,srf,spp], opacities, raw_gaussians[b,v,r,srf,1,c],
-    image_shape), same result container with the reference's shapes.  `sh_rotation`: "e3nn" (default: the
-    reference's Wigner-D matrices, needs e3nn), "identity", or a callable c2w_rotations[V,3,3] -> [V,d_sh,d_sh]."""
+    image_shape), same result container with the reference's shapes.  `sh_rotation`: "native" (default: the matrices of
+    rotate_sh from s360_sh_rotation_blocks), "e3nn" (wigner_blocks_e3nn: the reference's own construction, needs e3nn),
+    "identity", or a callable c2w_rotations[V,3,3] -> [V,d_sh,d_sh].  GPU tensors only.  differentiable_means: see
+    adapter_tail (default False = the reference's detached means)."""
 
-    def __init__(self, gaussian_scale_min: float, gaussian_scale_max: float, sh_degree: int, sh_rotation="e3nn"):
+    def __init__(self, gaussian_scale_min: float, gaussian_scale_max: float, sh_degree: int, sh_rotation="native",
+                 differentiable_means: bool = False):
         super().__init__()
         self.scale_min, self.scale_max, self.sh_degree, self.sh_rotation = gaussian_scale_min, gaussian_scale_max, sh_degree, sh_rotation
+        self.differentiable_means = bool(differentiable_means)
         self.register_buffer("sh_mask", sh_mask(self.d_sh), persistent=False)
 
     @property
@@ -208,6 +192,9 @@ class GaussianAdapterERP(torch.nn.Module):
         return 7 + 3 * self.d_sh
 
     def forward(self, dataset_name, extrinsics, depths, opacities, raw_gaussians, image_shape, eps: float = 1e-8):
+        if not depths.is_cuda:
+            raise RuntimeError("GaussianAdapterERP runs on the GPU only: depths is a CPU tensor (no CPU path in the product; "
+                               "oracle/adapter_ref.py is the checker the tests use)")
         if dataset_name not in ("hm3d", "replica"):
             raise Exception(f"ERP convention of dataset {dataset_name!r} is not implemented (utils360.py:93-104 'hm3d'/'replica' only)")
         b, v, r, srf, spp = depths.shape
@@ -217,14 +204,15 @@ class GaussianAdapterERP(torch.nn.Module):
         ext = extrinsics.reshape(b * v, 4, 4)
         if self.sh_rotation == "identity":
             rot = None
+        elif self.sh_rotation == "native":
+            rot = sh_rotation_blocks(ext, self.d_sh)
         elif self.sh_rotation == "e3nn":
             rot = wigner_blocks_e3nn(ext[:, :3, :3], self.d_sh)
         else:
             rot = self.sh_rotation(ext[:, :3, :3])
         raw = raw_gaussians.broadcast_to(b, v, r, srf, spp, self.d_in).reshape(b * v, r * srf * spp, self.d_in)
-        fn = adapter_tail if depths.is_cuda else adapter_tail_torch
-        g = fn(ext, depths.reshape(b * v, -1), opacities.reshape(b * v, -1), raw, (h, w), self.scale_min, self.scale_max,
-               sh_rotation=rot, eps=eps, per_ray=srf * spp)
+        g = adapter_tail(ext, depths.reshape(b * v, -1), opacities.reshape(b * v, -1), raw, (h, w), self.scale_min, self.scale_max,
+                         sh_rotation=rot, eps=eps, per_ray=srf * spp, differentiable_means=self.differentiable_means)
         sh5 = (b, v, r, srf, spp)
         return AdapterGaussians(g.means.reshape(*sh5, 3), g.covariances.reshape(*sh5, 3, 3), g.scales.reshape(*sh5, 3),
                                 g.rotations.reshape(*sh5, 4), g.harmonics.reshape(*sh5, 3, self.d_sh), opacities)

@@ -7,13 +7,14 @@
 //   Sigma    = C R(q^) diag(scales^2) R(q^)^T C^T   (R: gaussians.py:8-31, xyzw; C = c2w rotation)   (:89-92)
 //   mean     = C (dir(pixel) * depth) + t           (sphere_projection.py:6-86, utils360.py:93-104,148-153)
 //   harmonics= D_l (sh * sh_mask) per degree l      (:38-47,86; rotate_sh, src/misc/sh_rotation.py:10-30 — the
-//              Wigner-D blocks are an input: e3nn builds them on the host side, one d_sh x d_sh matrix per view)
+//              Wigner-D blocks, one d_sh x d_sh matrix per view, come from k_sh_rotation_blocks below or from the caller)
 // instead of ~20 torch launches with their [G,3,3] intermediates.  grid.y = view, so everything that depends on the
 // view only (pose, SH rotation blocks) is wave-uniform.  Streaming: 336 B read, 352 B (cov6: 340 B) written per Gaussian.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "../../include/s360.h"
+#include "s360_shrot_tables.h"
 
 namespace s360 {
 
@@ -240,9 +241,12 @@ __global__ __launch_bounds__(256) void k_adapter_bwd(AdapterParams ap, const flo
     }
     float d[3];
     erp_dir(g / ap.per_ray, ap.H, ap.W, d);
-    const float* gm = d_means + 3 * i;
+    if (d_means) {  // opt-in: the reference un-projects under torch.no_grad() (sphere_projection.py:14-86) — its means are
+                    // detached and depth receives gradient through the scales only (d_means == NULL, the default)
+        const float* gm = d_means + 3 * i;
 #pragma unroll
-    for (int x = 0; x < 3; ++x) dd += (E[x] * gm[0] + E[4 + x] * gm[1] + E[8 + x] * gm[2]) * d[x];  // (C^T dmean) . dir
+        for (int x = 0; x < 3; ++x) dd += (E[x] * gm[0] + E[4 + x] * gm[1] + E[8 + x] * gm[2]) * d[x];  // (C^T dmean) . dir
+    }
     d_depths[i] = dd;
     // harmonics
     const int deg = ap.d_sh == 25 ? 4 : ap.d_sh == 16 ? 3 : ap.d_sh == 9 ? 2 : ap.d_sh == 4 ? 1 : 0;
@@ -268,7 +272,76 @@ __global__ __launch_bounds__(256) void k_adapter_bwd(AdapterParams ap, const flo
     }
 }
 
+// ---- rotate_sh's matrices (src/misc/sh_rotation.py:19-24: wigner_D(l, *matrix_to_angles(R)) per degree) --------------------
+// D^l(R) is defined by Y^l(R d) = D^l(R) Y^l(d) in e3nn's real basis (polar axis y, azimuth from z towards x, m = -l..l, no
+// Condon-Shortley phase: l = 1 is (x, y, z), so D^1 = R).  One thread per (view, degree): evaluate Y^l at the 2l+1 tabulated
+// directions rotated by R and multiply by the tabulated inverse of the unrotated basis matrix (s360_shrot_tables.h).  float64:
+// the work is a few hundred flops per view and the blocks multiply every Gaussian's coefficients.
+__device__ inline void e3nn_sh(int l, double x, double y, double z, double* out) {
+    double q[5];  // d^m P_l / dy^m
+    switch (l) {
+        case 0: q[0] = 1.0; break;
+        case 1: q[0] = y; q[1] = 1.0; break;
+        case 2: q[0] = (3.0 * y * y - 1.0) * 0.5; q[1] = 3.0 * y; q[2] = 3.0; break;
+        case 3: q[0] = (5.0 * y * y * y - 3.0 * y) * 0.5; q[1] = (15.0 * y * y - 3.0) * 0.5; q[2] = 15.0 * y; q[3] = 15.0; break;
+        default: q[0] = (35.0 * y * y * y * y - 30.0 * y * y + 3.0) * 0.125; q[1] = (35.0 * y * y * y - 15.0 * y) * 0.5;
+                 q[2] = (105.0 * y * y - 15.0) * 0.5; q[3] = 105.0 * y; q[4] = 105.0; break;
+    }
+    out[l] = q[0];
+    double re = 1.0, im = 0.0, fact = 1.0;  // (z + i x)^m; fact = (l+m)!/(l-m)!
+    for (int m = 1; m <= l; ++m) {
+        const double nre = re * z - im * x, nim = re * x + im * z;
+        re = nre; im = nim;
+        fact *= (double)((l + m) * (l - m + 1));
+        const double n = sqrt(2.0 / fact);
+        out[l - m] = n * q[m] * im;
+        out[l + m] = n * q[m] * re;
+    }
+}
+
+__global__ void k_sh_rotation_blocks(const float* __restrict__ rotations, int stride, int n_views, int d_sh, int deg,
+                                     float* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int v = t / 5, l = t - 5 * v;
+    if (v >= n_views) return;
+    float* o = out + (size_t)v * d_sh * d_sh;
+    if (l == 0)  // this thread also clears the off-block entries of the view's matrix
+        for (int i = 0; i < d_sh; ++i)
+            for (int j = 0; j < d_sh; ++j) {
+                int li = 0, lj = 0;
+                while ((li + 1) * (li + 1) <= i) ++li;
+                while ((lj + 1) * (lj + 1) <= j) ++lj;
+                if (li != lj) o[i * d_sh + j] = 0.f;
+            }
+    if (l > deg) return;
+    const float* Rm = rotations + (size_t)v * stride;  // row-major 3x3, row stride 3 (stride 9) or 4 (a [4,4] pose, stride 16)
+    const int rs = stride == 16 ? 4 : 3;
+    const int n = 2 * l + 1;
+    const double(*dirs)[3] = l == 0 ? kShRotDir0 : l == 1 ? kShRotDir1 : l == 2 ? kShRotDir2 : l == 3 ? kShRotDir3 : kShRotDir4;
+    double B[9][9];  // B[m][i] = Y_m(R d_i)
+    for (int i = 0; i < n; ++i) {
+        const double dx = dirs[i][0], dy = dirs[i][1], dz = dirs[i][2];
+        double u[3];
+        for (int a = 0; a < 3; ++a) u[a] = (double)Rm[a * rs] * dx + (double)Rm[a * rs + 1] * dy + (double)Rm[a * rs + 2] * dz;
+        const double inv = 1.0 / sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);  // R is only float32-orthonormal
+        double y[9];
+        e3nn_sh(l, u[0] * inv, u[1] * inv, u[2] * inv, y);
+        for (int m = 0; m < n; ++m) B[m][i] = y[m];
+    }
+    for (int m = 0; m < n; ++m)
+        for (int m2 = 0; m2 < n; ++m2) {
+            double acc = 0.0;
+            for (int i = 0; i < n; ++i) {
+                const double a = l == 0 ? kShRotInv0[i][m2] : l == 1 ? kShRotInv1[i][m2] : l == 2 ? kShRotInv2[i][m2]
+                                 : l == 3 ? kShRotInv3[i][m2] : kShRotInv4[i][m2];
+                acc += B[m][i] * a;
+            }
+            o[(l * l + m) * d_sh + l * l + m2] = (float)acc;
+        }
+}
+
 }  // namespace s360
+
 
 using namespace s360;
 
@@ -300,12 +373,24 @@ extern "C" int s360_adapter_backward(const float* extrinsics, const float* depth
                                      int32_t per_ray, int32_t d_sh, float scale_min, float scale_max, float eps,
                                      const float* d_means, const float* d_covariances, int32_t cov9, const float* d_harmonics,
                                      float* d_depths, float* d_raw_gaussians, void* stream) {
-    if (!adapter_args_ok(extrinsics, depths, raw_gaussians, n_views, per_view, H, W, per_ray, d_sh) || !d_means ||
+    if (!adapter_args_ok(extrinsics, depths, raw_gaussians, n_views, per_view, H, W, per_ray, d_sh) ||
         !d_covariances || !d_harmonics || !d_depths || !d_raw_gaussians)
         return S360_E_BADARG;
     if (n_views == 0 || per_view == 0) return S360_OK;
     AdapterParams ap = {n_views, per_view, H, W, per_ray, d_sh, cov9, scale_min, scale_max, eps};
     hipLaunchKernelGGL(k_adapter_bwd, dim3((per_view + 255) / 256, n_views), dim3(256), 0, (hipStream_t)stream, ap, extrinsics,
                        depths, raw_gaussians, sh_rotation, d_means, d_covariances, d_harmonics, d_depths, d_raw_gaussians);
+    return hipGetLastError() == hipSuccess ? S360_OK : S360_E_LAUNCH;
+}
+
+extern "C" int s360_sh_rotation_blocks(const float* rotations, int32_t row_major_stride, int32_t n_views, int32_t d_sh,
+                                       float* sh_rotation_out, void* stream) {
+    if (!rotations || !sh_rotation_out || n_views < 0 || (row_major_stride != 9 && row_major_stride != 16)) return S360_E_BADARG;
+    if (d_sh != 1 && d_sh != 4 && d_sh != 9 && d_sh != 16 && d_sh != 25) return S360_E_BADARG;
+    if (n_views == 0) return S360_OK;
+    const int deg = d_sh == 25 ? 4 : d_sh == 16 ? 3 : d_sh == 9 ? 2 : d_sh == 4 ? 1 : 0;
+    const int threads = n_views * 5;
+    hipLaunchKernelGGL(k_sh_rotation_blocks, dim3((threads + 63) / 64), dim3(64), 0, (hipStream_t)stream, rotations,
+                       row_major_stride, n_views, d_sh, deg, sh_rotation_out);
     return hipGetLastError() == hipSuccess ? S360_OK : S360_E_LAUNCH;
 }

@@ -200,6 +200,20 @@ def reduce_scatter_gradients(grads: Sequence[Tensor], group=None) -> List[Tensor
     return [o[:n].reshape(n, *tail) for o, n, tail in outs]
 
 
+def rank_report(device) -> dict:
+    """What the communicator actually is, for the bench line: backend, world size as the process group reports it, and the
+    device index every rank is pinned to (gathered)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        idx = torch.cuda.current_device() if (torch.cuda.is_available() and torch.device(device).type == "cuda") else -1
+        return {"backend": None, "rccl_ranks": 1, "rank_devices": [idx]}
+    world = dist.get_world_size()
+    idx = torch.cuda.current_device() if torch.device(device).type == "cuda" else -1
+    mine = torch.tensor([idx], dtype=torch.int64, device=device)
+    out = torch.empty(world, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(out, mine)
+    return {"backend": dist.get_backend(), "rccl_ranks": world, "rank_devices": [int(x) for x in out.cpu()]}
+
+
 def max_over_ranks(value: float, device) -> float:
     if not (dist.is_available() and dist.is_initialized()):
         return value

@@ -265,3 +265,28 @@ def test_four_rank_pipelined_factored_exchange_and_reduce_scatter():
         lo, hi = rank * per, min(257, (rank + 1) * per)
         np.testing.assert_allclose(mine[0], full_m[lo:hi], rtol=1e-12, atol=1e-12)
         np.testing.assert_allclose(mine[1], full_c[lo:hi], rtol=1e-12, atol=1e-12)
+
+
+def test_bench_launches_its_own_ranks_when_started_plainly():
+    """`python bench.py --gpus 2` with no torchrun environment (how the driver starts the N = 1 run): bench.py re-launches itself
+    under torch.distributed.run, one process per rank, and rank 0 prints ONE JSON line that says what the communicator saw.
+    --dry-run keeps the GPU work out (there is none here); backend gloo."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["S360_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--dry-run", "1", "--steps", "2"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["backend"] == "gloo" and d["allreduce_ok"] and len(d["rank_devices"]) == 2
+    # N = 1 started plainly stays a single process (no launcher, no process group)
+    r1 = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "1", "--dry-run", "1", "--steps", "1"], env=env,
+                        capture_output=True, text=True, timeout=300)
+    d1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][0])
+    assert r1.returncode == 0 and d1["n_gpus"] == 1 and d1["rccl_ranks"] == 1 and d1["backend"] is None

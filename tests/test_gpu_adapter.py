@@ -1,12 +1,15 @@
-"""Fused adapter-tail kernels (s360_adapter_forward / backward) against the golden capture of the reference's
-GaussianAdapterERP (rotate_sh = identity, see tests/golden/make_golden_adapter.py) and against the torch restatement
-(values and autograd gradients), with and without SH rotation blocks, [.,3,3] and 6-entry covariance layouts."""
+"""Fused adapter-tail kernels (s360_adapter_forward / backward, s360_sh_rotation_blocks) against the golden capture of the
+reference's GaussianAdapterERP (values and the reference module's own autograd gradients; rotate_sh = identity, see
+tests/golden/make_golden_adapter.py), against the torch restatement in oracle/adapter_ref.py (values and autograd gradients,
+detached and opt-in differentiable means, with and without SH rotation blocks, [.,3,3] and 6-entry covariance layouts) and,
+for rotate_sh's matrices, against the oracle's float64 construction."""
 from pathlib import Path
 
 import numpy as np
 import pytest
 import torch
 
+from oracle import adapter_ref
 from splatter360_amd import adapter, decoder, synthetic
 
 pytestmark = pytest.mark.gpu
@@ -24,6 +27,21 @@ def test_fused_tail_matches_reference_capture(gpu):
                        ("scales", g["scales"]), ("rotations", g["rotations"]), ("opacities", g["opacities"])):
         got = getattr(out, name).cpu().numpy().reshape(want.shape)
         np.testing.assert_allclose(got, want, rtol=3e-6, atol=3e-6 * np.abs(want).max(), err_msg=name)
+
+
+def test_fused_tail_gradients_match_the_reference_modules_autograd(gpu):
+    """d_depths / d_raw_gaussians of the reference module itself (means detached: its un-projection runs under no_grad)."""
+    g = np.load(G / "adapter_erp_tail.npz")
+    t = lambda k: torch.tensor(g[k], device=gpu)
+    h, w = (int(x) for x in g["image_shape"])
+    mod = adapter.GaussianAdapterERP(float(g["scale_min"]), float(g["scale_max"]), 4, sh_rotation="identity").to(gpu)
+    d = t("depths").requires_grad_(True)
+    raw = t("raw_gaussians").requires_grad_(True)
+    out = mod("hm3d", t("extrinsics")[:, :, None, None, None], d, t("opacities_in"), raw, (h, w))
+    assert not out.means.requires_grad
+    ((out.covariances * t("cot_covariances")).sum() + (out.harmonics * t("cot_harmonics")).sum()).backward()
+    for got, want in ((d.grad, g["d_depths"]), (raw.grad, g["d_raw_gaussians"])):
+        np.testing.assert_allclose(got.cpu().numpy().reshape(want.shape), want, rtol=1e-4, atol=2e-5 * np.abs(want).max())
 
 
 def _random_case(gpu, v, h, w, seed, with_rot):
@@ -46,9 +64,10 @@ def _random_case(gpu, v, h, w, seed, with_rot):
     return tt(ext), tt(dep), tt(opa), tt(raw), tt(rot)
 
 
+@pytest.mark.parametrize("diff_means", [False, True])
 @pytest.mark.parametrize("with_rot", [False, True])
 @pytest.mark.parametrize("cov6", [False, True])
-def test_fused_tail_values_and_gradients_match_torch_autograd(gpu, with_rot, cov6):
+def test_fused_tail_values_and_gradients_match_torch_autograd(gpu, with_rot, cov6, diff_means):
     v, h, w = 3, 12, 24
     ext, dep, opa, raw, rot = _random_case(gpu, v, h, w, 5 + with_rot, with_rot)
     res = []
@@ -60,13 +79,14 @@ def test_fused_tail_values_and_gradients_match_torch_autograd(gpu, with_rot, cov
         d = dep.clone().requires_grad_(True)
         rw = raw.clone().requires_grad_(True)
         if fused:
-            out = adapter.adapter_tail(ext, d, opa, rw, (h, w), 0.5, 15.0, sh_rotation=rot, cov6=cov6)
+            out = adapter.adapter_tail(ext, d, opa, rw, (h, w), 0.5, 15.0, sh_rotation=rot, cov6=cov6, differentiable_means=diff_means)
             cov_term = (out.covariances * wc[:, :, r_, c_]).sum() if cov6 else (out.covariances * wc).sum()
         else:
-            out = adapter.adapter_tail_torch(ext, d, opa, rw, (h, w), 0.5, 15.0, sh_rotation=rot)
+            out = adapter_ref.adapter_tail_torch(ext, d, opa, rw, (h, w), 0.5, 15.0, sh_rotation=rot, differentiable_means=diff_means)
             # the 6-entry layout reads the upper triangle only (cuda_splatting.py:115,123)
             cov_term = (out.covariances[:, :, r_, c_] * wc[:, :, r_, c_]).sum() if cov6 else (out.covariances * wc).sum()
-        ((out.means * wm).sum() + cov_term + (out.harmonics * wh).sum()).backward()
+        assert out.means.requires_grad == diff_means
+        ((out.means * wm).sum() * (1.0 if diff_means else 0.0) + cov_term + (out.harmonics * wh).sum()).backward()
         res.append((out, d.grad, rw.grad))
     (ot, dt, rt), (of, df, rf) = res
     cov_t = ot.covariances[:, :, r_, c_] if cov6 else ot.covariances
@@ -96,3 +116,36 @@ def test_adapter_feeds_the_rasteriser_without_the_3x3_materialisation(gpu):
                                         views=views, image_height=64, image_width=64, sh_degree=4, shared_campos=True,
                                         sh_channel_major=True, want_radii=False)
     assert torch.equal(got, ref) and ref.abs().max().item() > 0
+
+
+def test_native_sh_rotation_blocks_match_the_float64_construction(gpu):
+    """s360_sh_rotation_blocks (rotate_sh's matrices, sh_rotation.py:19-24) against oracle/adapter_ref.wigner_blocks — and, through
+    the module's default sh_rotation="native", rotated harmonics against the torch restatement fed those float64 matrices."""
+    from scipy.spatial.transform import Rotation
+    R = Rotation.random(6, random_state=11).as_matrix().astype(np.float32)
+    want = adapter_ref.wigner_blocks(R, 25)
+    got = adapter.sh_rotation_blocks(torch.tensor(R, device=gpu), 25).cpu().numpy()
+    np.testing.assert_allclose(got, want, atol=3e-6)           # float32 rotation in, float64 inside, float32 out
+    pose = np.tile(np.eye(4, dtype=np.float32), (6, 1, 1))
+    pose[:, :3, :3] = R
+    pose[:, :3, 3] = 1.5
+    np.testing.assert_array_equal(adapter.sh_rotation_blocks(torch.tensor(pose, device=gpu), 25).cpu().numpy(), got)
+    for d_sh in (1, 4, 9, 16):
+        np.testing.assert_allclose(adapter.sh_rotation_blocks(torch.tensor(R, device=gpu), d_sh).cpu().numpy(), want[:, :d_sh, :d_sh], atol=3e-6)
+    v, h, w = 6, 4, 8
+    ext, dep, opa, raw, _ = _random_case(gpu, v, h, w, 21, False)
+    ext[:, :3, :3] = torch.tensor(R, device=gpu)
+    mod = adapter.GaussianAdapterERP(0.5, 15.0, 4).to(gpu)      # default: native rotate_sh
+    out = mod("hm3d", ext[None, :, None, None, None], dep[None, :, :, None, None], opa[None, :, :, None, None],
+              raw[None, :, :, None, None, :], (h, w))
+    ref = adapter_ref.adapter_tail_torch(ext.cpu(), dep.cpu(), opa.cpu(), raw.cpu(), (h, w), 0.5, 15.0,
+                                         sh_rotation=torch.tensor(want, dtype=torch.float32))
+    np.testing.assert_allclose(out.harmonics.cpu().numpy().reshape(v, h * w, 3, 25), ref.harmonics.numpy(), atol=2e-6)
+
+
+def test_native_sh_rotation_blocks_against_e3nn_where_it_exists(gpu):
+    pytest.importorskip("e3nn")
+    from scipy.spatial.transform import Rotation
+    R = torch.tensor(Rotation.random(4, random_state=5).as_matrix(), dtype=torch.float32)
+    want = adapter.wigner_blocks_e3nn(R, 25).numpy()
+    np.testing.assert_allclose(adapter.sh_rotation_blocks(R.to(gpu), 25).cpu().numpy(), want, atol=1e-5)

@@ -121,4 +121,9 @@ def test_fuzz_multi_view_fused_call_against_per_view_oracle(gpu, seed, shared):
         # amplifies 1e-6 differences of the raster gradients ~1000x (scripts/fuzz_diag2.py: its screen-space, covariance
         # and opacity gradients agree with the float64 oracle to 2e-6 / 1.4e-4 / 1.2e-5 — as close as the float32 oracle's
         # — while dL/dmean is off by 2e-3 (HIP) and 2.4e-4 (float32 oracle): conditioning, not a composite error).
-        assert e_hip <= max(1.5e-3, 3.0 * e_o32), (e_hip, e_o32)
+        from test_gpu_headline_parity import _report
+        _report(f"fuzz_views_seed{seed}_{'shared' if shared else 'perview'}_{tuple(p.shape)[1:]}", e_hip=e_hip, e_o32=e_o32)
+        # Floor 2e-4 (measured: <= 1.4e-4 on eleven of the twelve cases, 0.3x .. 2.2x the float32 oracle's own distance); the
+        # means of seed 2 keep the wide bar: that cloud holds the splat described above
+        ill = seed == 2 and p is ps[0]
+        assert e_hip <= (max(1.5e-3, 3.0 * e_o32) if ill else max(2e-4, 2.5 * e_o32)), (e_hip, e_o32)

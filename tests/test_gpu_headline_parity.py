@@ -73,11 +73,22 @@ def _check_face_forward(fs, img, f, tag, gx_gy):
     np.testing.assert_array_equal(fs["tile_start"][1:][nonempty], f["ranges"][nonempty, 1])
     st = _pixel_stats(img, f["image"])
     mism = float((fs["n_contrib"] != f["n_contrib"]).mean())
-    _report(tag, n_contrib_mismatch=mism, longest_list=int(np.diff(fs["tile_start"]).max()), num_rendered=int(L), **st)
-    assert st["mean"] <= 1e-5, (tag, st)
-    assert st["p999"] <= 5e-5 and st["max"] <= 2e-4, (tag, st)   # max: a pixel where alpha sits within ulps of 1/255 or T of 1e-4
-    assert mism <= 2e-3, (tag, mism)
-    np.testing.assert_allclose(fs["final_T"], f["final_T"], rtol=0, atol=5e-5)
+    amax = float(np.abs(f["image"]).max())
+    _report(tag, n_contrib_mismatch=mism, longest_list=int(np.diff(fs["tile_start"]).max()), num_rendered=int(L), image_absmax=amax, **st)
+    # north_star: "<= 1e-5 per-pixel L1" (of images in [0, 1]) — asserted on the MAXIMUM over pixels, relative to the image's
+    # own range where the synthetic SH colours exceed 1 (measured: mean 2.8e-8, max 3.6e-7 at 1 M, no n_contrib mismatch at
+    # any of these sizes; 1.2e-5 on one pixel of a 4 M polar face behind an 18.8 K-key list); a regression of one order of
+    # magnitude fails here
+    per_px = np.abs(img.astype(np.float64) - f["image"]).mean(0)
+    over = per_px > 1e-5 * max(1.0, amax)
+    # a pixel may sit behind an entry whose alpha lands within an ulp of 1/255 on opposite sides in v_exp_f32 and libm: one
+    # accepts it, the other does not (n_contrib, the LAST contributor, need not change) — an O(alpha T) = 1e-5-sized legitimate
+    # difference.  Seen once: one pixel of 1.57 M on the 4 M polar face (1.17e-5).  Allowed: one such pixel per 200 000, <= 5e-5.
+    assert int(over.sum()) <= per_px.size // 200_000 and st["max"] <= 5e-5, (tag, st, int(over.sum()))
+    assert st["p999"] <= 1e-6 and st["mean"] <= 1e-7, (tag, st, amax)
+    assert mism <= 1e-5, (tag, mism)
+    dT = np.abs(fs["final_T"].astype(np.float64) - f["final_T"])
+    assert int((dT > 2e-6).sum()) <= per_px.size // 200_000 and dT.max() <= 2e-5, (tag, float(dT.max()), int((dT > 2e-6).sum()))
 
 
 def _grad_err(got, want64, want32=None):
@@ -128,7 +139,7 @@ def test_1m_all_six_faces_forward_vs_oracle(gpu, cloud1m, params1m):
         _check_face_forward(_face_state(t, face, P, 256), faces[face], f, f"1m_face{face}_fwd", 256)
 
 
-@pytest.mark.parametrize("face", [0, 2])   # 0 = top (polar: lists of up to ~13 K keys), 2 = a side face
+@pytest.mark.parametrize("face", range(6))   # 0 / 5 = polar faces (lists of up to ~13 K keys), 1..4 = side faces
 def test_1m_backward_vs_oracle(gpu, cloud1m, params1m, face):
     rng = np.random.default_rng(100 + face)
     gimg = rng.standard_normal((3, 256, 256)).astype(np.float32)
@@ -152,7 +163,7 @@ def test_1m_backward_vs_oracle(gpu, cloud1m, params1m, face):
     for k in got:
         e, e32 = _grad_err(got[k], np.asarray(g64[k]) * fold[k], np.asarray(g32[k], np.float64) * fold[k])
         rep[k], rep[k + "_oracle_f32"] = e, e32
-        assert e <= max(2e-4, 2.0 * e32), (face, k, e, e32)
+        assert e <= max(1e-4, 1.1 * e32), (face, k, e, e32)    # measured: within 1.000x of the float32 oracle's own distance
     _report(f"1m_face{face}_bwd_rel_err_vs_f64_oracle", **rep)
 
 
@@ -186,7 +197,7 @@ def test_1m_fused_six_face_gradient_equals_sum_of_oracle_backwards(gpu, cloud1m,
     rep = {}
     for k in got:
         rep[k], _ = _grad_err(got[k], tot[k])
-        assert rep[k] <= 5e-4, (k, rep[k])
+        assert rep[k] <= 2e-4, (k, rep[k])      # measured <= 7.7e-5
     _report("1m_fused6_l2loss_bwd_rel_err_vs_f64_oracle_sum", **rep)
 
 
@@ -215,8 +226,49 @@ def test_4m_512_face_forward_backward_vs_oracle(gpu):
     rep = {}
     for k in got:   # float32 oracle only (its own rounding is part of the distance): looser bar than the f64 comparison
         rep[k], _ = _grad_err(got[k], np.asarray(g32[k], np.float64) * fold[k])
-        assert rep[k] <= 2e-3, (k, rep[k])
+        assert rep[k] <= 5e-5, (k, rep[k])      # measured <= 2.5e-6
     _report("4m_512_face2_bwd_rel_err_vs_f32_oracle", **rep)
+
+
+def test_4m_512_fused_six_faces_forward_backward_vs_oracle(gpu):
+    """BASELINE configs[4], one rank's whole share: ONE fused call renders the six 512x512 faces of a 2048x1024 panorama from
+    4 194 304 Gaussians, L2 loss on the faces, backward — every face's integer state and pixels against the oracle, the
+    summed gradient against the sum of six float32-oracle backwards (the float64 oracle needs ~6 x 40 s at this size)."""
+    cloud = synthetic.encoder_like_cloud(1024, 2048, seed=0)
+    P = cloud["means"].shape[0]
+    ps = [torch.tensor(cloud[k], device=gpu).requires_grad_(True) for k in ("means", "covariances", "harmonics", "opacities")]
+    ext, K, near, far = decoder.cube_cameras(torch.eye(4, device=gpu), 0.1, 10.0)
+    views = decoder.pack_camera_views(ext, K, near, far, torch.zeros(3, device=gpu))
+    faces = decoder.render_views_fused(ext, K, near, far, (512, 512), torch.zeros(3, device=gpu), *ps, views=views)
+    st = rasterizer.last_state()
+    assert not st.overflowed()
+    gt = torch.full_like(faces, 0.5)
+    ((faces - gt) ** 2).mean().backward()
+    seed = (2.0 / faces.numel() * (faces.detach() - gt)).cpu().numpy()
+    t = st.tensors()
+    img = faces.detach().cpu().numpy()
+    tot = dict(means3D=np.zeros((P, 3)), cov3D=np.zeros((P, 6)), shs=np.zeros((P, 25, 3)), opacities=np.zeros((P, 1)))
+    for face in range(6):
+        S = settings_from_views(views, face, 512, 512)
+        means, cov6, shs, opac = boundary_tensors(cloud, S["scale"])
+        o = oracle.rasterize(S, means3D=means, cov3D_precomp=cov6, opacities=opac, shs=shs)
+        f = o.forward()
+        _check_face_forward(_face_state(t, face, P, 1024), img[face], f, f"4m_512_fused_face{face}_fwd", 1024)
+        g = o.backward(seed[face])
+        sc = np.float64(S["scale"])
+        tot["means3D"] += np.asarray(g["means3D"], np.float64) * sc
+        tot["cov3D"] += np.asarray(g["cov3D"], np.float64) * sc * sc
+        tot["shs"] += np.asarray(g["shs"], np.float64)
+        tot["opacities"] += np.asarray(g["opacities"], np.float64).reshape(P, 1)
+        del o
+    r, c = np.triu_indices(3)
+    got = dict(means3D=ps[0].grad.cpu().numpy(), cov3D=ps[1].grad.cpu().numpy()[:, r, c],
+               shs=ps[2].grad.cpu().numpy().transpose(0, 2, 1), opacities=ps[3].grad.cpu().numpy().reshape(P, 1))
+    rep = {}
+    for k in got:
+        rep[k], _ = _grad_err(got[k], tot[k])
+        assert rep[k] <= 2e-4, (k, rep[k])
+    _report("4m_512_fused6_l2loss_bwd_rel_err_vs_f32_oracle_sum", **rep)
 
 
 @pytest.mark.parametrize("mode", ["depth", "disparity", "relative_disparity", "log"])
@@ -241,7 +293,7 @@ def test_eval_shape_colour_and_depth_vs_oracle(gpu, cloud1m, params1m, mode):
     means, cov6, shs, opac = boundary_tensors(cloud1m, S["scale"])
     f = oracle.rasterize(S, means3D=means, cov3D_precomp=cov6, opacities=opac, shs=shs).forward()
     st = _pixel_stats(col[face].cpu().numpy(), f["image"])
-    assert st["mean"] <= 1e-5 and st["max"] <= 2e-4, st
+    assert st["mean"] <= 1e-7 and st["max"] <= 1e-5, st
     z = decoder._depth_colors(ext[face:face + 1].cpu(), torch.tensor(cloud1m["means"])[None], near[face:face + 1].cpu(),
                               far[face:face + 1].cpu(), mode)[0].numpy()
     fd = oracle.rasterize(S, means3D=means, cov3D_precomp=cov6, opacities=opac,
@@ -252,7 +304,7 @@ def test_eval_shape_colour_and_depth_vs_oracle(gpu, cloud1m, params1m, mode):
     d = np.abs(got - want)
     _report(f"eval_1m_{mode}_pano{pi}_face{face}", colour_mean=st["mean"], colour_max=st["max"], depth_mean_rel=float(d.mean() / scale),
             depth_max_rel=float(d.max() / scale), depth_scale=scale)
-    assert d.mean() <= 1e-5 * scale and d.max() <= 5e-4 * scale, (mode, d.mean(), d.max(), scale)
+    assert d.mean() <= 1e-6 * scale and d.max() <= 1e-5 * scale, (mode, d.mean(), d.max(), scale)
 
 
 def test_render_cuda_orthographic_vs_oracle(gpu):
@@ -278,7 +330,7 @@ def test_render_cuda_orthographic_vs_oracle(gpu):
     assert f["num_rendered"] > 1000            # the cloud is actually in view
     st = _pixel_stats(img, f["image"])
     _report("orthographic_a9", **st, num_rendered=int(f["num_rendered"]))
-    assert st["mean"] <= 1e-5 and st["max"] <= 2e-4, st
+    assert st["mean"] <= 1e-7 and st["max"] <= 1e-5, st
 
 
 def test_sh_degree4_ignored_switch(gpu):

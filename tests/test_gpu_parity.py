@@ -69,13 +69,19 @@ def check_forward(h, f, P, H, W):
     # colours (SH evaluated with the oracle's rounding) and clamp flags
     rgb = np.stack([st["rec_b"][0][:, 2], st["rec_b"][0][:, 3], st["rec_c"][0][:, 0]], 1)
     np.testing.assert_allclose(rgb[vis], f["rgb"][vis], rtol=0, atol=2e-6)
-    l1 = np.abs(h["image"] - f["image"]).mean()
-    assert l1 <= 1e-5, l1
-    assert np.abs(h["image"] - f["image"]).max() <= 2e-4
+    # north_star: <= 1e-5 per-pixel L1.  Asserted on the maximum over the pixels whose n_contrib agrees with the oracle's; a
+    # pixel where exp() lands within an ulp of the 1/255 or 1e-4 threshold on opposite sides in v_exp_f32 and libm takes a
+    # different accept / stop decision (a legitimate O(alpha) difference): such pixels are counted, not hidden — at most
+    # one per 20 000 pixels (none on any committed case)
+    per_px = np.abs(h["image"].astype(np.float64) - f["image"]).mean(0)
     nc = st["n_contrib"][0].astype(np.uint32)
-    mism = (nc != f["n_contrib"]).mean()
-    assert mism <= 1e-3, mism   # exp() differs by ulps between v_exp_f32 and libm at the 1/255 and 1e-4 thresholds
-    np.testing.assert_allclose(st["final_T"][0], f["final_T"], rtol=0, atol=2e-5)
+    same = nc == f["n_contrib"]
+    assert per_px.mean() <= 1e-6, per_px.mean()
+    assert per_px[same].max(initial=0.0) <= 1e-5, per_px[same].max()
+    assert (~same).sum() <= same.size // 20000, int((~same).sum())
+    # T = prod(1 - alpha): one factor with alpha near its 0.99 clamp amplifies the ulp of exp() a hundredfold (measured 5.5e-6
+    # on the fuzz scenes, whose opacities reach 1; 2e-6 holds at the headline sizes and is asserted there)
+    np.testing.assert_allclose(st["final_T"][0][same], f["final_T"][same], rtol=0, atol=1e-5)
 
 
 def check_grads(hg, og, rtol=2e-4):
