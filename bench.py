@@ -4,9 +4,11 @@
 Metric (BASELINE.json): Msplats/s forward+backward at 1 048 576 Gaussians, 1024x512 ERP
 (= six 256x256 cube faces + cube->ERP stitch), L2 pixel loss on the faces (the reference's loss,
 src/loss/loss_mse.py:30-31), 1/2/4/8 GPUs with one target view per GPU (weak scaling) and one RCCL
-exchange of the per-Gaussian gradients per step (default: the factored form of DESIGN.md section 5 —
-all-reduce of the mean / covariance / opacity gradients + all-gather of the per-Gaussian dL/dRGB factors,
-SH gradient rebuilt locally; --grad-sync allreduce = one all-reduce of all 352 B/Gaussian).
+exchange of the per-Gaussian gradients per step (default --grad-sync chunked: the factored form of DESIGN.md section 5 —
+all-reduce of the packed mean / covariance / opacity gradients + all-gather of the per-Gaussian dL/dRGB factors, SH gradient
+rebuilt locally — issued Gaussian range by Gaussian range INSIDE the backward; --grad-sync factored = the same bytes as one
+exchange per step, optionally finished behind the next micro-batch's forward; --grad-sync allreduce = one all-reduce of all
+352 B/Gaussian).
 
 A "step" is one pass of the hot path per rank: fused six-face forward (L2 loss and its gradient seed fused
 into the composite store unless --fused-loss 0), stitch, backward (+ the gradient exchange when N > 1; after
@@ -39,7 +41,11 @@ import torch  # noqa: E402
 from splatter360_amd import _lib, decoder, distributed, rasterizer, stitch, synthetic  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 measured-achievable
-FWD_KERNELS = ("preprocess", "tile_scan", "emit", "sort_tiles", "render", "cube2erp")
+# VALU issue peak: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles per SIMD at 2.4 GHz (MI355X_MICROARCH.md chip
+# table; profiles/ VALU-busy figures use the same 4-cycle slot) = 614.4 G wave-instructions / s
+VALU_PEAK_GINST = 1024 * 2.4 / 4.0
+FWD_KERNELS = ("sh_eval", "preprocess", "tile_scan", "emit", "sort_tiles", "render", "cube2erp")
+VALU_BOUND = ("render", "render_bwd")   # the two alpha composites: instruction-issue-bound
 
 
 def parse():
@@ -60,9 +66,12 @@ def parse():
                     "0: the reference's torch ops on the rendered faces")
     ap.add_argument("--overlap-exchange", type=int, default=1,
                     help="N>1, factored: 1 (default) = a micro-batch's exchange is finished only after the next micro-batch's forward "
-                         "has been queued (it overlaps with that forward); 0 = finished right after its own backward")
-    ap.add_argument("--grad-sync", choices=("factored", "allreduce"), default="factored",
-                    help="N>1 gradient exchange: factored (default) or one all-reduce of the full 352 B/Gaussian set")
+                         "has been queued (it overlaps with that forward: a gradient-accumulation schedule); 0 = finished right "
+                         "after its own backward")
+    ap.add_argument("--grad-sync", choices=("chunked", "factored", "allreduce"), default="chunked",
+                    help="N>1 gradient exchange: chunked (default: factored bytes, exchanged range by range inside the backward), "
+                         "factored (one exchange per step, see --overlap-exchange) or allreduce (the full 352 B/Gaussian set)")
+    ap.add_argument("--chunks", type=int, default=4, help="Gaussian ranges of the chunked exchange")
     ap.add_argument("--dry-run", type=int, default=0,
                     help="1: launch / rendezvous / collectives only (no GPU work, value = null): lets the CPU test suite exercise "
                          "`python bench.py --gpus N` end to end with the gloo backend")
@@ -215,33 +224,38 @@ def main():
             out["grads"] = pending[0].finish()     # waits (on the stream) for the collectives, rebuilds dL/dSH locally
             pending[0] = None
 
+    local_only = [False]   # N > 1: steps without the exchange, to quote how much of it a step exposes
+
     def step_train():
         for p in params:
             p.grad = None
         views = decoder.pack_camera_views(ext, K, near, far, bg)  # camera glue of this step: one kernel (s360_pack_views)
+        ex = exchange_cfg if (chunked and not local_only[0]) else None
+        kw = dict(check="lazy", shared_campos=True, views=views, defer_sh=factored and not local_only[0], exchange=ex)
         if a.mode == "fwdbwd" and a.fused_loss:   # LossMse fused into the composite store
-            faces, fm = decoder.render_views_fused(ext, K, near, far, (face_w, face_w), bg, *params, check="lazy", shared_campos=True, views=views,
-                                                   defer_sh=factored, mse_target=gt)
+            faces, fm = decoder.render_views_fused(ext, K, near, far, (face_w, face_w), bg, *params, mse_target=gt, **kw)
             loss = fm.loss
         else:
-            faces = decoder.render_views_fused(ext, K, near, far, (face_w, face_w), bg, *params, check="lazy", shared_campos=True, views=views,
-                                               defer_sh=factored)
+            faces = decoder.render_views_fused(ext, K, near, far, (face_w, face_w), bg, *params, **kw)
             loss = ((faces - gt) ** 2).mean() if a.mode == "fwdbwd" else None
         out["erp"] = c2e.stitch_rendered(faces.detach())
-        # the forward above was queued while the PREVIOUS micro-batch's exchange is still running on the communicator's
-        # stream (gradient accumulation over micro-batches: SURVEY.md 8(e) "overlap with the next view's forward")
+        # factored + overlap: the forward above was queued while the PREVIOUS micro-batch's exchange is still running on the
+        # communicator's stream (gradient accumulation over micro-batches)
         finish_pending()
         if a.mode == "fwdbwd":
-            loss.backward(one)   # the seed autograd would otherwise allocate and fill every step
-            if factored:   # all-reduce 40 B/Gaussian (one packed buffer) + all-gather 16 B/Gaussian/rank, SH gradient rebuilt locally
+            loss.backward(one)   # the seed autograd would otherwise allocate and fill every step.  chunked: the per-Gaussian
+                                 # gradients come back summed over the ranks (the exchange runs inside this backward)
+            if factored and not local_only[0]:   # all-reduce 40 B/Gaussian (one packed buffer) + all-gather 16 B/Gaussian/rank
                 pending[0] = distributed.start_factored_exchange(*params, rasterizer.deferred_of(faces))
                 if not a.overlap_exchange:
                     finish_pending()
-            else:
+            elif world > 1 and not chunked and not local_only[0]:
                 distributed.allreduce_gradients([p.grad for p in params])
         out["faces"] = faces
 
     factored = world > 1 and a.mode == "fwdbwd" and a.grad_sync == "factored"
+    chunked = world > 1 and a.mode == "fwdbwd" and a.grad_sync == "chunked"
+    exchange_cfg = distributed.ExchangeConfig(n_chunks=a.chunks) if chunked else None
     step = step_eval if a.mode == "eval" else step_train
     views_per_step = 3 if a.mode == "eval" else 1
 
@@ -263,6 +277,43 @@ def main():
     sync()
     dt = distributed.max_over_ranks(time.perf_counter() - t0, dev)
     ms_per_step = dt / a.steps * 1e3
+
+    extra = {}
+    if a.mode == "fwdbwd":
+        # (1) the forward-only figure of BASELINE configs[1] (north_star: ">= 400 Msplats/s forward") from the same process: K
+        # more steps with nothing requiring grad (inference form of the call: no backward state is written)
+        def step_fwd():
+            with torch.no_grad():
+                views = decoder.pack_camera_views(ext, K, near, far, bg)
+                faces = decoder.render_views_fused(ext, K, near, far, (face_w, face_w), bg, *params, check="lazy", shared_campos=True, views=views)
+                out["erp_fwd"] = c2e.stitch_rendered(faces)
+        for _ in range(2):
+            step_fwd()
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            step_fwd()
+        sync()
+        dt_f = distributed.max_over_ranks(time.perf_counter() - t1, dev)
+        extra["forward_only"] = {"value": G * world / (dt_f / a.steps) / 1e6, "unit": "Msplats/s", "ms_per_step": dt_f / a.steps * 1e3,
+                                 "steps": a.steps, "what": "BASELINE configs[1]: fused six-face forward + stitch, inference form of the call"}
+        if world > 1:
+            # (2) how much of the gradient exchange a step exposes: the same K steps without it
+            local_only[0] = True
+            for _ in range(2):
+                step()
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(a.steps):
+                step()
+            sync()
+            dt_l = distributed.max_over_ranks(time.perf_counter() - t1, dev)
+            local_only[0] = False
+            extra["exchange"] = {"mode": a.grad_sync, "ms_per_step_without_exchange": dt_l / a.steps * 1e3,
+                                 "exposed_ms_per_step": (dt - dt_l) / a.steps * 1e3,
+                                 "bytes_received_per_rank": (2 * (world - 1) / world * 40 + (world - 1) * 16) * G if a.grad_sync != "allreduce"
+                                 else 2 * (world - 1) / world * 352 * G}
+    extra.update(distributed.rank_report(dev))   # backend, rccl_ranks (as the process group reports it), device index of every rank
 
     st = rasterizer.last_state()
     if st.overflowed():
@@ -287,12 +338,15 @@ def main():
     # kernel-interface (compulsory) bytes per launch, for the per-kernel table
     hw = 6 * face_w * face_w
     iface = dict(
-        preprocess=G * 340 + 6 * G * 4 + visible_pairs * 49,
+        sh_eval=G * (300 + 12 + 16 + (36 if a.mode == "fwdbwd" else 0)),
+        preprocess=G * (12 + 36 + 4 + 16) + 6 * G * 4 + visible_pairs * 57,
         render=L * (4 + 48) + hw * (12 + 8),
         sort_tiles=L * (8 + 8 + 4),
         emit=6 * G * 4 + visible_pairs * 32 + L * 8,
         render_bwd=L * (4 + 48 + 4) + hw * (12 + 8) + L * 48,
-        preprocess_bwd=G * 340 + L * 48 + 6 * G * 8 + G * (340 + 12),
+        gather_slots=L * (4 + 4) + L * 48 + visible_pairs * 48,
+        preprocess_bwd=G * (12 + 36 + 36 + 1) + visible_pairs * (48 + 1) + G * (12 + 36 + 4 + 16),
+        sh_bwd=G * (16 + 12 + 300),
         cube2erp=hw * 12 + (2 * face_w) * (4 * face_w) * (12 + 12),
     )
     for k, v in kernels.items():
@@ -306,7 +360,7 @@ def main():
     per_splat = BYTES_FWD if dom in FWD_KERNELS else BYTES_BWD
     dom_s = kernels[dom]["avg_us"] * 1e-6
     achieved = per_splat * G / dom_s / 1e9
-    traffic = valu_busy = valu_insts = None
+    traffic = valu_busy = valu_insts = counter_bytes_step = None
     pmc_note = "no committed PMC profile"
     pmc = ROOT / "profiles" / "pmc_latest.json"
     if pmc.exists():   # PMC counters of the committed rocprofv3 passes (scripts/collect_profiles.sh), per launch
@@ -316,6 +370,7 @@ def main():
             if stamp.get("source_hash") == _lib.source_hash() and stamp.get("gaussians") == G and stamp.get("face") == face_w:
                 rec = blob.get(dom, {})
                 traffic, valu_busy, valu_insts = rec.get("hbm_bytes_per_launch"), rec.get("valu_busy_frac"), rec.get("valu_insts_per_launch")
+                counter_bytes_step = stamp.get("counter_bytes_per_step")
                 pmc_note = f"PMC counters from profiles/pmc_latest.json (same kernel sources {stamp.get('source_hash')}, same workload)"
             else:   # never quote counters of other code or another workload: traffic stays null
                 pmc_note = (f"profiles/pmc_latest.json was collected from kernel sources {stamp.get('source_hash')} / G={stamp.get('gaussians')}"
@@ -334,6 +389,22 @@ def main():
         cfg_name = "BASELINE configs[4] single-rank shape" + (" (G = 2 context panoramas at 2048x1024)" if G == 1 << 22 else " (resolution-decoupled cloud)")
     else:
         cfg_name = "non-BASELINE size"
+    hbm_nominal = {"achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                   "note": f"{per_splat:.1f} B/splat (SURVEY 8d, {'fwd' if dom in FWD_KERNELS else 'bwd'} phase) x {G} splats / avg launch "
+                           f"{kernels[dom]['avg_us']:.1f} us of the dominant kernel group"}
+    if dom in VALU_BOUND:
+        # the composites are bound by VALU instruction issue, not by HBM or MFMA: their roofline is the issue rate.  achieved =
+        # wave64 VALU instructions per launch (SQ_INSTS_VALU of the hash-matched profile) / the launch time measured here
+        a_inst = None if valu_insts is None else valu_insts / dom_s / 1e9
+        roofline = {"bound": "valu", "kernel": dom, "achieved": a_inst, "peak": VALU_PEAK_GINST, "unit": "G wave64-inst/s",
+                    "frac": None if a_inst is None else a_inst / VALU_PEAK_GINST, "traffic": traffic,
+                    "valu_busy_frac": valu_busy, "valu_insts_per_launch": valu_insts, "hbm_nominal": hbm_nominal,
+                    "note": "dominant kernel group = an alpha composite: VALU-issue-bound (one wave64 instruction per 4 cycles per SIMD, "
+                            "1024 SIMDs, 2.4 GHz); hbm_nominal = the contract's algorithmic-bytes figure for the same launch, kept as a "
+                            "second number; see DESIGN.md section 4; " + pmc_note}
+    else:
+        roofline = {"bound": "hbm", "kernel": dom, **hbm_nominal, "traffic": traffic, "valu_busy_frac": valu_busy,
+                    "valu_insts_per_launch": valu_insts, "note": hbm_nominal["note"] + "; " + pmc_note}
     res = {
         "metric": f"Msplats/s {what} @{gm} Gaussians, {erp_w}x{erp_h} ERP",
         "value": value, "unit": "Msplats/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -343,19 +414,19 @@ def main():
                                f"context panoramas {pano_w}x{pano_h}), {erp_w}x{erp_h} ERP = 6 faces {face_w}x{face_w} + stitch, {a.mode}"
                                + (", L2 loss on faces" + (" (fused epilogue)" if a.fused_loss else "") if a.mode == "fwdbwd" else ""),
                    "gaussians": G, "erp": [erp_w, erp_h], "face": face_w, "views_per_gpu": views_per_step,
-                   "parallelism": f"view-sharded x{world}" + ((", RCCL factored grad exchange (all-reduce 40 B/G packed + all-gather dRGB 16 B/G/rank" + (", overlapped with the next micro-batch's forward" if a.overlap_exchange else "") + ")" if factored else
-                                                                  ", RCCL all-reduce of Gaussian grads") if world > 1 and a.mode == "fwdbwd" else ""),
+                   "parallelism": f"view-sharded x{world}" + (
+                       "" if not (world > 1 and a.mode == "fwdbwd") else
+                       f", RCCL chunked exchange inside the backward ({a.chunks} Gaussian ranges: all-reduce 40 B/G packed + all-gather dRGB 16 B/G/rank)" if chunked else
+                       ", RCCL factored grad exchange (all-reduce 40 B/G packed + all-gather dRGB 16 B/G/rank" + (", overlapped with the next micro-batch's forward" if a.overlap_exchange else "") + ")" if factored else
+                       ", RCCL all-reduce of Gaussian grads"),
                    "num_rendered": L, "visible_pairs": visible_pairs},
-        "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                     "valu_busy_frac": valu_busy, "valu_insts_per_launch": valu_insts,
-                     "note": f"{per_splat:.1f} B/splat (SURVEY §8d, {'fwd' if dom in FWD_KERNELS else 'bwd'} phase) x {G} splats / "
-                             f"avg launch {kernels[dom]['avg_us']:.1f} us of the dominant kernel; that kernel is VALU-issue-bound "
-                             "(alpha composite: valu_busy_frac = share of the kernel during which the SIMDs' VALU pipes issue, PMC), "
-                             "see DESIGN.md section 4; " + pmc_note},
-        "path_roofline": {"bytes_per_step": bytes_step, "achieved_GBps": bytes_step / (dt / a.steps) / 1e9 ,
-                          "frac_of_8TBps": bytes_step / (dt / a.steps) / 1e9 / HBM_PEAK_GBPS},
+        "roofline": roofline,
+        "path_roofline": {"bytes_per_step": bytes_step, "achieved_GBps": bytes_step / (dt / a.steps) / 1e9,
+                          "frac_of_8TBps": bytes_step / (dt / a.steps) / 1e9 / HBM_PEAK_GBPS,
+                          "counter_bytes_per_step": counter_bytes_step,
+                          "counter_over_algorithmic": None if counter_bytes_step is None else counter_bytes_step / bytes_step},
         "kernels": kernels,
+        **extra,
     }
     if a.mode == "eval" and rank == 0:
         # the same 18 colour + 18 depth face renders through the reference-style per-face drop-in calls

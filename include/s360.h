@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define S360_ABI_VERSION 16
+#define S360_ABI_VERSION 17
 #define S360_MAX_VIEWS 8
 #define S360_TILE 16
 
@@ -246,6 +246,31 @@ int s360_backward_split(const S360Params* prm, const S360View* views, const floa
 int s360_sh_backward(const S360Params* prm, int32_t n_groups, const S360View* views,
                      const float* means3D, const float* d_rgb_sums /* [n_groups,P,4] */, float* d_shs,
                      void* stream);
+
+/*
+ * The backward in two parts, for the chunked multi-GPU gradient exchange (no reference counterpart: the reference leaves the
+ * gradient exchange to Lightning DDP, src/main.py:117-130; here the per-Gaussian gradients of one panorama per rank are summed
+ * over the ranks INSIDE the rasteriser's backward, and the exchange of one Gaussian range runs while the next range is still
+ * being computed):
+ *   s360_backward_composite   every (tile, quadrant) replay + the per-pair sum -> state in bwd_workspace (no outputs);
+ *   s360_backward_gaussians   the per-Gaussian chains of Gaussians [g_begin, g_begin + g_count) from that state (views sharing
+ *                             one camera centre, SH given): d_packed[P,10] rows (d_mean 3 | the 6 unique d_covariance entries |
+ *                             d_opacity — the unit one all-reduce moves; complete d_mean incl. this rank's view-direction term),
+ *                             d_rgb_sum[P,4] rows (clamp-masked sum of dL/dRGB; .w = rank_stamp as int32 bits where the Gaussian
+ *                             was visible to this call, else -1 — what s360_sh_backward expects after the all-gather),
+ *                             optional d_means2D[V,P,3].  s360_backward_split == composite + gaussians over the whole cloud.
+ *   s360_unpack_gradients     packed[P,10] (after the all-reduce) -> d_means3D[P,3], d_cov ([P,3,3] upper triangle with cov9 != 0,
+ *                             else [P,6]), d_opacities[P].
+ */
+int s360_backward_composite(const S360Params* prm, const S360View* views, const void* workspace, size_t workspace_bytes,
+                            const float* dL_dimages, const float* dL_dimages_scale, const float* dL_ddepth, int32_t depth_mode,
+                            void* bwd_workspace, size_t bwd_workspace_bytes, void* stream);
+int s360_backward_gaussians(const S360Params* prm, const S360View* views, const float* means3D, const float* cov6,
+                            const float* shs, const void* workspace, size_t workspace_bytes, int32_t with_depth,
+                            int32_t depth_mode, int32_t g_begin, int32_t g_count, int32_t rank_stamp, float* d_packed,
+                            float* d_means2D, float* d_rgb_sum, void* bwd_workspace, size_t bwd_workspace_bytes, void* stream);
+int s360_unpack_gradients(const float* packed, int32_t P, int32_t cov9, float* d_means3D, float* d_cov, float* d_opacities,
+                          void* stream);
 
 /*
  * Camera records of a call in one launch: replaces the reference's per-call camera glue

@@ -4,7 +4,7 @@
 # Outputs land in gpurun_out/$ROUND/ ; scripts/make_profiles.py then condenses them into profiles/.
 # meta.json stamps the kernel-source hash the counters belong to (bench.py refuses to quote a mismatching profile).
 set -x
-ROUND=${ROUND:-r02}
+ROUND=${ROUND:-r03}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$ROUND
 mkdir -p $O

@@ -2,7 +2,7 @@
 import collections, csv, glob, json, os, shutil, subprocess, sys
 from pathlib import Path
 R = Path(__file__).resolve().parent.parent
-ROUND = os.environ.get("ROUND", "r02")
+ROUND = os.environ.get("ROUND", "r03")
 O = R / "gpurun_out" / ROUND
 P = R / "profiles"
 P.mkdir(exist_ok=True)
@@ -32,7 +32,7 @@ with open(P / f"{ROUND}_pmc_counters.csv", "w") as f:
 # VALU-issue view of every kernel (SQ counters are per-SIMD quad-cycles; GRBM_GUI_ACTIVE sums the 8 XCDs):
 # a gfx950 SIMD issues one wave64 VALU instruction per 4 cycles, 1024 SIMDs on the chip.
 pm = json.load(open(P / "pmc_latest.json"))
-by_kernel = {v["kernel"]: v for v in pm.values() if isinstance(v, dict) and "kernel" in v}
+by_kernel = {v["kernel"]: v for k, v in pm.items() if k != "_meta" and isinstance(v, dict) and "kernel" in v}
 for k, c in acc.items():
     kk = k.replace("s360::", "")
     if kk in by_kernel and "SQ_ACTIVE_INST_VALU" in c and "GRBM_GUI_ACTIVE" in c:
@@ -40,7 +40,12 @@ for k, c in acc.items():
         cycles = mean("GRBM_GUI_ACTIVE") / 8.0
         by_kernel[kk]["valu_insts_per_launch"] = round(mean("SQ_INSTS_VALU")) if "SQ_INSTS_VALU" in c else None
         by_kernel[kk]["valu_busy_frac"] = round(mean("SQ_ACTIVE_INST_VALU") * 4.0 / (cycles * 1024.0), 4)
-pm["_meta"] = json.loads((O / "meta.json").read_text())   # kernel-source hash + workload the counters belong to
-pm["_meta"]["round"] = ROUND
+meta = json.loads((O / "meta.json").read_text())   # kernel-source hash + workload the counters belong to
+meta.update(pm.get("_meta", {}))
+meta["round"] = ROUND
+pm["_meta"] = meta
+calib = R / "gpurun_out" / "calib" / "calibration.json"
+if calib.exists():
+    shutil.copy(calib, P / "fetch_write_calibration.json")
 json.dump(pm, open(P / "pmc_latest.json", "w"), indent=1, sort_keys=True)
 print("profiles/ updated")

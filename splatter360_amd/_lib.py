@@ -26,7 +26,7 @@ FLAG_SH_CHANNEL_MAJOR = 4
 FLAG_FORWARD_ONLY = 8
 FLAG_SH_DEG4_IGNORED = 16
 FLAG_SPHERICAL = 32
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 
 class S360Params(C.Structure):
@@ -42,7 +42,7 @@ class S360Layout(C.Structure):
         "tile_max_contrib", "strip_last", "slot_pair", "rgbc", "sh_jac", "surv", "surv_count", "backward_bytes")]
 
 
-EXPORTS = ("s360_abi_version", "s360_error_string", "s360_layout", "s360_forward", "s360_forward_depth", "s360_forward_mse", "s360_backward", "s360_backward_split", "s360_sh_backward", "s360_pack_views", "s360_adapter_forward", "s360_adapter_backward", "s360_sh_rotation_blocks",
+EXPORTS = ("s360_abi_version", "s360_error_string", "s360_layout", "s360_forward", "s360_forward_depth", "s360_forward_mse", "s360_backward", "s360_backward_split", "s360_backward_composite", "s360_backward_gaussians", "s360_unpack_gradients", "s360_sh_backward", "s360_pack_views", "s360_adapter_forward", "s360_adapter_backward", "s360_sh_rotation_blocks",
            "s360_cube2erp_forward", "s360_cube2erp_backward", "s360_profile_slots", "s360_profile_slot_name",
            "s360_profile_enable", "s360_profile_collect")
 
@@ -143,6 +143,12 @@ def lib() -> C.CDLL:
     l.s360_backward.argtypes = [C.POINTER(S360Params)] + [vp] * 7 + [sz] + [vp] * 3 + [i32] + [vp] * 7 + [sz, vp]
     l.s360_backward_split.restype = C.c_int
     l.s360_backward_split.argtypes = [C.POINTER(S360Params)] + [vp] * 6 + [sz] + [vp] * 3 + [i32] + [vp] * 6 + [sz, vp]
+    l.s360_backward_composite.restype = C.c_int
+    l.s360_backward_composite.argtypes = [C.POINTER(S360Params), vp, vp, sz, vp, vp, vp, i32, vp, sz, vp]
+    l.s360_backward_gaussians.restype = C.c_int
+    l.s360_backward_gaussians.argtypes = [C.POINTER(S360Params), vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp]
+    l.s360_unpack_gradients.restype = C.c_int
+    l.s360_unpack_gradients.argtypes = [vp, i32, i32, vp, vp, vp, vp]
     l.s360_sh_backward.restype = C.c_int
     l.s360_sh_backward.argtypes = [C.POINTER(S360Params), i32] + [vp] * 5
     l.s360_pack_views.restype = C.c_int

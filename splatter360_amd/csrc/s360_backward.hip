@@ -101,12 +101,17 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess_bwd(
     const float* __restrict__ shs, const uint8_t* __restrict__ vis_mask,
     const uint8_t* __restrict__ clamped, const float4* __restrict__ pairgrad, float* __restrict__ d_means3D,
     float* __restrict__ d_means2D, float* __restrict__ d_cov6, float* __restrict__ d_opac, float* __restrict__ d_shs,
-    float* __restrict__ d_colors, float4* __restrict__ drgb_out, int depth_mode, const float* __restrict__ sh_jac) {
+    float* __restrict__ d_colors, float4* __restrict__ drgb_out, int depth_mode, const float* __restrict__ sh_jac,
+    int g_begin, int g_end, float* __restrict__ d_packed, int view_stamp) {
+    // [g_begin, g_end): the Gaussians of this launch (the whole cloud, or one range of the chunked multi-GPU exchange — outputs
+    // land at their absolute positions either way).  d_packed != NULL: means / covariance / opacity gradients go to ONE
+    // [P,10] buffer (3 + the 6 unique covariance entries + 1), the unit the all-reduce moves, instead of three arrays.
+    // view_stamp >= 0: the visibility word of drgb_out is that stamp (the owning rank of the exchange) instead of the first view.
     extern __shared__ __attribute__((aligned(16))) float lds_sh[];  // [256*M*3] SH slab, then [256*V*3] dRGB
     const int tid = threadIdx.x;
-    const int g0 = blockIdx.x * S360_BLOCK;
+    const int g0 = g_begin + blockIdx.x * S360_BLOCK;
     const int g = g0 + tid;
-    const int P = kp.P;
+    const int P = g_end;
     const int nb = min(S360_BLOCK, P - g0);
     const int nfl = nb * kp.M * 3;
     float* lds_drgb = lds_sh + S360_BLOCK * kp.M * 3;  // per-thread, per-view dRGB (non-shared campos)
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess_bwd(
         const uint32_t vis = vis_mask[g];  // bit v: visible in view v (one byte instead of V tiles_touched words)
 
         for (int v = 0; v < kp.V; ++v) {
-            const size_t p = (size_t)v * P + g;
+            const size_t p = (size_t)v * kp.P + g;
             float gx_ = 0.f, gy_ = 0.f;
             float drgb_v[3] = {0.f, 0.f, 0.f};
             // gradients w.r.t. the scaled cloud of this view; folded back with scale / scale^2 below
@@ -370,7 +375,6 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess_bwd(
             } else {
                 for (int k = 0; k < kp.M * 3; ++k) sh[k] = 0.f;
                 for (int v = 0; v < kp.V; ++v) {
-                    const size_t p = (size_t)v * P + g;
                     if (!((vis >> v) & 1u)) continue;
                     const S360View& vw = views[v];
                     const float sc = vw.scale;
@@ -397,22 +401,31 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess_bwd(
                 dm2 += drgb_sum[ch] * J[3 * ch + 2];
             }
         }
-        d_means3D[3 * g] = dm0;
-        d_means3D[3 * g + 1] = dm1;
-        d_means3D[3 * g + 2] = dm2;
         if (USE_SH && !SH_PASS && drgb_out)
-            drgb_out[g] = make_float4(drgb_sum[0], drgb_sum[1], drgb_sum[2], __int_as_float(first_visible));
-        if (cov9) {
-            // adjoint of the upper-triangle gather: lower triangle receives no gradient
-            float* o = d_cov6 + 9 * (size_t)g;
-            o[0] = dc[0]; o[1] = dc[1]; o[2] = dc[2];
-            o[3] = 0.f;   o[4] = dc[3]; o[5] = dc[4];
-            o[6] = 0.f;   o[7] = 0.f;   o[8] = dc[5];
-        } else {
+            drgb_out[g] = make_float4(drgb_sum[0], drgb_sum[1], drgb_sum[2],
+                                      __int_as_float(view_stamp >= 0 && first_visible >= 0 ? view_stamp : first_visible));
+        if (d_packed) {
+            float* o = d_packed + 10 * (size_t)g;
+            o[0] = dm0; o[1] = dm1; o[2] = dm2;
 #pragma unroll
-            for (int k = 0; k < 6; ++k) d_cov6[6 * (size_t)g + k] = dc[k];
+            for (int k = 0; k < 6; ++k) o[3 + k] = dc[k];
+            o[9] = dop;
+        } else {
+            d_means3D[3 * g] = dm0;
+            d_means3D[3 * g + 1] = dm1;
+            d_means3D[3 * g + 2] = dm2;
+            if (cov9) {
+                // adjoint of the upper-triangle gather: lower triangle receives no gradient
+                float* o = d_cov6 + 9 * (size_t)g;
+                o[0] = dc[0]; o[1] = dc[1]; o[2] = dc[2];
+                o[3] = 0.f;   o[4] = dc[3]; o[5] = dc[4];
+                o[6] = 0.f;   o[7] = 0.f;   o[8] = dc[5];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) d_cov6[6 * (size_t)g + k] = dc[k];
+            }
+            d_opac[g] = dop;
         }
-        d_opac[g] = dop;
         if (!USE_SH && d_colors) {
             d_colors[3 * g] = dcol_sum[0];
             d_colors[3 * g + 1] = dcol_sum[1];
@@ -512,10 +525,137 @@ static int launch_sh_bwd(const KParams& kp, const S360View* views, const float* 
     const int wblk = (kp.P + 63) / 64;
     const size_t wlds = (size_t)64 * kp.M * 3 * 4;
     if (wlds > 64 * 1024) return S360_E_UNSUPPORTED;
+    ProfScope ps(PS_SH_BWD, st);
     if (kp.flags & S360_FLAG_SH_CHANNEL_MAJOR)
         hipLaunchKernelGGL((k_sh_bwd<true>), dim3(wblk), dim3(64), wlds, st, kp, views, means3D, drgb, n_groups, d_shs);
     else
         hipLaunchKernelGGL((k_sh_bwd<false>), dim3(wblk), dim3(64), wlds, st, kp, views, means3D, drgb, n_groups, d_shs);
+    return S360_OK;
+}
+
+struct BwdCtx {
+    KParams kp;
+    S360Layout L;
+    int nt;
+    float4* part;
+    uint32_t* valid_words;
+    uint32_t* order;
+    float4* pairgrad;
+};
+
+static int bwd_ctx(const S360Params* prm, const void* workspace, size_t workspace_bytes, void* bwd_workspace,
+                   size_t bwd_workspace_bytes, BwdCtx& c) {
+    if (!prm || !workspace || !bwd_workspace) return S360_E_BADARG;
+    if (prm->flags & S360_FLAG_FORWARD_ONLY) return S360_E_BADARG;
+    int rc = s360_layout(prm, &c.L);
+    if (rc) return rc;
+    if (workspace_bytes < c.L.total_bytes || bwd_workspace_bytes < c.L.backward_bytes) return S360_E_WORKSPACE;
+    KParams& kp = c.kp;
+    kp.P = prm->P; kp.V = prm->V; kp.H = prm->H; kp.W = prm->W; kp.deg = s360_effective_degree(prm); kp.M = prm->M;
+    kp.gx = (prm->W + 15) / 16; kp.gy = (prm->H + 15) / 16; kp.T = kp.gx * kp.gy;
+    kp.flags = prm->flags; kp.cap = prm->max_instances;
+    const bool sph = (kp.flags & S360_FLAG_SPHERICAL) != 0;
+    if (sph && (kp.V & 1)) return S360_E_BADARG;
+    c.nt = (sph ? kp.V / 2 : kp.V) * kp.T;
+    // backward scratch: [cap] x 4 quadrant partial records of 48 B, [cap] x 4 validity bytes, the launch order, one gathered
+    // 48-byte record per pair, [P] summed dL/dRGB
+    c.part = (float4*)bwd_workspace;
+    c.valid_words = (uint32_t*)((char*)bwd_workspace + (size_t)kp.cap * 4 * GREC * 4);
+    c.order = c.valid_words + kp.cap;
+    c.pairgrad = (float4*)((char*)(c.order + c.nt * 4) + 256 - ((uintptr_t)(c.order + c.nt * 4) & 255));
+    return S360_OK;
+}
+
+// Composite part of the backward: every (tile, quadrant) replay + the per-pair sum of the partial records.  Leaves one
+// 48-byte raster-gradient record per (view, Gaussian) pair in the backward workspace.
+static int backward_composite(const BwdCtx& c, const S360View* views, const void* workspace, const float* dL_dimages,
+                              const float* dL_dimages_scale, const float* dL_ddepth, int depth_mode, hipStream_t st) {
+    const KParams& kp = c.kp;
+    const S360Layout& L = c.L;
+    const char* ws = (const char*)workspace;
+    const uint32_t* header = (const uint32_t*)(ws + L.header);
+    const bool with_depth = dL_ddepth != nullptr;
+    const uint32_t* surv_count = (const uint32_t*)(ws + L.surv_count);  // per-unit replay length: also the work estimate
+    {
+        ProfScope ps(PS_RENDER_BWD, st);
+        hipLaunchKernelGGL(k_order_units, dim3(1 + 512), dim3(1024), 0, st, surv_count, c.order, c.nt * 4, c.valid_words, header, kp.cap);
+        launch_render_bwd_em(with_depth, c.nt * 4, st, kp, views, (const uint32_t*)(ws + L.tile_start), (const float4*)(ws + L.surv),
+                             surv_count, (const uint32_t*)(ws + L.slot_base), (const float*)(ws + L.depths),
+                             (const float*)(ws + L.final_T), (const uint32_t*)(ws + L.n_contrib), dL_dimages, dL_dimages_scale,
+                             dL_ddepth, c.part, (uint8_t*)c.valid_words, c.order, depth_mode,
+#ifdef S360_DBG_TIMING
+                             (uint32_t*)(ws + L.keys_alt));  // the forward's merge buffer is free by now
+#else
+                             (uint32_t*)nullptr);
+#endif
+    }
+    S360_CHECK_LAUNCH();
+    ProfScope ps(PS_GATHER, st);
+    hipLaunchKernelGGL(k_gather_slots, dim3((unsigned)(((size_t)kp.cap + S360_BLOCK - 1) / S360_BLOCK)), dim3(S360_BLOCK), 0, st,
+                       kp.cap, header, (const uint32_t*)(ws + L.slot_pair), c.part, c.valid_words, c.pairgrad);
+    S360_CHECK_LAUNCH();
+    return S360_OK;
+}
+
+// Per-Gaussian part for Gaussians [g_begin, g_end): geometry chains of the V views (+ the SH pass unless the views share a
+// camera centre, where k_sh_bwd follows or the caller defers it).
+static int backward_gaussians(const BwdCtx& c, const S360View* views, const float* means3D, const float* cov6, const float* shs,
+                              const void* workspace, bool with_depth, int depth_mode, int g_begin, int g_end, float* d_means3D,
+                              float* d_means2D, float* d_cov6, float* d_opacities, float* d_shs, float* d_colors, float* d_rgb_sum,
+                              float* d_packed, int view_stamp, hipStream_t st) {
+    const KParams& kp = c.kp;
+    const S360Layout& L = c.L;
+    const char* ws = (const char*)workspace;
+    const uint8_t* vis_mask = (const uint8_t*)(ws + L.vis_mask);
+    const uint8_t* clamped = (const uint8_t*)(ws + L.clamped);
+    const int dmode = with_depth ? depth_mode : -1;
+    const int n = g_end - g_begin;
+    if (n <= 0) return S360_OK;
+    const int nblk = (n + S360_BLOCK - 1) / S360_BLOCK;
+    float4* drgb = d_rgb_sum ? (float4*)d_rgb_sum : c.pairgrad + (size_t)kp.V * kp.P * 3;  // [P] summed dL/dRGB (+ first visible view)
+    if (shs) {
+        const bool shared = (kp.flags & S360_FLAG_SHARED_CAMPOS) != 0;
+        if ((d_rgb_sum || d_packed) && !shared) return S360_E_UNSUPPORTED;  // the split form needs one camera centre per call
+        if (shared) {
+            // dRGB/d(view direction) reaches dL/dmean here (from the forward's sh_jac), whether or not dL/dSH is wanted
+            // (harmonics frozen: d_shs == NULL), as upstream does (SURVEY App. A.4-9)
+            {
+                ProfScope ps(PS_PREPROCESS_BWD, st);
+                hipLaunchKernelGGL((k_preprocess_bwd<true, false>), dim3(nblk), dim3(S360_BLOCK), 0, st, kp, views, means3D, cov6, shs,
+                                   vis_mask, clamped, c.pairgrad, d_means3D, d_means2D, d_cov6, d_opacities, d_shs,
+                                   d_colors, drgb, dmode, (const float*)(ws + L.sh_jac), g_begin, g_end, d_packed, view_stamp);
+            }
+            if (!d_rgb_sum && d_shs) {
+                if (g_begin != 0 || g_end != kp.P) return S360_E_UNSUPPORTED;
+                const int rc2 = launch_sh_bwd(kp, views, means3D, drgb, 1, d_shs, st);
+                if (rc2) return rc2;
+            }
+        } else {
+            if (g_begin != 0 || g_end != kp.P) return S360_E_UNSUPPORTED;
+            size_t lds = (size_t)S360_BLOCK * kp.M * 3 * 4 + (size_t)S360_BLOCK * kp.V * 3 * 4;
+            if (lds > 160 * 1024) return S360_E_UNSUPPORTED;
+            {
+                static bool attr_done[64] = {};
+                int dev = 0;
+                if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !attr_done[dev]) {
+                    (void)hipFuncSetAttribute((const void*)k_preprocess_bwd<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    (void)hipGetLastError();
+                    attr_done[dev] = true;
+                }
+            }
+            ProfScope ps(PS_PREPROCESS_BWD, st);
+            hipLaunchKernelGGL((k_preprocess_bwd<true, true>), dim3(nblk), dim3(S360_BLOCK), lds, st, kp, views, means3D, cov6, shs,
+                               vis_mask, clamped, c.pairgrad, d_means3D, d_means2D, d_cov6, d_opacities, d_shs,
+                               d_colors, (float4*)nullptr, dmode, (const float*)nullptr, 0, kp.P, (float*)nullptr, -1);
+        }
+    } else {
+        if (d_packed) return S360_E_UNSUPPORTED;
+        ProfScope ps(PS_PREPROCESS_BWD, st);
+        hipLaunchKernelGGL((k_preprocess_bwd<false, false>), dim3(nblk), dim3(S360_BLOCK), 0, st, kp, views, means3D, cov6, shs,
+                           vis_mask, clamped, c.pairgrad, d_means3D, d_means2D, d_cov6, d_opacities, d_shs,
+                           d_colors, (float4*)nullptr, dmode, (const float*)nullptr, g_begin, g_end, (float*)nullptr, -1);
+    }
+    S360_CHECK_LAUNCH();
     return S360_OK;
 }
 
@@ -532,98 +672,15 @@ static int backward_impl(const S360Params* prm, const S360View* views, const flo
     if (prm->P > 0 && (!means3D || !cov6 || !d_means3D || !d_cov6 || !d_opacities)) return S360_E_BADARG;
     const bool with_depth = dL_ddepth != nullptr;
     if (with_depth && (depth_mode < 0 || depth_mode > 3)) return S360_E_BADARG;
-    S360Layout L;
-    int rc = s360_layout(prm, &L);
+    BwdCtx c;
+    int rc = bwd_ctx(prm, workspace, workspace_bytes, bwd_workspace, bwd_workspace_bytes, c);
     if (rc) return rc;
-    if (workspace_bytes < L.total_bytes || bwd_workspace_bytes < L.backward_bytes) return S360_E_WORKSPACE;
     if (prm->P == 0) return S360_OK;
     hipStream_t st = (hipStream_t)stream_;
-    const char* ws = (const char*)workspace;
-
-    KParams kp;
-    kp.P = prm->P; kp.V = prm->V; kp.H = prm->H; kp.W = prm->W; kp.deg = s360_effective_degree(prm); kp.M = prm->M;
-    kp.gx = (prm->W + 15) / 16; kp.gy = (prm->H + 15) / 16; kp.T = kp.gx * kp.gy;
-    kp.flags = prm->flags; kp.cap = prm->max_instances;
-    const bool sph = (kp.flags & S360_FLAG_SPHERICAL) != 0;
-    if (sph && (kp.V & 1)) return S360_E_BADARG;
-    const int nt = (sph ? kp.V / 2 : kp.V) * kp.T;
-
-    const uint32_t* header = (const uint32_t*)(ws + L.header);
-    const uint8_t* vis_mask = (const uint8_t*)(ws + L.vis_mask);
-    const uint32_t* slot_base = (const uint32_t*)(ws + L.slot_base);
-    const float4* recA = (const float4*)(ws + L.rec_a);
-    const float4* recB = (const float4*)(ws + L.rec_b);
-    const float4* recC = (const float4*)(ws + L.rec_c);
-    const uint8_t* clamped = (const uint8_t*)(ws + L.clamped);
-    const float* depths = (const float*)(ws + L.depths);
-    const uint32_t* tile_start = (const uint32_t*)(ws + L.tile_start);
-    const uint32_t* list = (const uint32_t*)(ws + L.list);
-    const float* final_T = (const float*)(ws + L.final_T);
-    const uint32_t* n_contrib = (const uint32_t*)(ws + L.n_contrib);
-    // backward scratch: [cap] x 4 quadrant partial records of 48 B, then [cap] x 4 validity bytes
-    float4* part = (float4*)bwd_workspace;
-    uint32_t* valid_words = (uint32_t*)((char*)bwd_workspace + (size_t)kp.cap * 4 * GREC * 4);
-
-    uint32_t* order = valid_words + kp.cap;  // [nt*4] after the validity words
-    const uint32_t* surv_count = (const uint32_t*)(ws + L.surv_count);  // per-unit replay length: also the work estimate
-    const bool use_order = !getenv("S360_NO_ORDER");
-    {
-    ProfScope ps(PS_RENDER_BWD, st);
-    hipLaunchKernelGGL(k_order_units, dim3(1 + 512), dim3(1024), 0, st, surv_count, use_order ? order : (uint32_t*)nullptr, nt * 4,
-                       valid_words, header, kp.cap);
-    const uint32_t* ord = use_order ? order : (const uint32_t*)nullptr;
-    launch_render_bwd_em(with_depth, nt * 4, st, kp, views, tile_start, (const float4*)(ws + L.surv), surv_count, slot_base, depths, final_T, n_contrib,
-                         dL_dimages, dL_dimages_scale, dL_ddepth, part, (uint8_t*)valid_words, ord, depth_mode,
-#ifdef S360_DBG_TIMING
-                         (uint32_t*)(ws + L.keys_alt));  // the forward's merge buffer is free by now
-#else
-                         (uint32_t*)nullptr);
-#endif
-    }
-    S360_CHECK_LAUNCH();
-    ProfScope ps(PS_PREPROCESS_BWD, st);
-    const int dmode = with_depth ? depth_mode : -1;
-    float4* pairgrad = (float4*)((char*)(order + nt * 4) + 256 - ((uintptr_t)(order + nt * 4) & 255));
-    hipLaunchKernelGGL(k_gather_slots, dim3((unsigned)(((size_t)kp.cap + S360_BLOCK - 1) / S360_BLOCK)), dim3(S360_BLOCK), 0, st,
-                       kp.cap, header, (const uint32_t*)(ws + L.slot_pair), part, valid_words, pairgrad);
-    const int nblk = (kp.P + S360_BLOCK - 1) / S360_BLOCK;
-    float4* drgb = d_rgb_sum ? (float4*)d_rgb_sum : pairgrad + (size_t)kp.V * kp.P * 3;  // [P] summed dL/dRGB (+ first visible view)
-    if (shs) {
-        const bool shared = (kp.flags & S360_FLAG_SHARED_CAMPOS) != 0;
-        if (d_rgb_sum && !shared) return S360_E_UNSUPPORTED;  // the split form needs one camera centre per call
-        if (shared) {
-            // dRGB/d(view direction) reaches dL/dmean here (from the forward's sh_jac), whether or not dL/dSH is wanted
-            // (harmonics frozen: d_shs == NULL), as upstream does (SURVEY App. A.4-9)
-            hipLaunchKernelGGL((k_preprocess_bwd<true, false>), dim3(nblk), dim3(S360_BLOCK), 0, st, kp, views, means3D, cov6, shs,
-                               vis_mask, clamped, pairgrad, d_means3D, d_means2D, d_cov6, d_opacities, d_shs,
-                               d_colors, drgb, dmode, (const float*)(ws + L.sh_jac));
-            if (!d_rgb_sum && d_shs) {
-                const int rc2 = launch_sh_bwd(kp, views, means3D, drgb, 1, d_shs, st);
-                if (rc2) return rc2;
-            }
-        } else {
-            size_t lds = (size_t)S360_BLOCK * kp.M * 3 * 4 + (size_t)S360_BLOCK * kp.V * 3 * 4;
-            if (lds > 160 * 1024) return S360_E_UNSUPPORTED;
-            {
-                static bool attr_done[64] = {};
-                int dev = 0;
-                if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !attr_done[dev]) {
-                    (void)hipFuncSetAttribute((const void*)k_preprocess_bwd<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                    (void)hipGetLastError();
-                    attr_done[dev] = true;
-                }
-            }
-            hipLaunchKernelGGL((k_preprocess_bwd<true, true>), dim3(nblk), dim3(S360_BLOCK), lds, st, kp, views, means3D, cov6, shs,
-                               vis_mask, clamped, pairgrad, d_means3D, d_means2D, d_cov6, d_opacities, d_shs,
-                               d_colors, (float4*)nullptr, dmode, (const float*)nullptr);
-        }
-    } else {
-        hipLaunchKernelGGL((k_preprocess_bwd<false, false>), dim3(nblk), dim3(S360_BLOCK), 0, st, kp, views, means3D, cov6, shs,
-                           vis_mask, clamped, pairgrad, d_means3D, d_means2D, d_cov6, d_opacities, d_shs,
-                           d_colors, (float4*)nullptr, dmode, (const float*)nullptr);
-    }
-    S360_CHECK_LAUNCH();
-    return S360_OK;
+    rc = backward_composite(c, views, workspace, dL_dimages, dL_dimages_scale, dL_ddepth, depth_mode, st);
+    if (rc) return rc;
+    return backward_gaussians(c, views, means3D, cov6, shs, workspace, with_depth, depth_mode, 0, prm->P, d_means3D, d_means2D,
+                              d_cov6, d_opacities, d_shs, d_colors, d_rgb_sum, nullptr, -1, st);
 }
 
 extern "C" int s360_backward(const S360Params* prm, const S360View* views, const float* means3D, const float* cov6,
@@ -661,6 +718,67 @@ extern "C" int s360_sh_backward(const S360Params* prm, int32_t n_groups, const S
     kp.flags = prm->flags; kp.cap = prm->max_instances;
     const int rc = launch_sh_bwd(kp, views, means3D, (const float4*)d_rgb_sums, n_groups, d_shs, (hipStream_t)stream_);
     if (rc) return rc;
+    S360_CHECK_LAUNCH();
+    return S360_OK;
+}
+
+extern "C" int s360_backward_composite(const S360Params* prm, const S360View* views, const void* workspace, size_t workspace_bytes,
+                                       const float* dL_dimages, const float* dL_dimages_scale, const float* dL_ddepth,
+                                       int32_t depth_mode, void* bwd_workspace, size_t bwd_workspace_bytes, void* stream_) {
+    if (!views || !dL_dimages) return S360_E_BADARG;
+    if (dL_ddepth && (depth_mode < 0 || depth_mode > 3)) return S360_E_BADARG;
+    BwdCtx c;
+    const int rc = bwd_ctx(prm, workspace, workspace_bytes, bwd_workspace, bwd_workspace_bytes, c);
+    if (rc) return rc;
+    if (prm->P == 0) return S360_OK;
+    return backward_composite(c, views, workspace, dL_dimages, dL_dimages_scale, dL_ddepth, depth_mode, (hipStream_t)stream_);
+}
+
+extern "C" int s360_backward_gaussians(const S360Params* prm, const S360View* views, const float* means3D, const float* cov6,
+                                       const float* shs, const void* workspace, size_t workspace_bytes, int32_t with_depth,
+                                       int32_t depth_mode, int32_t g_begin, int32_t g_count, int32_t rank_stamp,
+                                       float* d_packed, float* d_means2D, float* d_rgb_sum, void* bwd_workspace,
+                                       size_t bwd_workspace_bytes, void* stream_) {
+    if (!views || !means3D || !cov6 || !shs || !d_packed || !d_rgb_sum) return S360_E_BADARG;
+    if (with_depth && (depth_mode < 0 || depth_mode > 3)) return S360_E_BADARG;
+    BwdCtx c;
+    const int rc = bwd_ctx(prm, workspace, workspace_bytes, bwd_workspace, bwd_workspace_bytes, c);
+    if (rc) return rc;
+    if (g_begin < 0 || g_count < 0 || (long long)g_begin + g_count > prm->P) return S360_E_BADARG;
+    if (g_count == 0) return S360_OK;
+    return backward_gaussians(c, views, means3D, cov6, shs, workspace, with_depth != 0, depth_mode, g_begin, g_begin + g_count,
+                              nullptr, d_means2D, nullptr, nullptr, nullptr, nullptr, d_rgb_sum, d_packed, rank_stamp,
+                              (hipStream_t)stream_);
+}
+
+namespace s360 {
+// [P,10] packed gradients (3 mean + 6 unique covariance entries + 1 opacity) -> the three tensors of the reference's layouts
+__global__ __launch_bounds__(S360_BLOCK) void k_unpack_gradients(const float* __restrict__ packed, int P, int cov9,
+                                                                 float* __restrict__ d_means, float* __restrict__ d_cov,
+                                                                 float* __restrict__ d_opac) {
+    const int g = blockIdx.x * S360_BLOCK + threadIdx.x;
+    if (g >= P) return;
+    const float* s = packed + 10 * (size_t)g;
+    d_means[3 * g] = s[0]; d_means[3 * g + 1] = s[1]; d_means[3 * g + 2] = s[2];
+    if (cov9) {
+        float* o = d_cov + 9 * (size_t)g;
+        o[0] = s[3]; o[1] = s[4]; o[2] = s[5];
+        o[3] = 0.f;  o[4] = s[6]; o[5] = s[7];
+        o[6] = 0.f;  o[7] = 0.f;  o[8] = s[8];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) d_cov[6 * (size_t)g + k] = s[3 + k];
+    }
+    d_opac[g] = s[9];
+}
+}  // namespace s360
+
+extern "C" int s360_unpack_gradients(const float* packed, int32_t P, int32_t cov9, float* d_means3D, float* d_cov, float* d_opacities,
+                                     void* stream_) {
+    if (P < 0 || (P > 0 && (!packed || !d_means3D || !d_cov || !d_opacities))) return S360_E_BADARG;
+    if (P == 0) return S360_OK;
+    hipLaunchKernelGGL(s360::k_unpack_gradients, dim3((P + S360_BLOCK - 1) / S360_BLOCK), dim3(S360_BLOCK), 0, (hipStream_t)stream_,
+                       packed, P, cov9, d_means3D, d_cov, d_opacities);
     S360_CHECK_LAUNCH();
     return S360_OK;
 }

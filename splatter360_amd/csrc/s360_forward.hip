@@ -1432,7 +1432,6 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
     if (!fold_clear && hipMemsetAsync(tile_count, 0, L.tile_start - L.tile_count, st) != hipSuccess) return S360_E_LAUNCH;
     if (kp.P > 0) {
         {
-        ProfScope ps(PS_PREPROCESS, st);
         const int nblk = (kp.P + S360_BLOCK - 1) / S360_BLOCK;
         const size_t hist_bytes = (size_t)nt * 4;
         const int lds_hist = hist_bytes <= 48 * 1024 ? 1 : 0;
@@ -1442,6 +1441,7 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
         const bool eager = eager_sh;
         float4* rgbc = (float4*)(ws + L.rgbc);
         if (eager) {
+            ProfScope ps(PS_SH_EVAL, st);
             float* sh_jac = (float*)(ws + L.sh_jac);
             const bool jac = !(kp.flags & S360_FLAG_FORWARD_ONLY);
             const bool chm = (kp.flags & S360_FLAG_SH_CHANNEL_MAJOR) != 0;
@@ -1453,6 +1453,7 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
             } else if (chm && jac) S360_SHE(true, true); else if (chm) S360_SHE(true, false); else if (jac) S360_SHE(false, true); else S360_SHE(false, false);
 #undef S360_SHE
         }
+        ProfScope ps(PS_PREPROCESS, st);
         if (shs) {
             const size_t lds = lds_hist ? hist_bytes : 0;
             if (eager)

@@ -15,6 +15,9 @@ enum ProfSlot {
     PS_PREPROCESS_BWD,
     PS_STITCH,
     PS_STITCH_BWD,
+    PS_SH_EVAL,
+    PS_GATHER,
+    PS_SH_BWD,
     PS_NSLOTS
 };
 

@@ -195,14 +195,18 @@ def render_views_fused(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far
                        gaussian_sh_coefficients: Tensor, gaussian_opacities: Tensor, *, shared_campos: Optional[bool] = None,
                        max_instances: Optional[int] = None, check: str = "sync", views: Optional[Tensor] = None, glue: str = "native",
                        depth_mode: Optional[DepthRenderingMode] = None, defer_sh: bool = False,
-                       mse_target: Optional[Tensor] = None, mse_weight: float = 1.0, mse_count: Optional[int] = None):
+                       mse_target: Optional[Tensor] = None, mse_weight: float = 1.0, mse_count: Optional[int] = None,
+                       exchange=None):
     """V <= 8 views of ONE cloud in one fused rasteriser call: means[G,3], covariances[G,3,3],
     harmonics[G,3,d_sh] (the reference's Gaussians layout, src/model/types.py:7-12, read in place),
-    opacities[G] -> [V,3,h,w].  With the six face cameras of a panorama (one camera centre) this is bit-for-bit the
-    result of six reference-style render_cuda calls.
+    opacities[G] -> [V,3,h,w].  With the six face cameras of a panorama (one camera centre) and glue="torch" (the
+    reference's own camera ops) this is bit-for-bit the result of six reference-style render_cuda calls; the default one-kernel
+    glue agrees with it to a few ulp of the camera records (Gauss-Jordan instead of LU inverses).
     shared_campos: True = all views share one camera centre and near plane (SH colours evaluated once per
     Gaussian); False = per-view evaluation; None (default) = decided from `extrinsics` / `near`
-    (views_share_camera_centre: one small synchronising read when they live on the device).
+    (views_share_camera_centre: one small synchronising read when they live on the device, cached per camera tensor; with
+    pre-packed `views` and no extrinsics the views are taken to be independent, False).
+    exchange: distributed.ExchangeConfig — multi-GPU, the gradients come back summed over the ranks (rasterize_views).
     Host synchronisation: check="sync" (default) reads the binning-overflow flag back after the forward, like
     upstream's own scan read-back, and re-renders with the exact capacity if needed; check="lazy" together with an
     explicit shared_campos never synchronises (validate later with rasterizer.last_state().overflowed()).  With depth_mode set,
@@ -213,42 +217,39 @@ def render_views_fused(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far
     if views is None:  # callers may pass pre-packed views
         views = pack_camera_views(extrinsics, intrinsics, near, far, background, glue=glue)
     if shared_campos is None:
-        shared_campos = views_share_camera_centre(extrinsics, near)
+        shared_campos = views_share_camera_centre(extrinsics, near) if extrinsics is not None else int(views.shape[0]) == 1
     n = gaussian_sh_coefficients.shape[-1]
     h, w = image_shape
     out = rasterizer.rasterize_views(
         gaussian_means, gaussian_covariances, gaussian_opacities, gaussian_sh_coefficients, None, views=views,
         image_height=h, image_width=w, sh_degree=isqrt(n) - 1, shared_campos=shared_campos, want_radii=False,
         max_instances=max_instances, check=check, cov9=True, sh_channel_major=True, depth_mode=depth_mode,
-        defer_sh=defer_sh, mse_target=mse_target, mse_weight=mse_weight, mse_count=mse_count)
+        defer_sh=defer_sh, mse_target=mse_target, mse_weight=mse_weight, mse_count=mse_count, exchange=exchange)
     res = (out[0],) if depth_mode is None else (out[0], out[2])
     if mse_target is not None:
         res = res + (out[-1],)
     return res[0] if len(res) == 1 else res
 
 
+_SHARED_CACHE: dict = {}
+
+
 def views_share_camera_centre(extrinsics: Tensor, near: Tensor) -> bool:
     """True when all views have one camera centre and one near plane (the six faces of a panorama): the
-    condition under which SH colours may be evaluated once per Gaussian (S360_FLAG_SHARED_CAMPOS).  The camera
-    tensors come from the data loader (host-resident or long materialised), so this comparison is made on the
-    host copy when there is one; for device tensors it costs one small synchronising read — pass
-    shared_campos explicitly on latency-critical paths (DecoderSplattingFused caches the answer per call shape)."""
+    condition under which SH colours may be evaluated once per Gaussian (S360_FLAG_SHARED_CAMPOS).  For device tensors
+    the comparison costs one small synchronising read; the answer is cached per (tensor storage, version), so a camera set
+    that is reused step after step is read once.  Pass shared_campos explicitly on latency-critical paths."""
     if extrinsics.shape[0] <= 1:
         return True
-    t = extrinsics[..., :3, 3]
-    return bool(((t == t[:1]).all() & (near == near.reshape(-1)[0]).all()).item())
-
-
-class CameraPrefetcher:
-    """Round-1 helper kept for its interface: it used to replay the ~60-launch torch camera glue as a captured HIP
-    graph on a side stream.  With s360_pack_views the glue is one 5-us kernel on the current stream, so there is
-    nothing left to prefetch: pack() simply calls pack_camera_views (no side stream, no graph, no process-wide state)."""
-
-    def __init__(self, device=None, use_graph: bool = False, glue: str = "native"):
-        self.glue = glue
-
-    def pack(self, extrinsics, intrinsics, near, far, background, inputs_ready: bool = True) -> Tensor:
-        return pack_camera_views(extrinsics, intrinsics, near, far, background, glue=self.glue)
+    key = (extrinsics.data_ptr(), extrinsics._version, tuple(extrinsics.shape), near.data_ptr(), near._version)
+    hit = _SHARED_CACHE.get(key)
+    if hit is None:
+        t = extrinsics[..., :3, 3]
+        hit = bool(((t == t[:1]).all() & (near == near.reshape(-1)[0]).all()).item())
+        if len(_SHARED_CACHE) > 64:
+            _SHARED_CACHE.clear()
+        _SHARED_CACHE[key] = hit
+    return hit
 
 
 def render_cube_faces(pano_c2w: Tensor, near: Tensor, far: Tensor, face_w: int, background: Tensor,
@@ -295,17 +296,15 @@ class DecoderSplattingFused(torch.nn.Module):
     which share a camera centre) in single rasteriser calls, colour and depth together."""
 
     def __init__(self, background_color=(0.0, 0.0, 0.0), views_per_group: int = 6, shared_campos: Optional[bool] = None,
-                 cameras_ready: bool = False, use_graph: bool = False, check: str = "sync", glue: str = "native"):
+                 check: str = "sync", glue: str = "native"):
         """shared_campos: None (default) = checked per group of views, with ONE small device->host read per
         forward() call (groups whose views do not share a camera centre and near plane are rendered with per-view
-        SH evaluation instead of silently taking the first view's direction); True / False = trust the caller.
-        check: "sync" (overflow flag read back per rasteriser call, automatic re-render) or "lazy".
-        cameras_ready: the camera tensors were materialised before earlier work on the current stream was
-        queued (data-loader output), so their glue may overlap with that work on the side stream."""
+        SH evaluation instead of silently taking the first view's direction); True / False = trust the caller (no read).
+        check: "sync" (overflow flag read back per rasteriser call, automatic re-render) or "lazy"."""
         super().__init__()
         self.register_buffer("background_color", torch.tensor(background_color, dtype=torch.float32), persistent=False)
         self.views_per_group, self.shared_campos = views_per_group, shared_campos
-        self.check, self.glue = check, glue   # cameras_ready / use_graph: accepted for compatibility, unused
+        self.check, self.glue = check, glue
 
     def forward(self, gaussians, extrinsics, intrinsics, near, far, image_shape, depth_mode=None) -> "DecoderOutput":
         b, v = extrinsics.shape[:2]

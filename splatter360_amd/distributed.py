@@ -78,8 +78,14 @@ _TRIU = ((0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2))
 def _pack_small(d_means: Tensor, d_cov: Tensor, d_op: Tensor) -> Tensor:
     """means (3) + the 6 unique covariance entries + opacity (1) -> ONE contiguous [P,10] buffer (40 B / Gaussian): a single
     larger all-reduce instead of three, and the [P,3,3] covariance gradient (whose lower triangle is identically zero —
-    the rasteriser reads the upper triangle only, cuda_splatting.py:115,123) does not travel as 9 floats."""
+    the rasteriser reads the upper triangle only, cuda_splatting.py:115,123) does not travel as 9 floats.  RESTRICTION: a
+    non-zero strict lower triangle of d_cov (possible only for gradients produced outside the rasteriser) does not travel;
+    set S360_CHECK_TRIL=1 to assert its absence."""
     p = d_means.shape[0]
+    if d_cov.dim() == 3 and __debug__ and os.environ.get("S360_CHECK_TRIL"):
+        # only the upper triangle travels: a gradient in the strict lower triangle (a regulariser acting on the [P,3,3]
+        # covariances outside the rasteriser) would be dropped silently — fold it into the upper entries before calling
+        assert float(torch.tril(d_cov, -1).abs().max()) == 0.0, "covariance gradient has a non-zero strict lower triangle"
     c6 = d_cov if d_cov.dim() == 2 else torch.stack([d_cov[:, r, c] for r, c in _TRIU], dim=1)
     return torch.cat([d_means.reshape(p, 3), c6.reshape(p, 6), d_op.reshape(p, 1)], dim=1).contiguous()
 
@@ -98,14 +104,16 @@ def _unpack_small(buf: Tensor, cov_like: Tensor):
 class FactoredExchange:
     """The gradient exchange of one step, split in two so that it can sit behind other GPU work:
     start_factored_exchange() issues the collectives (they wait, on the communicator's stream, for the backward kernels
-    that produced the gradients and then run beside whatever the compute stream does next — in bench.py the NEXT
-    micro-batch's forward); finish() waits for the all-gathers, rebuilds the summed dL/dSH locally
-    (s360_sh_backward over the N gathered factors), waits for the all-reduce and returns the four summed gradients
-    (also stored in .grad of the tensors handed to start)."""
+    that produced the gradients and then run beside whatever the compute stream does next); finish() waits for the all-gathers,
+    rebuilds the summed dL/dSH locally (s360_sh_backward over the N gathered factors), waits for the all-reduce and RETURNS the
+    four summed gradients.  It does not touch the parameters' .grad: a .grad assigned here would be accumulated into by a
+    backward that runs between start and finish and travel through the next exchange a second time; callers that
+    want .grad semantics use sync_gradients_factored (blocking), which assigns after the exchange is complete."""
 
-    def __init__(self, params, deferred, small, rgb_all, rep_all, works_ag, work_ar, world):
+    def __init__(self, params, deferred, small, rgb_all, rep_all, works_ag, work_ar, world, means_snapshot):
         self.params, self.deferred, self.small = params, deferred, small
         self.rgb_all, self.rep_all, self.works_ag, self.work_ar, self.world = rgb_all, rep_all, works_ag, work_ar, world
+        self.means_snapshot = means_snapshot
         self.result = None
 
     def finish(self):
@@ -117,22 +125,23 @@ class FactoredExchange:
         for w in self.works_ag:
             w.wait()
         # dL/dSH = sum over ranks of Y(dir_rank) (x) dRGB_rank, rebuilt locally while the packed buffer is still being
-        # all-reduced (every rank's view-direction term of dL/dmean is already inside its d_means: s360_backward_split)
-        d_sh = rasterizer.finish_deferred_sh(d.prm, self.rep_all.reshape(self.world, -1), d.means3D, d.shs,
+        # all-reduced (every rank's view-direction term of dL/dmean is already inside its d_means: s360_backward_split).
+        # Directions come from the means AS THEY WERE at the backward (snapshot taken by start: an optimiser step may have
+        # moved the parameter since).
+        d_sh = rasterizer.finish_deferred_sh(d.prm, self.rep_all.reshape(self.world, -1), self.means_snapshot, d.shs,
                                              self.rgb_all.view(self.world, -1, 4))
         if self.work_ar is not None:
             self.work_ar.wait()
         d_means, d_cov, d_op = _unpack_small(self.small, covariances)
-        means.grad, covariances.grad, harmonics.grad = d_means.reshape(means.shape), d_cov, d_sh
-        opacities.grad = d_op.reshape(opacities.shape)
-        self.result = (means.grad, covariances.grad, harmonics.grad, opacities.grad)
+        self.result = (d_means.reshape(means.shape), d_cov, d_sh, d_op.reshape(opacities.shape))
         return self.result
 
 
 def start_factored_exchange(means: Tensor, covariances: Tensor, harmonics: Tensor, opacities: Tensor, deferred,
                             group=None) -> FactoredExchange:
     """Gradient exchange for views sharded one panorama per rank, exploiting that each rank's dL/dSH is the
-    rank-1 product Y(dir_rank) (x) dL/dRGB_rank per Gaussian:
+    rank-1 product Y(dir_rank) (x) dL/dRGB_rank per Gaussian (the pipelined form; `exchange_chunked` below is the one that
+    hides the exchange INSIDE a step):
         all-reduce   [means | cov6 | opacity].grad packed as one [P,10] buffer      (40 B per Gaussian)
         all-gather   d_rgb_sum[P,4] and one camera record per rank                    (16 B per Gaussian per rank)
     then every rank rebuilds the summed dL/dSH (and the view-direction part of dL/dmean) locally with
@@ -167,13 +176,87 @@ def start_factored_exchange(means: Tensor, covariances: Tensor, harmonics: Tenso
         work_ar = dist.all_reduce(small, op=dist.ReduceOp.SUM, group=group, async_op=True)
     else:
         rgb_all, rep_all = rgb, rep
-    return FactoredExchange((means, covariances, harmonics, opacities), d, small, rgb_all, rep_all, works_ag, work_ar, world)
+    snap = d.means3D.clone() if world > 1 else d.means3D      # 12 B / Gaussian: see FactoredExchange.finish
+    return FactoredExchange((means, covariances, harmonics, opacities), d, small, rgb_all, rep_all, works_ag, work_ar, world, snap)
 
 
 def sync_gradients_factored(means: Tensor, covariances: Tensor, harmonics: Tensor, opacities: Tensor, deferred,
                             group=None) -> None:
-    """start_factored_exchange(...).finish(): the blocking form (kept for callers that do not pipeline steps)."""
-    start_factored_exchange(means, covariances, harmonics, opacities, deferred, group).finish()
+    """start_factored_exchange(...).finish(), then the summed gradients are stored in .grad of the four tensors: the blocking
+    form (nothing can run between the two halves, so assigning .grad is safe here)."""
+    g = start_factored_exchange(means, covariances, harmonics, opacities, deferred, group).finish()
+    means.grad, covariances.grad, harmonics.grad, opacities.grad = g
+
+
+def chunk_bounds(p: int, n_chunks: int, align: int = 256) -> List[tuple]:
+    """[0, p) cut into at most n_chunks contiguous ranges whose starts are multiples of `align` (whole workgroups of the
+    per-Gaussian kernels); the last range is ragged.  Fewer ranges come back when p is small."""
+    n_chunks = max(1, int(n_chunks))
+    per = max(align, ((p + n_chunks - 1) // n_chunks + align - 1) // align * align)
+    return [(lo, min(p, lo + per)) for lo in range(0, p, per)] if p > 0 else []
+
+
+def exchange_chunked(p: int, packed: Tensor, rgb: Tensor, rep_view: Tensor, produce, rebuild_sh, n_chunks: int = 4, group=None,
+                     group_gather=None, timings: Optional[dict] = None) -> None:
+    """The gradient exchange of ONE step hidden inside that step (no gradient accumulation assumed): the per-Gaussian tail of
+    the backward is cut into Gaussian ranges and every range's collectives start as soon as its rows exist, so RCCL runs under
+    the tail kernels of the following ranges and under the local dL/dSH rebuilds of the preceding ones.
+
+        for each range c (in order):   produce(lo, hi)                 -> packed[lo:hi] (40 B/Gaussian), rgb[lo:hi] (16 B)
+                                       all-gather  rgb[lo:hi]          (async, `group_gather` or `group`)
+                                       all-reduce  packed[lo:hi]       (async, `group`)
+        for each range c (in order):   wait its all-gather;  rebuild_sh(lo, hi, rgb_all_c[world, hi-lo, 4], rep_all[world, 44])
+        wait every all-reduce                                           -> packed holds the sums over ranks
+
+    `produce` / `rebuild_sh` are the caller's kernels (rasterizer._RasterizeViews.backward: s360_backward_gaussians /
+    s360_sh_backward; the CPU tests: numpy slices of oracle gradients).  rep_view[44]: this rank's representative camera record
+    (all views of a call share the camera centre).  A second process group (`group_gather`) puts the all-gathers on their own
+    communicator so that they do not queue behind the all-reduces of earlier ranges.  Works for world size 1 (no collectives).
+    Per rank and step at N ranks: receives 2 (N-1)/N * 40 B + (N-1) * 16 B per Gaussian (0.19 GB at N = 8, 1 M Gaussians) —
+    what it can hide under: the tail kernels of the following ranges and the dL/dSH rebuilds of the preceding ones (a few hundred
+    microseconds at 1 M, N = 8) — DESIGN.md section 5 does the arithmetic."""
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    bounds = chunk_bounds(p, n_chunks)
+    if world == 1:
+        for lo, hi in bounds:
+            produce(lo, hi)
+        rep_all = rep_view.reshape(1, -1)
+        for lo, hi in bounds:
+            rebuild_sh(lo, hi, rgb[lo:hi].reshape(1, hi - lo, 4), rep_all)
+        return
+    gg = group_gather if group_gather is not None else group
+    rep_all = torch.empty((world * rep_view.numel(),), dtype=rep_view.dtype, device=rep_view.device)
+    work_rep = dist.all_gather_into_tensor(rep_all, rep_view.reshape(-1).contiguous(), group=gg, async_op=True)
+    gathers, reduces = [], []
+    for lo, hi in bounds:
+        produce(lo, hi)
+        buf = torch.empty((world * (hi - lo), 4), dtype=rgb.dtype, device=rgb.device)      # dim-0 concat: gloo-compatible
+        gathers.append((buf, dist.all_gather_into_tensor(buf, rgb[lo:hi], group=gg, async_op=True)))
+        reduces.append(dist.all_reduce(packed[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True))
+    work_rep.wait()
+    rep_all = rep_all.reshape(world, -1)
+    for (lo, hi), (buf, w) in zip(bounds, gathers):
+        w.wait()
+        rebuild_sh(lo, hi, buf.view(world, hi - lo, 4), rep_all)
+    for w in reduces:
+        w.wait()
+    if timings is not None:
+        timings["chunks"] = len(bounds)
+
+
+class ExchangeConfig:
+    """Hand this to rasterize_views(..., exchange=ExchangeConfig(...)) (views sharing one camera centre): the node's backward
+    then returns the per-Gaussian gradients SUMMED over the ranks of `group` (every rank renders its own panorama of the same
+    replicated cloud), exchanged range by range inside the backward itself — see exchange_chunked."""
+
+    def __init__(self, group=None, n_chunks: int = 4, group_gather=None):
+        self.group, self.n_chunks, self.group_gather = group, int(n_chunks), group_gather
+
+    def world(self) -> int:
+        return dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
+
+    def rank(self) -> int:
+        return dist.get_rank(self.group) if (dist.is_available() and dist.is_initialized()) else 0
 
 
 def reduce_scatter_gradients(grads: Sequence[Tensor], group=None) -> List[Tensor]:

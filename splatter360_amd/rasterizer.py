@@ -220,7 +220,11 @@ class _RasterizeViews(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, cov6, views, cfg, mse_target=None):
         (h, w, sh_degree, shared_campos, max_instances, check, want_radii, cov9, sh_channel_major, keep_slots, depth_mode,
-         defer_sh, mse_weight, mse_count, spherical) = cfg
+         defer_sh, mse_weight, mse_count, spherical, exchange) = cfg
+        if exchange is not None and (shs is None or not (shared_campos or int(views.shape[0]) == 1) or defer_sh):
+            raise RuntimeError("exchange=: the chunked gradient exchange needs SH colours and views sharing one camera centre "
+                               "(and replaces defer_sh)")
+        ctx.exchange = exchange
         if spherical and (mse_target is not None or int(views.shape[0]) % 2):
             raise RuntimeError("spherical mode: views come in (camera, seam ghost) pairs; the fused loss epilogue is cube-face only")
         if not means3D.is_cuda:
@@ -315,6 +319,45 @@ class _RasterizeViews(torch.autograd.Function):
             d_col = torch.empty((p, 3), dtype=torch.float32, device=dev) if (col is not None and need[3]) else None
             bws = torch.empty(lay.backward_bytes, dtype=torch.uint8, device=dev)
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            if ctx.exchange is not None:
+                # multi-GPU: the per-Gaussian gradients leave this node already SUMMED over the ranks — composite once, then
+                # the per-Gaussian tail range by range with every range's collectives in flight behind the next one
+                from . import distributed
+                ex = ctx.exchange
+                lib = _lib.lib()
+                rc = lib.s360_backward_composite(C.byref(prm), _ptr(vw), _ptr(state.workspace), lay.total_bytes, _ptr(g), _ptr(g_scale),
+                                                 _ptr(gd), dm, _ptr(bws), lay.backward_bytes, stream)
+                _lib.check(rc, "s360_backward_composite")
+                packed = torch.empty((p, 10), dtype=torch.float32, device=dev)
+                rgb = torch.empty((p, 4), dtype=torch.float32, device=dev)
+                if d_sh is None:
+                    d_sh = torch.empty_like(sh)
+                rank = ex.rank()
+
+                def produce(lo, hi):
+                    _lib.check(lib.s360_backward_gaussians(C.byref(prm), _ptr(vw), _ptr(m3), _ptr(c6), _ptr(sh), _ptr(state.workspace),
+                                                           lay.total_bytes, int(gd is not None), dm, lo, hi - lo, rank, _ptr(packed),
+                                                           _ptr(d_m2), _ptr(rgb), _ptr(bws), lay.backward_bytes, stream),
+                               "s360_backward_gaussians")
+
+                slab = sh.shape[1] * sh.shape[2]
+
+                def rebuild_sh(lo, hi, rgb_all, rep_all):
+                    sub = _lib.S360Params()
+                    C.memmove(C.byref(sub), C.byref(prm), C.sizeof(sub))
+                    sub.P, sub.V = hi - lo, int(rep_all.shape[0])
+                    st2 = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+                    _lib.check(lib.s360_sh_backward(C.byref(sub), int(rgb_all.shape[0]), _ptr(rep_all.contiguous()),
+                                                    C.c_void_p(m3.data_ptr() + 12 * lo), _ptr(rgb_all.contiguous()),
+                                                    C.c_void_p(d_sh.data_ptr() + 4 * slab * lo), st2), "s360_sh_backward")
+
+                distributed.exchange_chunked(p, packed, rgb, vw[0], produce, rebuild_sh, n_chunks=ex.n_chunks, group=ex.group,
+                                             group_gather=ex.group_gather)
+                _lib.check(lib.s360_unpack_gradients(_ptr(packed), p, int(c6.dim() == 3), _ptr(d_m3), _ptr(d_c6), _ptr(d_op), stream),
+                           "s360_unpack_gradients")
+                if d_m2 is not None:
+                    d_m2 = d_m2.sum(0) if v > 1 else d_m2[0]
+                return d_m3, d_m2, (d_sh if need[2] else None), None, d_op.view(-1, 1), d_c6, None, None, None
             if ctx.defer_sh:
                 # multi-GPU factored form: no SH pass here; the caller exchanges d_rgb_sum and finishes with
                 # finish_deferred_sh() (see distributed.sync_gradients_factored)
@@ -396,7 +439,7 @@ def rasterize_views(means3D: Tensor, cov6: Tensor, opacities: Tensor, shs: Optio
                     check: str = "sync", want_radii: bool = True, means2D: Optional[Tensor] = None,
                     cov9: bool = False, sh_channel_major: bool = False, keep_slots: bool = False,
                     depth_mode: Optional[str] = None, defer_sh: bool = False, mse_target: Optional[Tensor] = None,
-                    mse_weight: float = 1.0, mse_count: Optional[int] = None, spherical: bool = False):
+                    mse_weight: float = 1.0, mse_count: Optional[int] = None, spherical: bool = False, exchange=None):
     """Render V views ([V,44] packed, see pack_views) of one cloud.  cov9: cov6 is [P,3,3];
     sh_channel_major: shs is [P,3,M] (the reference's Gaussians layouts, consumed without copies).
     When no input requires grad the instance-slot tables (backward-only state) are skipped unless
@@ -411,6 +454,9 @@ def rasterize_views(means3D: Tensor, cov6: Tensor, opacities: Tensor, shs: Optio
     check="sync": read the overflow flag after the forward (one host sync, like upstream's own
     scan read-back) and re-run with the exact size if the binning capacity was exceeded;
     check="lazy": never synchronise — validate later via last_state().overflowed().
+    exchange=distributed.ExchangeConfig(...) (views sharing one camera centre, SH colours): the gradients this node returns
+    are SUMMED over the ranks of the process group — each rank renders its own views of the same replicated cloud — and the
+    exchange runs range by range inside the backward (distributed.exchange_chunked).
     spherical=True: native equirectangular splat mode (S360_FLAG_SPHERICAL; no reference counterpart, specified by the
     oracle's geo_sph): `views` = pack_views_spherical(...) — (camera, seam ghost) pairs — and the result is one
     [H,W] equirectangular image per pair; means2D gradients are in pixel units."""
@@ -420,7 +466,7 @@ def rasterize_views(means3D: Tensor, cov6: Tensor, opacities: Tensor, shs: Optio
     if depth_mode is not None and depth_mode not in DEPTH_MODES:
         raise ValueError(f"depth_mode must be one of {sorted(DEPTH_MODES)}")
     cfg = (image_height, image_width, sh_degree, shared_campos, max_instances, check, want_radii, cov9,
-           sh_channel_major, keep_slots, depth_mode, defer_sh, mse_weight, mse_count, bool(spherical))
+           sh_channel_major, keep_slots, depth_mode, defer_sh, mse_weight, mse_count, bool(spherical), exchange)
     images, radii, depth, loss, clipped = _RasterizeViews.apply(means3D, means2D, shs, colors_precomp, op2, cov6, views,
                                                                 cfg, mse_target)
     images.s360_deferred = _RasterizeViews.last_holder      # see deferred_of()

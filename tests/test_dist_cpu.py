@@ -4,6 +4,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -208,7 +209,12 @@ def _pipelined_worker(rank, world, port, q):
         inp = _pipe_inputs(rank, step)
         # --- "forward of micro-batch `step`" would be enqueued here, while the previous exchange is in flight ---
         if pending is not None:
+            # a backward that runs between start and finish accumulates into .grad — finish() must leave .grad alone,
+            # or the reduced gradients would travel through the next exchange a second time
+            sentinel = torch.full_like(means, 7.0)
+            means.grad = sentinel
             results.append([g.double().numpy().copy() for g in pending.finish()])
+            assert means.grad is sentinel and cov.grad is None and op.grad is None and sh.grad is None
         # --- "backward of micro-batch `step`": fills .grad and leaves the deferred SH factors ---
         means.grad, cov.grad, op.grad = torch.tensor(inp["means"]), torch.tensor(inp["cov"]), torch.tensor(inp["op"])
         d_rgb_sum = torch.zeros((257, 4), dtype=torch.float32)
@@ -265,6 +271,95 @@ def test_four_rank_pipelined_factored_exchange_and_reduce_scatter():
         lo, hi = rank * per, min(257, (rank + 1) * per)
         np.testing.assert_allclose(mine[0], full_m[lo:hi], rtol=1e-12, atol=1e-12)
         np.testing.assert_allclose(mine[1], full_c[lo:hi], rtol=1e-12, atol=1e-12)
+
+
+def _chunk_inputs(rank, p):
+    rng = np.random.default_rng(500 + rank)
+    vis = rng.uniform(size=p) < 0.6
+    return dict(packed=rng.standard_normal((p, 10)), drgb=(rng.standard_normal((p, 3)) * vis[:, None]).astype(np.float32), vis=vis,
+                campos=np.array([0.1 * rank, 0.03 * rank, -0.07 * rank], np.float32))
+
+
+def _chunked_worker(rank, world, port, q, p, n_chunks, two_groups):
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    sys.path[:0] = [str(root), str(root / "tests")]
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from splatter360_amd import distributed as D
+    D.init(backend="gloo")
+    gg = dist.new_group(list(range(world))) if two_groups else None
+    m3, _ = _pipe_cloud(p)
+    inp = _chunk_inputs(rank, p)
+    packed = torch.zeros((p, 10), dtype=torch.float64)
+    rgb = torch.zeros((p, 4), dtype=torch.float32)
+    d_sh = torch.zeros((p, 25, 3), dtype=torch.float32)
+    rep = torch.zeros(44, dtype=torch.float32)
+    rep[32:35] = torch.tensor(inp["campos"]); rep[40] = 1.0
+    produced, rebuilt = [], []
+
+    def produce(lo, hi):                      # stands in for s360_backward_gaussians on rows [lo, hi)
+        assert not produced or produced[-1][1] == lo
+        produced.append((lo, hi))
+        packed[lo:hi] = torch.tensor(inp["packed"][lo:hi])
+        rgb[lo:hi, :3] = torch.tensor(inp["drgb"][lo:hi])
+        rgb[lo:hi, 3] = torch.where(torch.tensor(inp["vis"][lo:hi]), torch.tensor(rank, dtype=torch.int32), torch.tensor(-1, dtype=torch.int32)).view(torch.float32)
+
+    def rebuild_sh(lo, hi, rgb_all, rep_all):  # stands in for s360_sh_backward on rows [lo, hi)
+        assert tuple(rgb_all.shape) == (world, hi - lo, 4) and tuple(rep_all.shape) == (world, 44)
+        rebuilt.append((lo, hi))
+        d_sh[lo:hi] = _sh_pass_restated(None, rep_all, torch.tensor(m3[lo:hi]), d_sh[lo:hi], rgb_all)
+
+    D.exchange_chunked(p, packed, rgb, rep, produce, rebuild_sh, n_chunks=n_chunks, group=None, group_gather=gg)
+    assert produced == rebuilt == D.chunk_bounds(p, n_chunks) and produced[0][0] == 0 and produced[-1][1] == p
+    q.put((rank, packed.numpy(), d_sh.double().numpy(), len(produced)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,p,n_chunks,two_groups", [(8, 1000, 4, False), (8, 1000, 4, True), (3, 700, 8, False), (2, 100, 4, False)])
+def test_chunked_exchange_sums_every_range_over_the_ranks(world, p, n_chunks, two_groups):
+    """distributed.exchange_chunked at world size 8 (gloo): ragged Gaussian ranges (1000 = 3 x 256 + 232), more ranges asked
+    for than the cloud has workgroups, a cloud smaller than one workgroup, all-gathers on their own process group — every
+    rank ends with the packed gradients summed over the ranks and dL/dSH rebuilt from all ranks' factors, range by range."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_chunked_worker, args=(r, world, port, q, p, n_chunks, two_groups)) for r in range(world)]
+    [pr.start() for pr in procs]
+    outs = [q.get(timeout=300) for _ in range(world)]
+    [pr.join(timeout=60) for pr in procs]
+    assert all(pr.exitcode == 0 for pr in procs)
+    ins = [_chunk_inputs(r, p) for r in range(world)]
+    want_packed = sum(i["packed"] for i in ins)
+    m3, _ = _pipe_cloud(p)
+    rgb = torch.zeros((world, p, 4), dtype=torch.float32)
+    views = torch.zeros((world, 44), dtype=torch.float32)
+    for r, i in enumerate(ins):
+        rgb[r, :, :3] = torch.tensor(i["drgb"])
+        rgb[r, :, 3] = torch.where(torch.tensor(i["vis"]), torch.tensor(r, dtype=torch.int32), torch.tensor(-1, dtype=torch.int32)).view(torch.float32)
+        views[r, 32:35] = torch.tensor(i["campos"]); views[r, 40] = 1.0
+    want_sh = _sh_pass_restated(None, views, torch.tensor(m3), torch.zeros((p, 25, 3)), rgb).double().numpy()
+    from splatter360_amd.distributed import chunk_bounds
+    for rank, packed, d_sh, n in outs:
+        assert n == len(chunk_bounds(p, n_chunks))
+        np.testing.assert_allclose(packed, want_packed, rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(d_sh, want_sh, rtol=1e-5, atol=1e-5)
+
+
+def test_chunked_exchange_single_process_and_bounds():
+    from splatter360_amd import distributed as D
+    assert D.chunk_bounds(0, 4) == [] and D.chunk_bounds(5, 4) == [(0, 5)]
+    for p, n in ((1 << 20, 4), (1000, 4), (1 << 20 | 3, 7), (257, 2)):
+        b = D.chunk_bounds(p, n)
+        assert b[0][0] == 0 and b[-1][1] == p and len(b) <= n and all(lo % 256 == 0 for lo, _ in b)
+        assert all(b[i][1] == b[i + 1][0] for i in range(len(b) - 1))
+    calls = []
+    packed, rgb = torch.zeros((600, 10)), torch.zeros((600, 4))
+    D.exchange_chunked(600, packed, rgb, torch.zeros(44), lambda lo, hi: calls.append(("p", lo, hi)),
+                       lambda lo, hi, a, b: calls.append(("s", lo, hi, tuple(a.shape), tuple(b.shape))), n_chunks=3)
+    assert calls == [("p", 0, 256), ("p", 256, 512), ("p", 512, 600), ("s", 0, 256, (1, 256, 4), (1, 44)),
+                     ("s", 256, 512, (1, 256, 4), (1, 44)), ("s", 512, 600, (1, 88, 4), (1, 44))]
 
 
 def test_bench_launches_its_own_ranks_when_started_plainly():
