@@ -511,11 +511,16 @@ __global__ __launch_bounds__(64) void k_sh_bwd(KParams kp, const S360View* __res
 
 using namespace s360;
 
+#ifdef S360_DEBUG_LAUNCH  /* compile-time diagnostic (-DS360_DEBUG_LAUNCH): no environment reads in the host path */
+#define S360_LAUNCH_DIAG(e) fprintf(stderr, "s360: %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__)
+#else
+#define S360_LAUNCH_DIAG(e) ((void)0)
+#endif
 #define S360_CHECK_LAUNCH()                                                                          \
     do {                                                                                             \
         hipError_t e_ = hipGetLastError();                                                           \
         if (e_ != hipSuccess) {                                                                      \
-            if (getenv("S360_DEBUG")) fprintf(stderr, "s360: %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+            S360_LAUNCH_DIAG(e_);                                                                    \
             return S360_E_LAUNCH;                                                                    \
         }                                                                                            \
     } while (0)

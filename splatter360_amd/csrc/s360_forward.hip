@@ -1306,13 +1306,6 @@ using namespace s360;
 
 static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
-// Experiment knob: reserving (unused) dynamic LDS caps the number of resident workgroups per CU so
-// that the tail of a launch is balanced dynamically by the dispatcher.
-static size_t occupancy_cap_lds(const char* env, size_t dflt) {
-    const char* e = getenv(env);
-    return e ? (size_t)atol(e) : dflt;
-}
-
 extern "C" int s360_layout(const S360Params* prm, S360Layout* out) {
     if (!prm || !out) return S360_E_BADARG;
     if (prm->P < 0 || prm->V < 1 || prm->V > S360_MAX_VIEWS || prm->H < 1 || prm->W < 1) return S360_E_BADARG;
@@ -1363,11 +1356,16 @@ extern "C" int s360_layout(const S360Params* prm, S360Layout* out) {
     return S360_OK;
 }
 
+#ifdef S360_DEBUG_LAUNCH  /* compile-time diagnostic (-DS360_DEBUG_LAUNCH): no environment reads in the host path */
+#define S360_LAUNCH_DIAG(e) fprintf(stderr, "s360: %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__)
+#else
+#define S360_LAUNCH_DIAG(e) ((void)0)
+#endif
 #define S360_CHECK_LAUNCH()                                                                          \
     do {                                                                                             \
         hipError_t e_ = hipGetLastError();                                                           \
         if (e_ != hipSuccess) {                                                                      \
-            if (getenv("S360_DEBUG")) fprintf(stderr, "s360: %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+            S360_LAUNCH_DIAG(e_);                                                                    \
             return S360_E_LAUNCH;                                                                    \
         }                                                                                            \
     } while (0)
@@ -1415,7 +1413,7 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
     uint64_t* keys = (uint64_t*)(ws + L.keys);
     uint64_t* keys_alt = (uint64_t*)(ws + L.keys_alt);
     uint32_t* chunk_start = (uint32_t*)(ws + L.chunk_start);
-    uint32_t* tile_order = getenv("S360_NO_TILE_ORDER") ? nullptr : (uint32_t*)(ws + L.tile_order);
+    uint32_t* tile_order = (uint32_t*)(ws + L.tile_order);
     uint32_t* list = (uint32_t*)(ws + L.list);
     float* final_T = (float*)(ws + L.final_T);
     uint32_t* n_contrib = (uint32_t*)(ws + L.n_contrib);
@@ -1530,11 +1528,11 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
         uint32_t* dbg = header + 8;           // S360_DBG_COUNT counters
 #endif
         if (depth_maps)
-            hipLaunchKernelGGL(k_render<true>, rgrid, rblock, occupancy_cap_lds("S360_RENDER_LDS", 0), st, kp, views, tile_start,
+            hipLaunchKernelGGL(k_render<true>, rgrid, rblock, 0, st, kp, views, tile_start,
                                list, recA, recB, recC, images, final_T, n_contrib, tile_max_contrib, strip_last, dbg,
                                depths, depth_maps, depth_mode, ep, kp.P > 0 ? tile_order : (const uint32_t*)nullptr, surv, surv_count);
         else
-            hipLaunchKernelGGL(k_render<false>, rgrid, rblock, occupancy_cap_lds("S360_RENDER_LDS", 0), st, kp, views, tile_start,
+            hipLaunchKernelGGL(k_render<false>, rgrid, rblock, 0, st, kp, views, tile_start,
                                list, recA, recB, recC, images, final_T, n_contrib, tile_max_contrib, strip_last, dbg,
                                depths, depth_maps, depth_mode, ep, kp.P > 0 ? tile_order : (const uint32_t*)nullptr, surv, surv_count);
         if (ep.target && ep.loss_out)

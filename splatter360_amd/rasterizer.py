@@ -106,8 +106,19 @@ def pack_views_spherical(pano_c2w: Tensor, background: Tensor, scale=1.0, near=0
     return v.repeat_interleave(2, dim=0).contiguous()
 
 
-def default_capacity(p: int, v: int) -> int:
-    """Initial capacity (instances = (Gaussian, tile) pairs) of the binning buffers."""
+_CAPACITY_HINT: dict = {}   # (P, V, H, W) -> instances of the most recent call of that shape whose count was read back
+
+
+def default_capacity(p: int, v: int, h: int = 0, w: int = 0) -> int:
+    """Capacity (instances = (Gaussian, tile) pairs) of the binning buffers and, through them, of the backward scratch
+    (192 B per instance of capacity): 1.25 x the instance count the previous call of this shape produced, once a caller has read
+    one back (check="sync" reads it with the overflow flag; RasterState.num_rendered() / overflowed() do too), else the
+    first-call guess 1.5 P V.  A call that overflows is re-rendered with the exact size in check="sync" mode; in check="lazy"
+    mode the caller must validate (last_state().overflowed()) — a scene that grows by more than a quarter between two steps
+    without anyone reading a count is the one case that needs max_instances= passed explicitly."""
+    hint = _CAPACITY_HINT.get((p, v, h, w))
+    if hint is not None:
+        return int(min(2**32 - 1, max(1 << 16, hint + hint // 4 + (1 << 16))))
     return int(min(2**32 - 1, max(1 << 16, (3 * p * v) // 2 + (1 << 18))))
 
 
@@ -159,12 +170,19 @@ class RasterState:
         bits = (vis[None, :] >> torch.arange(p.V, device=vis.device, dtype=torch.int32)[:, None]) & 1
         return torch.where(bits.bool(), raw, torch.zeros_like(raw))
 
+    def _read_header(self):
+        h = self.header()[:2].cpu()          # one synchronising read for both words
+        n, over = int(h[0]) & 0xFFFFFFFF, bool(int(h[1]))
+        p = self.prm
+        _CAPACITY_HINT[(p.P, p.V, p.H, p.W)] = n    # sizes the next call of this shape (default_capacity)
+        return n, over
+
     def num_rendered(self) -> int:
         """Host read of num_instances (synchronises)."""
-        return int(self.header()[0].item()) & 0xFFFFFFFF
+        return self._read_header()[0]
 
     def overflowed(self) -> bool:
-        return bool(self.header()[1].item())
+        return self._read_header()[1]
 
 
 def _ptr(t: Optional[Tensor]):
@@ -250,7 +268,7 @@ class _RasterizeViews(torch.autograd.Function):
                 _lib.FLAG_COV9 if cov9 else 0) | (_lib.FLAG_SH_CHANNEL_MAJOR if sh_channel_major else 0) | (
                 0 if (needs_bwd or keep_slots) else _lib.FLAG_FORWARD_ONLY) | (
                 _lib.FLAG_SH_DEG4_IGNORED if SH_DEG4_IGNORED else 0) | (_lib.FLAG_SPHERICAL if spherical else 0)
-            prm.max_instances = int(max_instances) if max_instances else default_capacity(p, v)
+            prm.max_instances = int(max_instances) if max_instances else default_capacity(p, v, int(h), int(w))
             mse = None
             if mse_target is not None:
                 tgt = _f32c(mse_target, "mse_target")
