@@ -502,6 +502,9 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* l
 constexpr uint32_t SORT_SHORT = 2048;
 constexpr uint32_t SORT_CHUNK = 4096;
 constexpr uint32_t MAX_PASSES = 4;
+#ifndef S360_MERGE_TAIL_GRID
+#define S360_MERGE_TAIL_GRID 128
+#endif
 
 constexpr int TS_BLOCK = 1024;  // one workgroup; 16 waves: 1 536 tiles in two sweeps (a 256-thread block needed six: 10 us of barriers)
 __global__ __launch_bounds__(TS_BLOCK) void k_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_start,
@@ -905,10 +908,11 @@ __global__ __launch_bounds__(512) void k_merge_pass(const uint32_t* __restrict__
 // positions), which tolerates VIRTUAL +inf padding at indices >= n: an ascending compare-exchange never
 // moves a padding key inwards, so nothing outside [0, n) is ever read or written.  Rare and slow.
 __global__ __launch_bounds__(S360_BLOCK) void k_sort_tiles_global(const uint32_t* __restrict__ tile_start, uint64_t* __restrict__ keys,
-                                                                 uint32_t* __restrict__ list, uint32_t lo, uint32_t cap) {
-    const uint32_t s = min(tile_start[blockIdx.x], cap), e = min(tile_start[blockIdx.x + 1], cap);
+                                                                 uint32_t* __restrict__ list, uint32_t lo, uint32_t cap, int nt) {
+  for (int tile = blockIdx.x; tile < nt; tile += gridDim.x) {   // grid-stride over the tiles: almost always nothing to do
+    const uint32_t s = min(tile_start[tile], cap), e = min(tile_start[tile + 1], cap);
     const uint32_t n = e - s;
-    if (n <= lo) return;
+    if (n <= lo) continue;   // block-uniform
     uint32_t npad = 1;
     while (npad < n) npad <<= 1;
     uint64_t* kk = keys + s;
@@ -943,6 +947,8 @@ __global__ __launch_bounds__(S360_BLOCK) void k_sort_tiles_global(const uint32_t
         }
     }
     for (uint32_t i = threadIdx.x; i < n; i += S360_BLOCK) list[s + i] = (uint32_t)kk[i];
+    __syncthreads();
+  }
 }
 
 // ------------------------------------------------------------------------------ composite
@@ -1508,11 +1514,17 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
             const size_t lds512 = (4096 + 512) * 8;
             hipLaunchKernelGGL(k_sort_stage1, dim3(cgrid + nt + 1), dim3(512), lds512, st, tile_start, chunk_start, nt, keys, keys_alt, list,
                                kp.cap, passes, cgrid, tile_count, tile_order);
+            // every merge kernel walks the chunk table grid-stride, so its grid is a matter of speed only: pass 0 gets the full
+            // grid; the later passes — needed by lists beyond 8 192 / 16 384 / 32 768 keys, i.e. by few tiles or none, and
+            // launched unconditionally because the host never reads a list length back — get S360_MERGE_TAIL_GRID blocks (an
+            // empty 1 024-block launch costs 4.3 us, a 128-block one 2 us); same for the global-memory fallback beyond 65 536
+            const unsigned tail_grid = cgrid < (unsigned)S360_MERGE_TAIL_GRID ? cgrid : (unsigned)S360_MERGE_TAIL_GRID;
             for (uint32_t p = 0; p < passes; ++p)
-                hipLaunchKernelGGL(k_merge_pass, dim3(cgrid), dim3(512), lds512, st, tile_start, chunk_start, nt, keys, keys_alt, list,
-                                   kp.cap, p, passes, header);
+                hipLaunchKernelGGL(k_merge_pass, dim3(p == 0 ? cgrid : tail_grid), dim3(512), lds512, st, tile_start, chunk_start, nt, keys,
+                                   keys_alt, list, kp.cap, p, passes, header);
             if ((size_t)global_lo < cap_keys)  // otherwise no list can be that long
-                hipLaunchKernelGGL(k_sort_tiles_global, dim3(nt), dim3(S360_BLOCK), 0, st, tile_start, keys, list, global_lo, kp.cap);
+                hipLaunchKernelGGL(k_sort_tiles_global, dim3((unsigned)nt < tail_grid ? nt : tail_grid), dim3(S360_BLOCK), 0, st, tile_start,
+                                   keys, list, global_lo, kp.cap, nt);
         }
         S360_CHECK_LAUNCH();
     }
