@@ -23,7 +23,7 @@
 
 namespace s360 {
 
-constexpr int GREC = 12;  // floats per partial record: gx gy gA gB | gC gop gr gg | gb gz - -
+constexpr int GREC = 4 * PREC_F4;  // floats per partial record slot: gx gy gA gB | gC gop gr gg | gb gz - - (| pad)
 
 // Sum of the per-(instance, quadrant) partial gradients of every (view, Gaussian) pair, SLOT-parallel: thread i owns instance
 // slot i — it adds that slot's (up to four) quadrant partials in quadrant order, parks the 10-float sum in LDS, and the thread
@@ -40,7 +40,7 @@ __device__ __forceinline__ void slot_sum(const float4* __restrict__ part, const 
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         if ((vw4 >> (8 * q)) & 0xFFu) {
-            const float4* r = part + ((size_t)i * 4 + q) * 3;
+            const float4* r = part + ((size_t)i * 4 + q) * PREC_F4;
             const float4 r0 = r[0], r1 = r[1], r2 = r[2];
             s[0] += r0.x; s[1] += r0.y; s[2] += r0.z; s[3] += r0.w;
             s[4] += r1.x; s[5] += r1.y; s[6] += r1.z; s[7] += r1.w;

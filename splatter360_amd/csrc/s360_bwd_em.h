@@ -311,7 +311,7 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
         if (lane_ok && anyc && inst < kp.cap) {
             const float ln2 = 0.6931471805599453f;
             // dG/d(centre) = ln2 G (2 a' dx + b' dy) with the pre-scaled conic; dG/d(conic a) = -G dx^2 / 2 ...
-            float4* o = part + ((size_t)inst * 4 + wave) * 3;
+            float4* o = part + ((size_t)inst * 4 + wave) * PREC_F4;
             o[0] = make_float4(ln2 * (X.x + X.y), ln2 * (Y.x + Y.y), -0.5f * (XX.x + XX.y), -(XY.x + XY.y));
             o[1] = make_float4(-0.5f * (YY.x + YY.y), g_op.x + g_op.y, g_r.x + g_r.y, g_g.x + g_g.y);
             o[2] = make_float4(g_b.x + g_b.y, g_z.x + g_z.y, 0.f, 0.f);

@@ -26,8 +26,15 @@ static inline int s360_effective_degree(const S360Params* prm) {
     return (prm->sh_degree > 3 && (prm->flags & S360_FLAG_SH_DEG4_IGNORED)) ? 3 : prm->sh_degree;
 }
 
+// float4s per (instance, quadrant) partial raster-gradient record of the backward: 3 = packed 48-byte records, 4 = 64-byte aligned
+// slots (a record never straddles a 128-byte line or a 32-byte write granule)
+#ifndef S360_PREC_F4
+#define S360_PREC_F4 4
+#endif
+
 namespace s360 {
 
+constexpr int PREC_F4 = S360_PREC_F4;
 constexpr int SUB_W = S360_SUB_W, SUB_H = 64 / S360_SUB_W;
 __device__ __forceinline__ int sub_ox(int w) { return SUB_W == 16 ? 0 : 8 * (w & 1); }
 __device__ __forceinline__ int sub_oy(int w) { return SUB_W == 16 ? 4 * w : 8 * (w >> 1); }
