@@ -1,6 +1,7 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun): bench JSON + rocprofv3 kernel stats + PMC HBM counters (separate passes, as
-# MI355X_MICROARCH.md prescribes: --pmc never together with the trace domains other than --kernel-trace).
+# MI355X_MICROARCH.md prescribes: --pmc never together with the trace domains other than --kernel-trace) + the side configurations
+# (forward only, evaluation shape, BASELINE configs[4] single-rank shape, 2 gloo ranks on the one GPU).
 # Outputs land in gpurun_out/$ROUND/ ; scripts/make_profiles.py then condenses them into profiles/.
 # meta.json stamps the kernel-source hash the counters belong to (bench.py refuses to quote a mismatching profile).
 set -x
@@ -12,6 +13,10 @@ cd /tmp && export TMPDIR=/tmp
 python -c "import sys, json; sys.path.insert(0, '$R'); from splatter360_amd import _lib; print(json.dumps(dict(source_hash=_lib.source_hash(), gaussians=1048576, face=256)))" > $O/meta.json
 python $R/bench.py --steps 20 --warmup 5 > $O/bench_fwdbwd.json 2> $O/bench_fwdbwd.err
 python $R/bench.py --steps 20 --warmup 5 --mode fwd --cpu-baseline 0 > $O/bench_fwd.json 2> $O/bench_fwd.err
+python $R/bench.py --steps 10 --warmup 3 --mode eval --cpu-baseline 0 > $O/bench_eval.json 2> /dev/null
+python $R/bench.py --steps 10 --warmup 3 --pano-h 1024 --cpu-baseline 0 > $O/bench_c5_4m_fwdbwd.json 2> /dev/null
+python $R/bench.py --steps 10 --warmup 3 --pano-h 1024 --mode fwd --cpu-baseline 0 > $O/bench_c5_4m_fwd.json 2> /dev/null
+S360_DIST_BACKEND=gloo S360_FORCE_DEVICE=0 python $R/bench.py --gpus 2 --steps 4 --warmup 2 --cpu-baseline 0 > $O/bench_2rank_gloo_one_gpu.json 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python $R/bench.py --steps 20 --warmup 5 --cpu-baseline 0 > $O/bench_under_rocprof.json 2>/dev/null
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -o pmc -- python $R/bench.py --steps 3 --warmup 1 --cpu-baseline 0 > /dev/null 2>&1

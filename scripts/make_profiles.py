@@ -12,8 +12,11 @@ with open(P / f"{ROUND}_bench_kernel_stats.csv", "w") as f:
     w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
     for r in rows[:45]:
         w.writerow([r["Name"].split("(")[0][:90], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
-for n in ("bench_fwdbwd.json", "bench_fwd.json", "bench_under_rocprof.json"):
-    txt = (O / n).read_text().strip().splitlines()
+for n in ("bench_fwdbwd.json", "bench_fwd.json", "bench_under_rocprof.json", "bench_eval.json", "bench_c5_4m_fwdbwd.json",
+          "bench_c5_4m_fwd.json", "bench_2rank_gloo_one_gpu.json"):
+    if not (O / n).exists():
+        continue
+    txt = [l for l in (O / n).read_text().strip().splitlines() if l.startswith("{")]
     (P / (ROUND + "_" + n)).write_text(json.dumps(json.loads(txt[-1]), indent=1) + "\n")
 subprocess.run([sys.executable, str(R / "scripts" / "make_pmc_json.py"), str(P / "pmc_latest.json"),
                 str(O / "pmc_FETCH_SIZE" / "pmc_counter_collection.csv"), str(O / "pmc_WRITE_SIZE" / "pmc_counter_collection.csv")], check=True)

@@ -499,8 +499,13 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* l
 // Lists longer than SORT_SHORT keys are sorted as chunks of SORT_CHUNK keys (k_sort_stage1: one 512-thread
 // workgroup per chunk) followed, when there is more than one chunk, by global merge passes (k_merge_pass);
 // chunk_start[t] = number of such chunks before tile t (0 chunks for the short tiles, which have their own class).
+#ifndef S360_SORT_THREADS
+#define S360_SORT_THREADS 512   // workgroup of the sort kernels; a chunk is 8 keys per thread
+#endif
+constexpr int SORT_THREADS = S360_SORT_THREADS;
 constexpr uint32_t SORT_SHORT = 2048;
-constexpr uint32_t SORT_CHUNK = 4096;
+constexpr uint32_t SORT_CHUNK = 8 * SORT_THREADS;
+static_assert(SORT_SHORT % SORT_THREADS == 0 && SORT_SHORT <= SORT_CHUNK, "short lists: SORT_SHORT / SORT_THREADS keys per thread");
 constexpr uint32_t MAX_PASSES = 4;
 #ifndef S360_MERGE_TAIL_GRID
 #define S360_MERGE_TAIL_GRID 128
@@ -785,7 +790,7 @@ __device__ __forceinline__ ChunkUnit chunk_unit(const uint32_t* __restrict__ til
 // path), then one block per tile for the short lists, and a last block that deals the composite's tile order — round 1
 // ran the short-list sort and the ordering on a process-wide side stream (fork / join events, a host mutex): ~25 us of
 // cross-stream latency inside a 100-us stage, and library-global state.
-__global__ __launch_bounds__(512) void k_sort_stage1(const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ chunk_start,
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_stage1(const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ chunk_start,
                                                     int nt, uint64_t* __restrict__ keys, uint64_t* __restrict__ alt,
                                                     uint32_t* __restrict__ list, uint32_t cap, uint32_t max_passes, uint32_t cgrid,
                                                     const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_order) {
@@ -798,7 +803,7 @@ __global__ __launch_bounds__(512) void k_sort_stage1(const uint32_t* __restrict_
             if (u.valid && u.passes <= max_passes) {
                 const uint32_t c0 = u.k * SORT_CHUNK, len = min(SORT_CHUNK, u.n - c0);
                 uint64_t* dst = ((u.passes & 1u) ? alt : keys) + u.s + c0;
-                block_merge_sort<512, 8>(keys + u.s + c0, dst, u.passes == 0 ? list + u.s : nullptr, len, lds_m);
+                block_merge_sort<SORT_THREADS, 8>(keys + u.s + c0, dst, u.passes == 0 ? list + u.s : nullptr, len, lds_m);
             }
             __syncthreads();
         }
@@ -809,10 +814,10 @@ __global__ __launch_bounds__(512) void k_sort_stage1(const uint32_t* __restrict_
         const uint32_t s = min(tile_start[tile], cap), e = min(tile_start[tile + 1], cap);
         const uint32_t n = e - s;
         if (n == 0 || n > SORT_SHORT) return;
-        block_merge_sort<512, 4>(keys + s, keys + s, list + s, n, lds_m);
+        block_merge_sort<SORT_THREADS, (int)(SORT_SHORT / SORT_THREADS)>(keys + s, keys + s, list + s, n, lds_m);
         return;
     }
-    if (tile_order) order_units_body<512>(tile_count, tile_order, nt);  // longest list first (dispatch order of k_render)
+    if (tile_order) order_units_body<SORT_THREADS>(tile_count, tile_order, nt);  // longest list first (dispatch order of k_render)
 }
 
 // Merge path over two sorted runs in global memory: number of A elements among the first d outputs.  Executed by
@@ -837,11 +842,11 @@ __device__ __forceinline__ uint32_t merge_path_global_wave(const uint64_t* __res
     return lo;
 }
 
-__global__ __launch_bounds__(512) void k_merge_pass(const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ chunk_start,
+__global__ __launch_bounds__(SORT_THREADS) void k_merge_pass(const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ chunk_start,
                                                    int nt, uint64_t* __restrict__ keys, uint64_t* __restrict__ alt,
                                                    uint32_t* __restrict__ list, uint32_t cap, uint32_t pass, uint32_t max_passes,
                                                    const uint32_t* __restrict__ header) {
-    constexpr int THREADS = 512, E = 8;
+    constexpr int THREADS = SORT_THREADS, E = 8;
     extern __shared__ __attribute__((aligned(16))) uint64_t lds_m[];  // [SORT_CHUNK + SORT_CHUNK/E] skewed
     __shared__ uint32_t s_part[2];
 #define S360_PHYS(i) ((i) + (i) / E)
@@ -1511,8 +1516,8 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
             const uint32_t global_lo = SORT_CHUNK << passes;  // lists longer than this go to the global-memory network
             // the chunk blocks walk the chunk table grid-stride, so a moderate grid serves any count
             const unsigned cgrid = (unsigned)min((size_t)1024, (size_t)kp.cap / SORT_CHUNK + (size_t)kp.cap / SORT_SHORT + 2);
-            const size_t lds512 = (4096 + 512) * 8;
-            hipLaunchKernelGGL(k_sort_stage1, dim3(cgrid + nt + 1), dim3(512), lds512, st, tile_start, chunk_start, nt, keys, keys_alt, list,
+            const size_t lds512 = (size_t)(SORT_CHUNK + SORT_CHUNK / 8) * 8;
+            hipLaunchKernelGGL(k_sort_stage1, dim3(cgrid + nt + 1), dim3(SORT_THREADS), lds512, st, tile_start, chunk_start, nt, keys, keys_alt, list,
                                kp.cap, passes, cgrid, tile_count, tile_order);
             // every merge kernel walks the chunk table grid-stride, so its grid is a matter of speed only: pass 0 gets the full
             // grid; the later passes — needed by lists beyond 8 192 / 16 384 / 32 768 keys, i.e. by few tiles or none, and
@@ -1520,7 +1525,7 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
             // empty 1 024-block launch costs 4.3 us, a 128-block one 2 us); same for the global-memory fallback beyond 65 536
             const unsigned tail_grid = cgrid < (unsigned)S360_MERGE_TAIL_GRID ? cgrid : (unsigned)S360_MERGE_TAIL_GRID;
             for (uint32_t p = 0; p < passes; ++p)
-                hipLaunchKernelGGL(k_merge_pass, dim3(p == 0 ? cgrid : tail_grid), dim3(512), lds512, st, tile_start, chunk_start, nt, keys,
+                hipLaunchKernelGGL(k_merge_pass, dim3(p == 0 ? cgrid : tail_grid), dim3(SORT_THREADS), lds512, st, tile_start, chunk_start, nt, keys,
                                    keys_alt, list, kp.cap, p, passes, header);
             if ((size_t)global_lo < cap_keys)  // otherwise no list can be that long
                 hipLaunchKernelGGL(k_sort_tiles_global, dim3((unsigned)nt < tail_grid ? nt : tail_grid), dim3(S360_BLOCK), 0, st, tile_start,
