@@ -699,7 +699,20 @@ __device__ __forceinline__ void block_merge_sort(const uint64_t* __restrict__ in
     }
 #pragma unroll
     for (int q = 0; q < E; ++q) lds_m[S360_PHYS((uint32_t)(tid * E + q))] = k[q];
-    __syncthreads();
+    // While a pair of runs (2 * width keys) lies inside the 64 * E keys of ONE wave, only that wave reads and writes them: the
+    // workgroup barrier of those passes (6 of the 9 for a full list, each waiting for the slowest of 8 waves) is replaced by
+    // wave-level ordering — DS operations of a wave execute in order; the fence keeps the compiler from moving them.
+#define S360_SORT_SYNC(w)                                                      \
+    do {                                                                       \
+        if (2u * (w) <= 64u * E) {                                             \
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");             \
+            __builtin_amdgcn_wave_barrier();                                   \
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");             \
+        } else {                                                               \
+            __syncthreads();                                                   \
+        }                                                                      \
+    } while (0)
+    S360_SORT_SYNC(E);
     // runs of length `width` are sorted; merge neighbouring pairs until one run remains.  Runs that lie
     // entirely in the padding (start >= n) never need merging, so stop once width covers n.
     uint32_t npad = E;
@@ -730,13 +743,15 @@ __device__ __forceinline__ void block_merge_sort(const uint64_t* __restrict__ in
                 kb = b < width ? S360_B(b) : ~0ull;
             }
         }
-        __syncthreads();
+        S360_SORT_SYNC(width);          // every read of this pass precedes its writes
 #pragma unroll
         for (int q = 0; q < E; ++q) lds_m[S360_PHYS(out0 + q)] = k[q];
-        __syncthreads();
+        S360_SORT_SYNC(2u * width);     // ... which the NEXT pass (runs of 2 * width, pairs of 4 * width) reads
 #undef S360_A
 #undef S360_B
     }
+    __syncthreads();
+#undef S360_SORT_SYNC
 #pragma unroll
     for (int q = 0; q < E; ++q) {
         const uint32_t i = (uint32_t)(tid * E + q);
