@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define S360_ABI_VERSION 17
+#define S360_ABI_VERSION 18
 #define S360_MAX_VIEWS 8
 #define S360_TILE 16
 
@@ -290,8 +290,9 @@ int s360_pack_views(const float* extrinsics, const float* intrinsics, const floa
  * Gaussian-adapter tail: the producer of the per-Gaussian buffers this library rasterises — replaces
  * GaussianAdapterERP.forward (/root/reference/src/model/encoder/common/gaussian_adapter_erp.py:50-119: scale map :63-78,
  * quaternion normalisation :82, sh_mask :38-47,86, world covariance :89-92 with build_covariance of
- * common/gaussians.py:33-44, sphere un-projection src/geometry/sphere_projection.py:6-86 in the 'hm3d' / 'replica'
- * ERP convention of src/geometry/utils360.py:93-104,148-153) in one launch.
+ * common/gaussians.py:33-44, sphere un-projection src/geometry/sphere_projection.py:6-86 in the ERP convention of the dataset,
+ * src/geometry/utils360.py:37-153: erp_convention 0 = 'hm3d' / 'replica' (the reference's configs), 1 = 'm3d',
+ * 2 = 'residential', 3 = 'CoffeeArea' / 'outdoor_colmap') in one launch.
  *   extrinsics[V,4,4] context-panorama camera-to-world; depths[V,Gv]; raw_gaussians[V,Gv,7+3*d_sh] = 3 scale logits,
  *   quaternion (x,y,z,w), 3*d_sh SH coefficients channel-major; Gv = H*W*per_ray Gaussians per view, ray-major;
  *   sh_rotation[V,d_sh,d_sh] or NULL (= identity): per-view SH rotation, only the (2l+1)x(2l+1) diagonal blocks are
@@ -319,12 +320,12 @@ int s360_adapter_forward(const float* extrinsics, const float* depths, const flo
                          const float* sh_rotation, int32_t n_views, int32_t per_view, int32_t H, int32_t W,
                          int32_t per_ray, int32_t d_sh, float scale_min, float scale_max, float eps, float* means,
                          float* covariances, int32_t cov9, float* harmonics, float* scales_out,
-                         float* rotations_out, void* stream);
+                         float* rotations_out, int32_t erp_convention, void* stream);
 int s360_adapter_backward(const float* extrinsics, const float* depths, const float* raw_gaussians,
                           const float* sh_rotation, int32_t n_views, int32_t per_view, int32_t H, int32_t W,
                           int32_t per_ray, int32_t d_sh, float scale_min, float scale_max, float eps,
                           const float* d_means, const float* d_covariances, int32_t cov9, const float* d_harmonics,
-                          float* d_depths, float* d_raw_gaussians, void* stream);
+                          float* d_depths, float* d_raw_gaussians, int32_t erp_convention, void* stream);
 
 /*
  * Cube -> equirectangular stitch: replaces Cube2Equirec.forward

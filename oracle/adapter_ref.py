@@ -38,14 +38,30 @@ def sh_mask(d_sh: int) -> Tensor:
     return m
 
 
-def erp_directions(h: int, w: int, device=None) -> Tensor:
-    """utils360.py:93-104,148-153 ('hm3d' / 'replica')."""
+def erp_directions(h: int, w: int, device=None, dataset_name: str = "hm3d") -> Tensor:
+    """utils360.py: get_xy_coords :21-35, equi_2_spherical :37-104, spherical_2_cartesian :106-153, per dataset name."""
     x = torch.linspace(0, w - 1, w, device=device)
     y = torch.linspace(0, h - 1, h, device=device)
-    theta = (0.5 - (x + 0.5) / w) * 2 * math.pi
-    phi = -((y + 0.5) / h - 0.5) * math.pi
-    phi, theta = torch.meshgrid(phi, theta, indexing="ij")
-    return torch.stack([torch.cos(phi) * torch.sin(theta), torch.sin(phi), torch.cos(phi) * torch.cos(theta)], -1).reshape(-1, 3)
+    y, x = torch.meshgrid(y, x, indexing="ij")
+    if dataset_name in ("hm3d", "replica"):
+        theta = (0.5 - (x + 0.5) / w) * 2 * math.pi
+        phi = -((y + 0.5) / h - 0.5) * math.pi
+        d = (torch.cos(phi) * torch.sin(theta), torch.sin(phi), torch.cos(phi) * torch.cos(theta))
+    elif dataset_name == "m3d":
+        theta = x / (w - 1) * 2 * math.pi - 0.5 * math.pi
+        phi = y / (h - 1) * math.pi
+        d = (torch.sin(phi) * torch.cos(theta), torch.cos(phi), torch.sin(phi) * torch.sin(theta))
+    elif dataset_name == "residential":
+        theta = math.pi * (2 * x / (w - 1) - 1.5)
+        phi = math.pi * (0.5 - y / (h - 1))
+        d = (torch.cos(theta) * torch.cos(phi), torch.sin(phi), torch.sin(theta) * torch.cos(phi))
+    elif dataset_name in ("CoffeeArea", "outdoor_colmap"):
+        theta = (-2 * math.pi / (w - 1)) * x + 2 * math.pi
+        phi = (math.pi / (h - 1)) * y
+        d = (torch.sin(phi) * torch.cos(theta), torch.sin(phi) * torch.sin(theta), torch.cos(phi))
+    else:
+        raise Exception(dataset_name)
+    return torch.stack(d, -1).reshape(-1, 3)
 
 
 def quaternion_to_matrix(q: Tensor, eps: float = 1e-8) -> Tensor:
@@ -72,7 +88,7 @@ def rotate_sh_blocks(sh: Tensor, rot: Optional[Tensor]) -> Tensor:
 
 def adapter_tail_torch(extrinsics: Tensor, depths: Tensor, opacities: Tensor, raw_gaussians: Tensor, image_shape,
                        scale_min: float, scale_max: float, sh_rotation: Optional[Tensor] = None, eps: float = 1e-8,
-                       per_ray: int = 1, differentiable_means: bool = False):
+                       per_ray: int = 1, differentiable_means: bool = False, dataset_name: str = "hm3d"):
     """GaussianAdapterERP.forward on flat tensors: extrinsics[V,4,4] (context panorama c2w), depths / opacities[V,Gv]
     (Gv = h*w*per_ray, ray-major), raw_gaussians[V,Gv,7+3*d_sh] = (3 scale logits, 4 quaternion xyzw, 3*d_sh SH as (xyz d_sh)).
     Returns a namespace with fields means, covariances, scales, rotations, harmonics, opacities ([V,Gv,...])."""
@@ -90,7 +106,7 @@ def adapter_tail_torch(extrinsics: Tensor, depths: Tensor, opacities: Tensor, ra
     cov = r @ s @ s.transpose(-1, -2) @ r.transpose(-1, -2)
     c2w = extrinsics[:, None, :3, :3]
     cov = c2w @ cov @ c2w.transpose(-1, -2)
-    dirs = erp_directions(h, w, depths.device).repeat_interleave(per_ray, 0)          # [Gv,3]
+    dirs = erp_directions(h, w, depths.device, dataset_name).repeat_interleave(per_ray, 0)          # [Gv,3]
     dm = depths if differentiable_means else depths.detach()   # sphere_projection.py:14: the reference computes means under no_grad
     pts = dirs[None] * dm[..., None]
     means = torch.einsum("vij,vgj->vgi", extrinsics[:, :3, :3], pts) + extrinsics[:, None, :3, 3]

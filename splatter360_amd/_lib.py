@@ -26,7 +26,7 @@ FLAG_SH_CHANNEL_MAJOR = 4
 FLAG_FORWARD_ONLY = 8
 FLAG_SH_DEG4_IGNORED = 16
 FLAG_SPHERICAL = 32
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 
 class S360Params(C.Structure):
@@ -155,9 +155,9 @@ def lib() -> C.CDLL:
     l.s360_pack_views.argtypes = [vp] * 5 + [i32, i32, i32, vp, vp]
     f32 = C.c_float
     l.s360_adapter_forward.restype = C.c_int
-    l.s360_adapter_forward.argtypes = [vp] * 4 + [i32] * 6 + [f32] * 3 + [vp, vp, i32, vp, vp, vp, vp]
+    l.s360_adapter_forward.argtypes = [vp] * 4 + [i32] * 6 + [f32] * 3 + [vp, vp, i32, vp, vp, vp, i32, vp]
     l.s360_adapter_backward.restype = C.c_int
-    l.s360_adapter_backward.argtypes = [vp] * 4 + [i32] * 6 + [f32] * 3 + [vp, vp, i32, vp, vp, vp, vp]
+    l.s360_adapter_backward.argtypes = [vp] * 4 + [i32] * 6 + [f32] * 3 + [vp, vp, i32, vp, vp, vp, i32, vp]
     l.s360_sh_rotation_blocks.restype = C.c_int
     l.s360_sh_rotation_blocks.argtypes = [vp, i32, i32, i32, vp, vp]
     l.s360_cube2erp_forward.restype = C.c_int

@@ -7,8 +7,9 @@ Reference behaviour mirrored (file:line under /root/reference):
   * GaussianAdapterERP.forward            src/model/encoder/common/gaussian_adapter_erp.py:50-119
       scale map :63-78, quaternion normalisation :82, sh_mask :38-47,86, world covariance :89-92
   * build_covariance / quaternion_to_matrix  src/model/encoder/common/gaussians.py:8-44  (xyzw order)
-  * sphere un-projection                  src/geometry/sphere_projection.py:6-86 with the 'hm3d' / 'replica' ERP
-                                          convention of src/geometry/utils360.py:93-104,148-153
+  * sphere un-projection                  src/geometry/sphere_projection.py:6-86 with the dataset's ERP ray convention
+                                          (src/geometry/utils360.py:37-153: 'hm3d' / 'replica', 'm3d', 'residential',
+                                          'CoffeeArea' / 'outdoor_colmap')
   * rotate_sh                             src/misc/sh_rotation.py:10-30 — block-diagonal Wigner-D product.  The per-view
                                           matrices (`sh_rotation[V, d_sh, d_sh]`, only the (2l+1)x(2l+1) diagonal blocks
                                           are read; None = identity) come from sh_rotation_blocks() — one small kernel,
@@ -43,6 +44,10 @@ class AdapterGaussians:
     opacities: Tensor
 
 
+# ERP ray convention per dataset name (src/geometry/utils360.py:37-153); the reference's configs use 'hm3d' and 'replica'
+ERP_CONVENTIONS = {"hm3d": 0, "replica": 0, "m3d": 1, "residential": 2, "CoffeeArea": 3, "outdoor_colmap": 3}
+
+
 def sh_mask(d_sh: int) -> Tensor:
     """1 for DC, 0.1 * 0.25^degree for the higher bands (gaussian_adapter_erp.py:38-47)."""
     deg = math.isqrt(d_sh) - 1
@@ -50,16 +55,6 @@ def sh_mask(d_sh: int) -> Tensor:
     for l in range(1, deg + 1):
         m[l * l:(l + 1) * (l + 1)] = 0.1 * 0.25 ** l
     return m
-
-
-def erp_directions(h: int, w: int, device=None) -> Tensor:
-    """[h*w,3] unit rays of the ERP pixel centres, 'hm3d'/'replica' convention (utils360.py:93-104,148-153)."""
-    x = torch.linspace(0, w - 1, w, device=device)
-    y = torch.linspace(0, h - 1, h, device=device)
-    theta = (0.5 - (x + 0.5) / w) * 2 * math.pi
-    phi = -((y + 0.5) / h - 0.5) * math.pi
-    phi, theta = torch.meshgrid(phi, theta, indexing="ij")
-    return torch.stack([torch.cos(phi) * torch.sin(theta), torch.sin(phi), torch.cos(phi) * torch.cos(theta)], -1).reshape(-1, 3)
 
 
 def wigner_blocks_e3nn(c2w_rotations: Tensor, d_sh: int) -> Tensor:
@@ -99,7 +94,7 @@ def sh_rotation_blocks(rotations: Tensor, d_sh: int) -> Tensor:
 class _AdapterTail(torch.autograd.Function):
     @staticmethod
     def forward(ctx, extrinsics, depths, raw, sh_rot, cfg):
-        h, w, per_ray, smin, smax, eps, cov6, diff_means = cfg
+        h, w, per_ray, smin, smax, eps, cov6, diff_means, conv = cfg
         if not depths.is_cuda:
             raise RuntimeError("the fused adapter tail runs on the GPU only: depths is a CPU tensor (no CPU path; "
                                "oracle/adapter_ref.py is the checker the tests use)")
@@ -121,9 +116,9 @@ class _AdapterTail(torch.autograd.Function):
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             rc = _lib.lib().s360_adapter_forward(_ptr(ext), _ptr(dep), _ptr(rw), _ptr(rot), v, gv, h, w, per_ray, d_sh,
                                                  C.c_float(smin), C.c_float(smax), C.c_float(eps), _ptr(means), _ptr(cov),
-                                                 int(not cov6), _ptr(harm), _ptr(scales), _ptr(rots), stream)
+                                                 int(not cov6), _ptr(harm), _ptr(scales), _ptr(rots), conv, stream)
         _lib.check(rc, "s360_adapter_forward")
-        ctx.cfg = (h, w, per_ray, smin, smax, eps, cov6, v, gv, d_sh, diff_means)
+        ctx.cfg = (h, w, per_ray, smin, smax, eps, cov6, v, gv, d_sh, diff_means, conv)
         ctx.save_for_backward(ext, dep, rw, rot)
         if diff_means:
             ctx.mark_non_differentiable(scales, rots)
@@ -134,7 +129,7 @@ class _AdapterTail(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_means, d_cov, d_harm, _ds, _dr):
         ext, dep, rw, rot = ctx.saved_tensors
-        h, w, per_ray, smin, smax, eps, cov6, v, gv, d_sh, diff_means = ctx.cfg
+        h, w, per_ray, smin, smax, eps, cov6, v, gv, d_sh, diff_means, conv = ctx.cfg
         dev = dep.device
         z = lambda t, shape: torch.zeros(shape, dtype=torch.float32, device=dev) if t is None else t.detach().float().contiguous()
         d_means = z(d_means, (v, gv, 3)) if diff_means else None   # NULL at the ABI: means detached like the reference's
@@ -146,25 +141,29 @@ class _AdapterTail(torch.autograd.Function):
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             rc = _lib.lib().s360_adapter_backward(_ptr(ext), _ptr(dep), _ptr(rw), _ptr(rot), v, gv, h, w, per_ray, d_sh,
                                                   C.c_float(smin), C.c_float(smax), C.c_float(eps), _ptr(d_means), _ptr(d_cov),
-                                                  int(not cov6), _ptr(d_harm), _ptr(d_dep), _ptr(d_raw), stream)
+                                                  int(not cov6), _ptr(d_harm), _ptr(d_dep), _ptr(d_raw), conv, stream)
         _lib.check(rc, "s360_adapter_backward")
         return None, d_dep, d_raw, None, None
 
 
 def adapter_tail(extrinsics: Tensor, depths: Tensor, opacities: Tensor, raw_gaussians: Tensor, image_shape,
                  scale_min: float, scale_max: float, sh_rotation: Optional[Tensor] = None, eps: float = 1e-8,
-                 per_ray: int = 1, cov6: bool = False, differentiable_means: bool = False) -> AdapterGaussians:
+                 per_ray: int = 1, cov6: bool = False, differentiable_means: bool = False,
+                 dataset_name: str = "hm3d") -> AdapterGaussians:
     """The fused adapter tail (s360_adapter_forward / backward): extrinsics[V,4,4] (context panorama c2w), depths /
     opacities[V,Gv] (Gv = h*w*per_ray, ray-major), raw_gaussians[V,Gv,7+3*d_sh] = (3 scale logits, 4 quaternion xyzw, 3*d_sh SH
     as (xyz d_sh)); differentiable w.r.t. depths and raw_gaussians, opacities pass through.  Like the reference, whose sphere
     un-projection runs under torch.no_grad() (src/geometry/sphere_projection.py:14-86), the returned means are DETACHED: depth
     receives gradient through the scales only.  differentiable_means=True is this project's opt-in deviation (the
     un-projection's own term is added).  cov6=True returns the covariance as its 6 unique entries (00,01,02,11,12,22) — the
-    rasteriser's cov3D_precomp layout — instead of [.,3,3]."""
+    rasteriser's cov3D_precomp layout — instead of [.,3,3].  dataset_name selects the ERP ray convention (ERP_CONVENTIONS)."""
     h, w = image_shape
+    if dataset_name not in ERP_CONVENTIONS:
+        raise Exception(f"no ERP convention for dataset {dataset_name!r} (src/geometry/utils360.py raises for it too)")
     means, cov, harm, scales, rots = _AdapterTail.apply(extrinsics, depths, raw_gaussians, sh_rotation,
                                                         (int(h), int(w), int(per_ray), float(scale_min), float(scale_max),
-                                                         float(eps), bool(cov6), bool(differentiable_means)))
+                                                         float(eps), bool(cov6), bool(differentiable_means),
+                                                         ERP_CONVENTIONS[dataset_name]))
     return AdapterGaussians(means, cov, scales, rots, harm, opacities)
 
 
@@ -195,8 +194,8 @@ class GaussianAdapterERP(torch.nn.Module):
         if not depths.is_cuda:
             raise RuntimeError("GaussianAdapterERP runs on the GPU only: depths is a CPU tensor (no CPU path in the product; "
                                "oracle/adapter_ref.py is the checker the tests use)")
-        if dataset_name not in ("hm3d", "replica"):
-            raise Exception(f"ERP convention of dataset {dataset_name!r} is not implemented (utils360.py:93-104 'hm3d'/'replica' only)")
+        if dataset_name not in ERP_CONVENTIONS:
+            raise Exception(f"no ERP convention for dataset {dataset_name!r} (src/geometry/utils360.py raises for it too)")
         b, v, r, srf, spp = depths.shape
         h, w = image_shape
         if srf != 1 and raw_gaussians.shape[4] == 1:
@@ -212,7 +211,8 @@ class GaussianAdapterERP(torch.nn.Module):
             rot = self.sh_rotation(ext[:, :3, :3])
         raw = raw_gaussians.broadcast_to(b, v, r, srf, spp, self.d_in).reshape(b * v, r * srf * spp, self.d_in)
         g = adapter_tail(ext, depths.reshape(b * v, -1), opacities.reshape(b * v, -1), raw, (h, w), self.scale_min, self.scale_max,
-                         sh_rotation=rot, eps=eps, per_ray=srf * spp, differentiable_means=self.differentiable_means)
+                         sh_rotation=rot, eps=eps, per_ray=srf * spp, differentiable_means=self.differentiable_means,
+                         dataset_name=dataset_name)
         sh5 = (b, v, r, srf, spp)
         return AdapterGaussians(g.means.reshape(*sh5, 3), g.covariances.reshape(*sh5, 3, 3), g.scales.reshape(*sh5, 3),
                                 g.rotations.reshape(*sh5, 4), g.harmonics.reshape(*sh5, 3, self.d_sh), opacities)

@@ -21,7 +21,7 @@ namespace s360 {
 constexpr float kPi = 3.14159265358979323846f;
 
 struct AdapterParams {
-    int V, Gv, H, W, per_ray, d_sh, cov9;
+    int V, Gv, H, W, per_ray, d_sh, cov9, conv;
     float smin, smax, eps;
 };
 
@@ -30,15 +30,40 @@ __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(
 // sh_mask per degree: 1, 0.1 * 0.25^l (gaussian_adapter_erp.py:38-47), rounded to float32 like the reference's buffer
 __device__ constexpr float kShMask[5] = {1.0f, 0.025f, 0.00625f, 0.0015625f, 0.000390625f};
 
-// unit ray of ERP pixel n (row-major) in the 'hm3d' / 'replica' convention
-__device__ __forceinline__ void erp_dir(int n, int H, int W, float* d) {
+// unit ray of ERP pixel n (row-major) in the reference's per-dataset conventions (src/geometry/utils360.py: equi_2_spherical
+// :37-104 pixel -> (theta, phi), spherical_2_cartesian :106-153 -> xyz):
+//   0 'hm3d' / 'replica'  1 'm3d'  2 'residential'  3 'CoffeeArea' / 'outdoor_colmap'
+__device__ __forceinline__ void erp_dir(int n, int H, int W, int conv, float* d) {
     const int y = n / W, x = n - y * W;
-    const float theta = ((0.5f - ((float)x + 0.5f) / (float)W) * 2.0f) * kPi;
-    const float phi = -((((float)y + 0.5f) / (float)H - 0.5f)) * kPi;
-    const float cp = cosf(phi);
-    d[0] = cp * sinf(theta);
-    d[1] = sinf(phi);
-    d[2] = cp * cosf(theta);
+    if (conv == 0) {
+        const float theta = ((0.5f - ((float)x + 0.5f) / (float)W) * 2.0f) * kPi;
+        const float phi = -((((float)y + 0.5f) / (float)H - 0.5f)) * kPi;
+        const float cp = cosf(phi);
+        d[0] = cp * sinf(theta);
+        d[1] = sinf(phi);
+        d[2] = cp * cosf(theta);
+    } else if (conv == 1) {
+        const float theta = (float)x / (float)(W - 1) * 2.0f * kPi - 0.5f * kPi;
+        const float phi = (float)y / (float)(H - 1) * kPi;
+        const float sp = sinf(phi);
+        d[0] = sp * cosf(theta);
+        d[1] = cosf(phi);
+        d[2] = sp * sinf(theta);
+    } else if (conv == 2) {
+        const float theta = kPi * (2.0f * (float)x / (float)(W - 1) - 1.5f);
+        const float phi = kPi * (0.5f - (float)y / (float)(H - 1));
+        const float cp = cosf(phi);
+        d[0] = cosf(theta) * cp;
+        d[1] = sinf(phi);
+        d[2] = sinf(theta) * cp;
+    } else {
+        const float theta = (-2.0f * kPi / (float)(W - 1)) * (float)x + 2.0f * kPi;
+        const float phi = (kPi / (float)(H - 1)) * (float)y;
+        const float sp = sinf(phi);
+        d[0] = sp * cosf(theta);
+        d[1] = sp * sinf(theta);
+        d[2] = cosf(phi);
+    }
 }
 
 struct QuatGeom {
@@ -107,7 +132,7 @@ __global__ __launch_bounds__(256) void k_adapter_fwd(AdapterParams ap, const flo
     }
     // mean
     float d[3];
-    erp_dir(g / ap.per_ray, ap.H, ap.W, d);
+    erp_dir(g / ap.per_ray, ap.H, ap.W, ap.conv, d);
     const float p[3] = {d[0] * depth, d[1] * depth, d[2] * depth};
 #pragma unroll
     for (int a = 0; a < 3; ++a) means[3 * i + a] = (E[4 * a] * p[0] + E[4 * a + 1] * p[1] + E[4 * a + 2] * p[2]) + E[4 * a + 3];
@@ -240,7 +265,7 @@ __global__ __launch_bounds__(256) void k_adapter_bwd(AdapterParams ap, const flo
         dd += ds[k] * base[k] * px;
     }
     float d[3];
-    erp_dir(g / ap.per_ray, ap.H, ap.W, d);
+    erp_dir(g / ap.per_ray, ap.H, ap.W, ap.conv, d);
     if (d_means) {  // opt-in: the reference un-projects under torch.no_grad() (sphere_projection.py:14-86) — its means are
                     // detached and depth receives gradient through the scales only (d_means == NULL, the default)
         const float* gm = d_means + 3 * i;
@@ -357,12 +382,13 @@ extern "C" int s360_adapter_forward(const float* extrinsics, const float* depths
                                     const float* sh_rotation, int32_t n_views, int32_t per_view, int32_t H, int32_t W,
                                     int32_t per_ray, int32_t d_sh, float scale_min, float scale_max, float eps,
                                     float* means, float* covariances, int32_t cov9, float* harmonics, float* scales_out,
-                                    float* rotations_out, void* stream) {
+                                    float* rotations_out, int32_t erp_convention, void* stream) {
+    if (erp_convention < 0 || erp_convention > 3 || (erp_convention != 0 && (H < 2 || W < 2))) return S360_E_BADARG;
     if (!adapter_args_ok(extrinsics, depths, raw_gaussians, n_views, per_view, H, W, per_ray, d_sh) || !means || !covariances ||
         !harmonics)
         return S360_E_BADARG;
     if (n_views == 0 || per_view == 0) return S360_OK;
-    AdapterParams ap = {n_views, per_view, H, W, per_ray, d_sh, cov9, scale_min, scale_max, eps};
+    AdapterParams ap = {n_views, per_view, H, W, per_ray, d_sh, cov9, erp_convention, scale_min, scale_max, eps};
     hipLaunchKernelGGL(k_adapter_fwd, dim3((per_view + 255) / 256, n_views), dim3(256), 0, (hipStream_t)stream, ap, extrinsics,
                        depths, raw_gaussians, sh_rotation, means, covariances, harmonics, scales_out, rotations_out);
     return hipGetLastError() == hipSuccess ? S360_OK : S360_E_LAUNCH;
@@ -372,12 +398,13 @@ extern "C" int s360_adapter_backward(const float* extrinsics, const float* depth
                                      const float* sh_rotation, int32_t n_views, int32_t per_view, int32_t H, int32_t W,
                                      int32_t per_ray, int32_t d_sh, float scale_min, float scale_max, float eps,
                                      const float* d_means, const float* d_covariances, int32_t cov9, const float* d_harmonics,
-                                     float* d_depths, float* d_raw_gaussians, void* stream) {
+                                     float* d_depths, float* d_raw_gaussians, int32_t erp_convention, void* stream) {
+    if (erp_convention < 0 || erp_convention > 3 || (erp_convention != 0 && (H < 2 || W < 2))) return S360_E_BADARG;
     if (!adapter_args_ok(extrinsics, depths, raw_gaussians, n_views, per_view, H, W, per_ray, d_sh) ||
         !d_covariances || !d_harmonics || !d_depths || !d_raw_gaussians)
         return S360_E_BADARG;
     if (n_views == 0 || per_view == 0) return S360_OK;
-    AdapterParams ap = {n_views, per_view, H, W, per_ray, d_sh, cov9, scale_min, scale_max, eps};
+    AdapterParams ap = {n_views, per_view, H, W, per_ray, d_sh, cov9, erp_convention, scale_min, scale_max, eps};
     hipLaunchKernelGGL(k_adapter_bwd, dim3((per_view + 255) / 256, n_views), dim3(256), 0, (hipStream_t)stream, ap, extrinsics,
                        depths, raw_gaussians, sh_rotation, d_means, d_covariances, d_harmonics, d_depths, d_raw_gaussians);
     return hipGetLastError() == hipSuccess ? S360_OK : S360_E_LAUNCH;

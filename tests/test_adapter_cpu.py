@@ -57,6 +57,20 @@ def test_torch_restatement_gradients_match_the_reference_modules_autograd():
     assert d2.grad.abs().max() > 0
 
 
+def test_every_erp_convention_of_the_reference_matches_its_capture():
+    """utils360.py knows five ray conventions (hm3d / replica, m3d, residential, CoffeeArea / outdoor_colmap); the capture holds
+    the reference module's means for each."""
+    g, t, (b, v, r) = _load()
+    h, w = (int(x) for x in g["image_shape"])
+    for name in ("hm3d", "replica", "m3d", "residential", "CoffeeArea", "outdoor_colmap"):
+        out = adapter_ref.adapter_tail_torch(t("extrinsics").reshape(b * v, 4, 4), t("depths").reshape(b * v, r), t("opacities_in").reshape(b * v, r),
+                                             t("raw_gaussians").reshape(b * v, r, -1), (h, w), float(g["scale_min"]), float(g["scale_max"]),
+                                             dataset_name=name)
+        want = g["means"] if name == "hm3d" else g["means_" + name]
+        np.testing.assert_allclose(out.means.numpy().reshape(want.shape), want, rtol=2e-6, atol=2e-6 * np.abs(want).max(), err_msg=name)
+    assert adapter.ERP_CONVENTIONS == {"hm3d": 0, "replica": 0, "m3d": 1, "residential": 2, "CoffeeArea": 3, "outdoor_colmap": 3}
+
+
 def test_product_module_has_the_reference_signature_and_refuses_cpu_tensors():
     g, t, (b, v, r) = _load()
     h, w = (int(x) for x in g["image_shape"])

@@ -44,6 +44,29 @@ def test_fused_tail_gradients_match_the_reference_modules_autograd(gpu):
         np.testing.assert_allclose(got.cpu().numpy().reshape(want.shape), want, rtol=1e-4, atol=2e-5 * np.abs(want).max())
 
 
+@pytest.mark.parametrize("name", ["replica", "m3d", "residential", "CoffeeArea", "outdoor_colmap"])
+def test_fused_tail_other_erp_conventions_match_reference_capture(gpu, name):
+    g = np.load(G / "adapter_erp_tail.npz")
+    t = lambda k: torch.tensor(g[k], device=gpu)
+    h, w = (int(x) for x in g["image_shape"])
+    mod = adapter.GaussianAdapterERP(float(g["scale_min"]), float(g["scale_max"]), 4, sh_rotation="identity", differentiable_means=True).to(gpu)
+    d = t("depths").requires_grad_(True)
+    out = mod(name, t("extrinsics")[:, :, None, None, None], d, t("opacities_in"), t("raw_gaussians"), (h, w))
+    want = g["means_" + name]
+    np.testing.assert_allclose(out.means.detach().cpu().numpy().reshape(want.shape), want, rtol=3e-6, atol=3e-6 * np.abs(want).max())
+    # the opt-in mean gradient follows the same convention: d mean / d depth = C dir
+    (out.means * t("cot_means")).sum().backward()
+    b, v, r = g["depths"].shape[:3]
+    dd = torch.tensor(g["depths"]).reshape(b * v, r).requires_grad_(True)
+    ref = adapter_ref.adapter_tail_torch(torch.tensor(g["extrinsics"]).reshape(b * v, 4, 4), dd, torch.tensor(g["opacities_in"]).reshape(b * v, r),
+                                         torch.tensor(g["raw_gaussians"]).reshape(b * v, r, -1), (h, w), 0.5, 15.0, differentiable_means=True,
+                                         dataset_name=name)
+    (ref.means * torch.tensor(g["cot_means"]).reshape(ref.means.shape)).sum().backward()
+    np.testing.assert_allclose(d.grad.cpu().numpy().reshape(-1), dd.grad.numpy().reshape(-1), rtol=1e-4, atol=1e-5 * float(dd.grad.abs().max()))
+    with pytest.raises(Exception):
+        mod("re10k", t("extrinsics")[:, :, None, None, None], d, t("opacities_in"), t("raw_gaussians"), (h, w))
+
+
 def _random_case(gpu, v, h, w, seed, with_rot):
     rng = np.random.default_rng(seed)
     ext = np.tile(np.eye(4, dtype=np.float32), (v, 1, 1))
