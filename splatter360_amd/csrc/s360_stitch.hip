@@ -37,27 +37,42 @@ __global__ __launch_bounds__(S360_BLOCK) void k_cube2erp_fwd(const float* __rest
     const int x0 = (int)x0f, y0 = (int)y0f, z0 = (int)z0f;
     const float fx = ix - x0f, fy = iy - y0f, fz = iz - z0f;
     const float wx[2] = {1.0f - fx, fx}, wy[2] = {1.0f - fy, fy}, wz[2] = {1.0f - fz, fz};
-    for (int c = 0; c < C; ++c) {
-        float acc = 0.f;
+    // The eight taps once per pixel (offset + weight), then per channel eight INDEPENDENT loads in flight before the first use
+    // (the per-channel, per-tap branches of the plain loop nest issued one dependent load at a time: 19 us for 19 MB).  A tap
+    // outside the volume keeps a clamped (valid) address and weight 0: acc + v * 0 == acc for the finite pixels of a render, in the
+    // same dz, dy, dx order as before — bit-identical output.
+    size_t off[8];
+    float wgt[8];
 #pragma unroll
-        for (int dz = 0; dz < 2; ++dz) {
-            const int z = z0 + dz;
-            if (z < 0 || z > 5) continue;
-            const int sf = fm.src[z];
-            const float* fp = faces + (size_t)sf * fm.fs + (size_t)c * fm.cs;
+    for (int dz = 0; dz < 2; ++dz) {
+        const int z = z0 + dz, zc = min(max(z, 0), 5);
+        const bool zin = z >= 0 && z <= 5;
+        const size_t fo = (size_t)fm.src[zc] * fm.fs;
+        const bool fl = fm.flip[zc] != 0;
 #pragma unroll
-            for (int dy = 0; dy < 2; ++dy) {
-                const int y = y0 + dy;
-                if (y < 0 || y >= fw) continue;
+        for (int dy = 0; dy < 2; ++dy) {
+            const int y = y0 + dy, yc = min(max(y, 0), fw - 1);
+            const bool yin = y >= 0 && y < fw;
+            const int yy = fl ? fw - 1 - yc : yc;
 #pragma unroll
-                for (int dx = 0; dx < 2; ++dx) {
-                    const int x = x0 + dx;
-                    if (x < 0 || x >= fw) continue;
-                    const int yy = fm.flip[z] ? fw - 1 - y : y, xx = fm.flip[z] ? fw - 1 - x : x;
-                    acc += fp[(size_t)yy * fm.rs + xx] * (wx[dx] * wy[dy] * wz[dz]);
-                }
+            for (int dx = 0; dx < 2; ++dx) {
+                const int x = x0 + dx, xc = min(max(x, 0), fw - 1);
+                const bool xin = x >= 0 && x < fw;
+                const int xx = fl ? fw - 1 - xc : xc;
+                const int k = 4 * dz + 2 * dy + dx;
+                off[k] = fo + (size_t)yy * fm.rs + xx;
+                wgt[k] = (zin && yin && xin) ? wx[dx] * wy[dy] * wz[dz] : 0.0f;
             }
         }
+    }
+    for (int c = 0; c < C; ++c) {
+        const float* fp = faces + (size_t)c * fm.cs;
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = fp[off[k]];
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += v[k] * wgt[k];
         erp[(size_t)c * n + i] = acc;
     }
 }
