@@ -72,6 +72,10 @@ def parse():
                     help="N>1 gradient exchange: chunked (default: factored bytes, exchanged range by range inside the backward), "
                          "factored (one exchange per step, see --overlap-exchange) or allreduce (the full 352 B/Gaussian set)")
     ap.add_argument("--chunks", type=int, default=4, help="Gaussian ranges of the chunked exchange")
+    ap.add_argument("--forward-figure", type=int, default=1,
+                    help="fwdbwd mode: 1 (default) = K more forward-only steps after the timed region, reported as `forward_only` "
+                         "(BASELINE configs[1]); 0 = skip them (the rocprofv3 passes of scripts/collect_profiles.sh: per-kernel averages "
+                         "then hold the training form of every kernel only)")
     ap.add_argument("--dry-run", type=int, default=0,
                     help="1: launch / rendezvous / collectives only (no GPU work, value = null): lets the CPU test suite exercise "
                          "`python bench.py --gpus N` end to end with the gloo backend")
@@ -283,13 +287,15 @@ def main():
     ms_per_step = dt / a.steps * 1e3
 
     extra = {}
-    if a.mode == "fwdbwd":
+    if a.mode == "fwdbwd" and a.forward_figure:
         # (1) the forward-only figure of BASELINE configs[1] (north_star: ">= 400 Msplats/s forward") from the same process: K
         # more steps with nothing requiring grad (inference form of the call: no backward state is written)
+        frozen = [p.detach() for p in params]   # nothing requires grad: the call takes its inference form (S360_FLAG_FORWARD_ONLY)
+
         def step_fwd():
             with torch.no_grad():
                 views = decoder.pack_camera_views(ext, K, near, far, bg)
-                faces = decoder.render_views_fused(ext, K, near, far, (face_w, face_w), bg, *params, check="lazy", shared_campos=True, views=views)
+                faces = decoder.render_views_fused(ext, K, near, far, (face_w, face_w), bg, *frozen, check="lazy", shared_campos=True, views=views)
                 out["erp_fwd"] = c2e.stitch_rendered(faces)
         for _ in range(2):
             step_fwd()
@@ -301,6 +307,7 @@ def main():
         dt_f = distributed.max_over_ranks(time.perf_counter() - t1, dev)
         extra["forward_only"] = {"value": G * world / (dt_f / a.steps) / 1e6, "unit": "Msplats/s", "ms_per_step": dt_f / a.steps * 1e3,
                                  "steps": a.steps, "what": "BASELINE configs[1]: fused six-face forward + stitch, inference form of the call"}
+    if a.mode == "fwdbwd":
         if world > 1:
             # (2) how much of the gradient exchange a step exposes: the same K steps without it
             local_only[0] = True
