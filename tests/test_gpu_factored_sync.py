@@ -96,6 +96,45 @@ def test_chunked_exchange_world_size_one_is_the_plain_backward_bit_for_bit(gpu, 
         assert torch.equal(p.grad, w)
 
 
+def test_chunked_exchange_with_depth_gradient_and_upstream_layouts(gpu):
+    """The in-backward exchange on the other input forms: the fused depth map's gradient (dL_ddepth through
+    s360_backward_gaussians) and the upstream rasteriser layouts ([P,6] covariance, [P,25,3] harmonics) — world size 1, so the
+    result must equal the one-call backward exactly."""
+    from splatter360_amd import decoder, distributed as D, rasterizer
+    ps = _cloud(gpu)
+    ext, K, near, far = _cams(gpu, POSITIONS[1])
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    wc, wd = torch.randn((6, 3, 64, 64), generator=gen).to(gpu), torch.randn((6, 64, 64), generator=gen).to(gpu)
+    res = []
+    for ex in (None, D.ExchangeConfig(n_chunks=5)):
+        for p in ps:
+            p.grad = None
+        col, dep = decoder.render_views_fused(ext, K, near, far, (64, 64), torch.zeros(3, device=gpu), *ps, depth_mode="disparity",
+                                              shared_campos=True, exchange=ex)
+        ((col * wc).sum() + (dep * wd).sum()).backward()
+        res.append([p.grad.clone() for p in ps])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    # upstream layouts through rasterize_views
+    views = decoder.pack_camera_views(ext, K, near, far, torch.zeros(3, device=gpu))
+    r, c = torch.triu_indices(3, 3)
+    res = []
+    for ex in (None, D.ExchangeConfig(n_chunks=3)):
+        m = ps[0].detach().clone().requires_grad_(True)
+        c6 = ps[1].detach()[:, r, c].clone().requires_grad_(True)
+        sh = ps[2].detach().transpose(1, 2).contiguous().requires_grad_(True)
+        op = ps[3].detach().clone().requires_grad_(True)
+        img, _ = rasterizer.rasterize_views(m, c6, op, sh, views=views, image_height=64, image_width=64, sh_degree=4,
+                                            shared_campos=True, exchange=ex)
+        (img * wc).sum().backward()
+        res.append([t.grad.clone() for t in (m, c6, sh, op)])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    with pytest.raises(RuntimeError):      # per-view camera centres cannot use the factored exchange
+        rasterizer.rasterize_views(ps[0], ps[1], ps[3], ps[2], views=views, image_height=64, image_width=64, sh_degree=4,
+                                   shared_campos=False, cov9=True, sh_channel_major=True, exchange=D.ExchangeConfig())
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
