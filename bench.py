@@ -354,7 +354,7 @@ def main():
         render=L * (4 + 48) + hw * (12 + 8),
         sort_tiles=L * (8 + 8 + 4),
         emit=6 * G * 4 + visible_pairs * 32 + L * 8,
-        render_bwd=L * (4 + 48 + 4) + hw * (12 + 8) + L * 48,
+        render_bwd=L * (48 + 4) + hw * (12 + 8) + L * 48,
         gather_slots=L * (4 + 4) + L * 48 + visible_pairs * 48,
         preprocess_bwd=G * (12 + 36 + 36 + 1) + visible_pairs * (48 + 1) + G * (12 + 36 + 4 + 16),
         sh_bwd=G * (16 + 12 + 300),

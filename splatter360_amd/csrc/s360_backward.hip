@@ -582,8 +582,11 @@ static int backward_composite(const BwdCtx& c, const S360View* views, const void
     const bool with_depth = dL_ddepth != nullptr;
     const uint32_t* surv_count = (const uint32_t*)(ws + L.surv_count);  // per-unit replay length: also the work estimate
     {
-        ProfScope ps(PS_RENDER_BWD, st);
+        ProfScope ps(PS_ORDER, st);
         hipLaunchKernelGGL(k_order_units, dim3(1 + 512), dim3(1024), 0, st, surv_count, c.order, c.nt * 4, c.valid_words, header, kp.cap);
+    }
+    {
+        ProfScope ps(PS_RENDER_BWD, st);
         launch_render_bwd_em(with_depth, c.nt * 4, st, kp, views, (const uint32_t*)(ws + L.tile_start), (const float4*)(ws + L.surv),
                              surv_count, (const uint32_t*)(ws + L.slot_base), (const float*)(ws + L.depths),
                              (const float*)(ws + L.final_T), (const uint32_t*)(ws + L.n_contrib), dL_dimages, dL_dimages_scale,

@@ -18,6 +18,7 @@ enum ProfSlot {
     PS_SH_EVAL,
     PS_GATHER,
     PS_SH_BWD,
+    PS_ORDER,
     PS_NSLOTS
 };
 

@@ -199,7 +199,7 @@ void prof_mark(int slot, hipStream_t st, bool end) {
 
 static const char* kSlotNames[PS_NSLOTS] = {"preprocess", "tile_scan", "emit", "sort_tiles", "render",
                                             "render_bwd", "preprocess_bwd", "cube2erp", "cube2erp_bwd", "sh_eval", "gather_slots",
-                                            "sh_bwd"};
+                                            "sh_bwd", "order_units"};
 
 extern "C" int s360_profile_slots(void) { return PS_NSLOTS; }
 extern "C" const char* s360_profile_slot_name(int slot) { return slot >= 0 && slot < PS_NSLOTS ? kSlotNames[slot] : ""; }
