@@ -187,3 +187,24 @@ def test_two_rank_factored_sync_gloo_on_one_gpu(gpu):
     for rank, err, mass in outs:
         assert mass > 0
         assert max(err) <= 2e-5, (rank, err)
+
+
+def test_bench_two_ranks_on_one_gpu_end_to_end(gpu):
+    """`python bench.py --gpus 2` started plainly on a one-GPU box (gloo, both ranks pinned to cuda:0): the self-launch, the
+    chunked in-backward exchange through the real kernels, the timing protocol and the JSON line — small cloud, two steps."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(S360_DIST_BACKEND="gloo", S360_FORCE_DEVICE="0")
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--cpu-baseline", "0",
+                        "--pano-h", "64", "--face", "64"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["backend"] == "gloo" and d["rank_devices"] == [0, 0]
+    assert d["value"] > 0 and d["scaling"] == "weak" and d["exchange"]["mode"] == "chunked" and d["forward_only"]["value"] > 0
+    assert "chunked exchange inside the backward" in d["config"]["parallelism"]
