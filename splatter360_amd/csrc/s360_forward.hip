@@ -589,15 +589,41 @@ __global__ __launch_bounds__(S360_BLOCK) void k_emit(KParams kp, const uint32_t*
         for (int i = threadIdx.x; i < kp.T; i += S360_BLOCK) cnt[i] = 0u;
         __syncthreads();
     }
-    // visible pairs of this thread (bit j: pair g0 + j*256); their rects are recomputed in the second phase
-    uint32_t vis = 0, tt[EMIT_PPT];
+    // The block's visible pairs — one in six of its 1 024 (Gaussian, view) candidates — are first COMPACTED (ballot-free: a
+    // block scan of the per-thread counts, pair indices into LDS) and then dealt out again one per thread: every visible pair's
+    // record, depth and tile count are then fetched in ONE round of independent gathers and kept in registers for both binning
+    // phases, instead of up to four sequential rounds per phase behind the thread that happened to own several visible pairs.
+    __shared__ uint32_t s_p[S360_BLOCK * EMIT_PPT];
+    uint32_t vis = 0;
 #pragma unroll
     for (int j = 0; j < EMIT_PPT; ++j) {
         const int g = g0 + j * S360_BLOCK;
-        // one visibility byte per Gaussian, then the count of the visible pairs only (instead of a word per pair)
-        const bool seen = g < kp.P && ((vis_mask[g] >> v) & 1u);
-        tt[j] = seen ? tiles_touched[(size_t)v * kp.P + g] : 0u;
-        if (seen) vis |= 1u << j;
+        if (g < kp.P && ((vis_mask[g] >> v) & 1u)) vis |= 1u << j;   // one visibility byte per Gaussian
+    }
+    uint32_t nvis;
+    {
+        uint32_t off = block_exclusive_scan((uint32_t)__builtin_popcount(vis), s_scan, nvis);
+        for (uint32_t m = vis; m; m &= m - 1) s_p[off++] = (uint32_t)v * (uint32_t)kp.P + (uint32_t)(g0 + __builtin_ctz(m) * S360_BLOCK);
+    }
+    __syncthreads();
+    // this thread's pairs: compact entries tid, tid + 256, ... (usually one)
+    uint32_t pr[EMIT_PPT], tt[EMIT_PPT], rlo[EMIT_PPT], rhi[EMIT_PPT], dbits[EMIT_PPT];
+#pragma unroll
+    for (int j = 0; j < EMIT_PPT; ++j) {
+        const uint32_t e = threadIdx.x + j * S360_BLOCK;
+        tt[j] = 0u; pr[j] = 0u; rlo[j] = rhi[j] = dbits[j] = 0u;
+        if (e < nvis) {
+            const uint32_t p = s_p[e];
+            const float4 rc = recA[3 * (size_t)p + 2];
+            const float4 ra = recA[3 * (size_t)p];
+            pr[j] = p;
+            tt[j] = tiles_touched[p];
+            dbits[j] = __float_as_uint(depths[p]);
+            int minx, miny, maxx, maxy;
+            tile_rect(ra.x, ra.y, __float_as_int(rc.y), kp.gx, kp.gy, minx, miny, maxx, maxy);
+            rlo[j] = (uint32_t)minx | ((uint32_t)miny << 16);
+            rhi[j] = (uint32_t)maxx | ((uint32_t)maxy << 16);
+        }
     }
     // Training calls: the pair's instance slots — where the backward composite leaves its partial gradients, one record
     // per (pair, tile) — are `touched` consecutive slots reserved here: block total -> ONE returning atomic on the
@@ -605,22 +631,26 @@ __global__ __launch_bounds__(S360_BLOCK) void k_emit(KParams kp, const uint32_t*
     // 14 000 returning atomics on a single address cost 20 us), exclusive scan inside the block.  Which block gets which
     // range varies from run to run; nothing depends on it (k_gather_slots sums a pair's slots in slot order = the fixed
     // tile order of its rectangle), and the upstream point_offsets scan over all V*P pairs (a 25 us kernel) is not needed.
-    uint32_t slot0 = 0, ticket = 0;
-    if (slot_pair) {
-        uint32_t mine = 0, tot;
+    uint32_t sl[EMIT_PPT], ticket = 0;   // first slot of each of this thread's pairs: slots follow the compact (= Gaussian) order
 #pragma unroll
-        for (int j = 0; j < EMIT_PPT; ++j) mine += tt[j];
-        slot0 = block_exclusive_scan(mine, s_scan, tot);
+    for (int j = 0; j < EMIT_PPT; ++j) sl[j] = 0u;
+    if (slot_pair) {
+        uint32_t carry = 0;
+#pragma unroll
+        for (int j = 0; j < EMIT_PPT; ++j) {
+            if ((uint32_t)j * S360_BLOCK >= nvis) break;   // block-uniform: usually one round (a block holds ~175 visible pairs)
+            uint32_t tot;
+            sl[j] = carry + block_exclusive_scan(tt[j], s_scan, tot);
+            carry += tot;
+        }
         // issued now, consumed after the counting phase
-        if (threadIdx.x == 0 && tot) ticket = tile_start[tb] + atomicAdd(&slot_ticket[image_of_view(kp, v) * 64], tot);
+        if (threadIdx.x == 0 && carry) ticket = tile_start[tb] + atomicAdd(&slot_ticket[image_of_view(kp, v) * 64], carry);
     }
     if (LDS_BIN) {
-        for (uint32_t m = vis; m; m &= m - 1) {
-            const size_t p = (size_t)v * kp.P + g0 + __builtin_ctz(m) * S360_BLOCK;
-            const float4 rc = recA[3 * p + 2];
-            const float4 ra = recA[3 * p];
-            int minx, miny, maxx, maxy;
-            tile_rect(ra.x, ra.y, __float_as_int(rc.y), kp.gx, kp.gy, minx, miny, maxx, maxy);
+#pragma unroll
+        for (int j = 0; j < EMIT_PPT; ++j) {
+            if (!tt[j]) continue;
+            const int minx = rlo[j] & 0xFFFFu, miny = rlo[j] >> 16, maxx = rhi[j] & 0xFFFFu, maxy = rhi[j] >> 16;
             for (int y = miny; y < maxy; ++y)
                 for (int x = minx; x < maxx; ++x) atomicAdd(&cnt[y * kp.gx + x], 1u);
         }
@@ -636,23 +666,18 @@ __global__ __launch_bounds__(S360_BLOCK) void k_emit(KParams kp, const uint32_t*
     if (slot_pair || LDS_BIN) {
         if (slot_pair && threadIdx.x == 0) s_slot0 = ticket;
         __syncthreads();
-        if (slot_pair) slot0 += s_slot0;
     }
-    for (uint32_t m = vis; m; m &= m - 1) {
-        const size_t p = (size_t)v * kp.P + g0 + __builtin_ctz(m) * S360_BLOCK;
-        const float4 rc = recA[3 * p + 2];
-        const float4 ra = recA[3 * p];
-        int minx, miny, maxx, maxy;
-        tile_rect(ra.x, ra.y, __float_as_int(rc.y), kp.gx, kp.gy, minx, miny, maxx, maxy);
-        const uint64_t key = ((uint64_t)__float_as_uint(depths[p]) << 32) | (uint64_t)(uint32_t)p;
-        // owner table of the pair's instance slots (slot = slot_base[p] + position inside the rectangle in this emission order)
-        uint32_t slot = slot0;
-        if (slot_pair) {
-            const int j = __builtin_ctz(m);
-            slot_base[p] = slot0;
 #pragma unroll
-            for (int q = 0; q < EMIT_PPT; ++q)
-                if (q == j) slot0 += tt[q];
+    for (int j = 0; j < EMIT_PPT; ++j) {
+        if (!tt[j]) continue;
+        const uint32_t p = pr[j];
+        const int minx = rlo[j] & 0xFFFFu, miny = rlo[j] >> 16, maxx = rhi[j] & 0xFFFFu, maxy = rhi[j] >> 16;
+        const uint64_t key = ((uint64_t)dbits[j] << 32) | (uint64_t)p;
+        // owner table of the pair's instance slots (slot = slot_base[p] + position inside the rectangle in this emission order)
+        uint32_t slot = 0;
+        if (slot_pair) {
+            slot = sl[j] + s_slot0;
+            slot_base[p] = slot;
         }
         for (int y = miny; y < maxy; ++y)
             for (int x = minx; x < maxx; ++x) {
@@ -661,7 +686,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_emit(KParams kp, const uint32_t*
                                              : tile_start[tb + t] + atomicAdd(&tile_cursor[tb + t], 1u);
                 if (pos < kp.cap) keys[pos] = key;
                 if (slot_pair) {
-                    if (slot < kp.cap) slot_pair[slot] = (uint32_t)p;
+                    if (slot < kp.cap) slot_pair[slot] = p;
                     ++slot;
                 }
             }
