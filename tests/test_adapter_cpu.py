@@ -149,3 +149,24 @@ def test_e3nn_basis_is_the_documented_one_for_low_degrees():
     np.testing.assert_allclose(y3[:, 0], np.sqrt(30) / 6 * (y2[:, 0] * z + y2[:, 4] * x), atol=1e-14)
     np.testing.assert_allclose(y3[:, 1], np.sqrt(5) * y2[:, 0] * y, atol=1e-14)
     np.testing.assert_allclose(y3[:, 3], 0.5 * y * (2 * y * y - 3 * (x * x + z * z)), atol=1e-14)
+
+
+def test_e3nn_degree4_members_follow_the_recalled_recursion_up_to_one_factor():
+    """e3nn generates degree l from degree l-1 (its `_spherical_harmonics` source, as recalled):
+    sh_4_0 = 3/4 sqrt2 (sh_3_0 z + sh_3_6 x), sh_4_1 = 3/4 sh_3_0 y + 3/8 sqrt6 (sh_3_1 z + sh_3_5 x),
+    sh_4_4 = -3/28 sqrt42 (sh_3_2 x + sh_3_4 z) + 3/7 sqrt7 sh_3_3 y, sh_4_8 = 3/4 sqrt2 (sh_3_6 z - sh_3_0 x).
+    The closed form used here must give the same four functions up to ONE common (per-degree) normalisation factor — order and
+    signs of the degree-4 members are what the rotation matrices depend on."""
+    rng = np.random.default_rng(4)
+    d = rng.standard_normal((25, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    x, y, z = d.T
+    s3 = adapter_ref.e3nn_real_sh(3, d).T
+    y4 = adapter_ref.e3nn_real_sh(4, d)
+    rec = {0: 0.75 * np.sqrt(2) * (s3[0] * z + s3[6] * x),
+           1: 0.75 * s3[0] * y + 0.375 * np.sqrt(6) * (s3[1] * z + s3[5] * x),
+           4: -3 / 28 * np.sqrt(42) * (s3[2] * x + s3[4] * z) + 3 / 7 * np.sqrt(7) * s3[3] * y,
+           8: 0.75 * np.sqrt(2) * (s3[6] * z - s3[0] * x)}
+    factor = np.sqrt(7.0) / 3.0          # e3nn's degree-3 -> degree-4 step carries sqrt(9/7) in its own normalisation
+    for m, f in rec.items():
+        np.testing.assert_allclose(f * factor, y4[:, m], atol=1e-13, err_msg=str(m))
