@@ -15,7 +15,8 @@ What it restates (file:line under /root/reference):
     Y^l(R d) = D^l(R) Y^l(d) in e3nn's real basis, restated from e3nn's documentation / generated formulas:
     polar axis y, azimuth from z towards x, m = -l..l, no Condon-Shortley phase, i.e.
         Y_{l,m}  = sqrt(2 (l-|m|)!/(l+|m|)!) * d^|m|P_l/dy^|m| * { Im (z+ix)^|m| (m<0) | Re (z+ix)^m (m>0) },  Y_{l,0} = P_l(y)
-    (l = 1: (x, y, z); l = 2: sqrt3 xz, sqrt3 xy, y^2 - (x^2+z^2)/2, sqrt3 yz, sqrt3/2 (z^2-x^2) — e3nn's own l <= 2 forms).
+    (l = 1: (x, y, z); l = 2: sqrt3 xz, sqrt3 xy, y^2 - (x^2+z^2)/2, sqrt3 yz, sqrt3/2 (z^2-x^2) — e3nn's own l <= 2 forms; three
+    l = 3 and four l = 4 members are checked against e3nn's generation recursion as recalled: tests/test_adapter_cpu.py).
     PARITY UNPINNED for this convention: nothing under /root/reference holds a rotated-harmonics vector and e3nn cannot be
     imported; tests pin the construction by properties (D^1 = R, orthogonality, homomorphism, equivariance at fresh directions).
 """
