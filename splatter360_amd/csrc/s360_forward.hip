@@ -285,15 +285,21 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess(
     extern __shared__ __attribute__((aligned(16))) float lds_sh[];
     const int tid = threadIdx.x;
     const int g0 = blockIdx.x * S360_BLOCK;
-    const int g = g0 + tid;
     const int P = kp.P;
+    // every thread runs the view loop (the per-view histogram mode below has barriers in it): a thread past the end works on the
+    // last Gaussian again and writes nothing
+    const bool act = g0 + tid < P;
+    const int g = act ? g0 + tid : P - 1;
     uint32_t* hist = reinterpret_cast<uint32_t*>(lds_sh);
-    const int nhist = (image_of_view(kp, kp.V - 1) + 1) * kp.T;
+    // lds_hist: 1 = the block's tile histogram of ALL images in LDS (V*T words <= 48 KB); 2 = one image at a time (T words <= 48 KB:
+    // faces beyond 512^2 with six views), flushed after every view; 0 = global atomics per instance (a 5-ms kernel at 16 M Gaussians
+    // on 1024^2 faces before mode 2 existed)
+    const int nhist = lds_hist == 2 ? kp.T : (image_of_view(kp, kp.V - 1) + 1) * kp.T;
     if (lds_hist)
         for (int i = tid; i < nhist; i += S360_BLOCK) hist[i] = 0u;
 
     __syncthreads();
-    if (g < P) {
+    {
     const float mx0 = means[3 * g], my0 = means[3 * g + 1], mz0 = means[3 * g + 2];
     float c60[6];
     load_cov6(cov6, g, (kp.flags & S360_FLAG_COV9) != 0, c60);
@@ -368,7 +374,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess(
                 }
                 int minx, miny, maxx, maxy;
                 tile_rect(px, py, rad, kp.gx, kp.gy, minx, miny, maxx, maxy);
-                const int area = keep ? (maxx - minx) * (maxy - miny) : 0;
+                const int area = (keep && act) ? (maxx - minx) * (maxy - miny) : 0;
                 if (area != 0) {
                     if (USE_SH && EAGER) {
                         if (!have_rgb) {
@@ -447,23 +453,35 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess(
                     depths[p] = zkey;
                     clamped[p] = (uint8_t)clampbits;
                     // block-local histogram in LDS; one global atomic per (block, touched tile) below
-                    uint32_t* tc = (lds_hist ? hist : tile_count) + (size_t)image_of_view(kp, v) * kp.T;
+                    uint32_t* tc = lds_hist == 2 ? hist : (lds_hist ? hist : tile_count) + (size_t)image_of_view(kp, v) * kp.T;
                     for (int y = miny; y < maxy; ++y)
                         for (int x = minx; x < maxx; ++x) atomicAdd(&tc[y * kp.gx + x], 1u);
                 }
             }
         }
-        if (radii) radii[p] = radius;
+        if (act && radii) radii[p] = radius;
         // visibility of the V (<= 8) views in ONE byte per Gaussian: k_emit and the backward test that instead of V words
         // (24 MB written here and read twice for six views of 1 M Gaussians); tiles_touched only exists for visible pairs
         if (touched) {
             tiles_touched[p] = touched;
             vis |= 1u << v;
         }
+        if (lds_hist == 2) {   // block-uniform: this view's counts go out, the histogram is reused by the next view
+            __syncthreads();
+            uint32_t* tcg = tile_count + (size_t)image_of_view(kp, v) * kp.T;
+            for (int i = tid; i < nhist; i += S360_BLOCK) {
+                const uint32_t c = hist[i];
+                if (c) {
+                    atomicAdd(&tcg[i], c);
+                    hist[i] = 0u;
+                }
+            }
+            __syncthreads();
+        }
     }
-    vis_mask[g] = (uint8_t)vis;
-    }  // g < P
-    if (lds_hist) {
+    if (act) vis_mask[g] = (uint8_t)vis;
+    }
+    if (lds_hist == 1) {
         __syncthreads();
         for (int i = tid; i < nhist; i += S360_BLOCK) {
             const uint32_t c = hist[i];
@@ -1485,8 +1503,9 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
     if (kp.P > 0) {
         {
         const int nblk = (kp.P + S360_BLOCK - 1) / S360_BLOCK;
-        const size_t hist_bytes = (size_t)nt * 4;
-        const int lds_hist = hist_bytes <= 48 * 1024 ? 1 : 0;
+        // the block's tile histogram: all images in LDS when they fit, else one image at a time, else global atomics
+        const int lds_hist = (size_t)nt * 4 <= 48 * 1024 ? 1 : ((size_t)kp.T * 4 <= 48 * 1024 ? 2 : 0);
+        const size_t hist_bytes = lds_hist == 2 ? (size_t)kp.T * 4 : (size_t)nt * 4;
         // views sharing one camera centre: SH colours once per Gaussian in their own streaming kernel.  Always in training
         // calls (the backward relies on sh_jac); in inference calls only when several views amortise the full-cloud read
         // (a single-face drop-in call sees ~17 % of the cloud and keeps the lazy in-kernel evaluation).

@@ -173,6 +173,28 @@ def test_fused_cube6_equals_six_dropin_calls(gpu):
     assert ins_f[1].grad[:, 1, 0].abs().max().item() == 0.0
 
 
+def test_fused_cube6_at_736px_faces_uses_the_per_view_histogram_and_equals_six_calls(gpu):
+    """Six 736x736 faces = 6 x 2116 tiles: the all-images tile histogram (50.8 KB) no longer fits the geometry kernel's LDS budget
+    and it switches to the one-image-at-a-time form (flushed after every view, barriers inside the view loop, a ragged last
+    block); the six single-face calls still use the all-images form.  Same images bit for bit, same integer state."""
+    from splatter360_amd import cameras, decoder
+    cloud = synthetic.uniform_cloud(5_003, seed=11, extent=2.5, scale_range=(0.02, 0.25))     # 5 003: a ragged last workgroup
+    fw = 736
+    pose = torch.tensor(synthetic.target_pano_pose((0.1, -0.2, 0.05)), device=gpu)
+    near, far = torch.tensor(0.1, device=gpu), torch.tensor(10.0, device=gpu)
+    bg = torch.tensor([0.1, 0.2, 0.3], device=gpu)
+    ins = _cloud_tensors(cloud, gpu, False)
+    faces = decoder.render_cube_faces(pose, near, far, fw, bg, *ins, glue="torch")
+    tt = rasterizer.last_state().tensors()["tiles_touched"].clone()
+    ext = cameras.cube_face_extrinsics(pose[None])
+    k = cameras.cube_face_intrinsics(1, device=gpu)
+    for f in range(6):
+        ref = decoder.render_cuda(ext[:, f], k[:, f], near[None], far[None], (fw, fw), bg[None], ins[0][None], ins[1][None],
+                                  ins[2][None], ins[3][None])[0]
+        assert torch.equal(faces[f], ref)
+        assert torch.equal(tt[f], rasterizer.last_state().tensors()["tiles_touched"][0])
+
+
 def test_fused_cube6_vs_oracle(gpu):
     from splatter360_amd import decoder
     cloud = synthetic.uniform_cloud(10_000, seed=11, extent=3.0, scale_range=(0.02, 0.3))
