@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define S360_ABI_VERSION 18
+#define S360_ABI_VERSION 19
 #define S360_MAX_VIEWS 8
 #define S360_TILE 16
 
@@ -78,6 +78,15 @@ enum {
                                          and tanfov are ignored; sort key and near cull use the RADIAL distance;
                                          d_means2D is in pixel units */
 
+#define S360_FLAG_LEAN_LISTS 64u       /* binning-time exact cull: a (Gaussian, tile) instance is counted, emitted, sorted and given an
+                                         instance slot only if the splat can reach alpha >= 1/255 on some pixel of that 16x16 tile
+                                         (the tile-sized instance of the composites' own quadrant test; upstream bins the whole 3-sigma
+                                         rectangle; rectangles of more than 32 tiles are binned whole).  Skipped
+                                         instances contribute to no pixel, so images, final_T, radii and every gradient are
+                                         BIT-IDENTICAL to a call without the flag; tiles_touched, the sorted lists, num_instances and
+                                         n_contrib (list positions) differ.  Flag clear = the upstream-compatible lists (what the
+                                         integer-state parity tests compare with the oracle). */
+
 typedef struct S360View {
     float viewmatrix[16];
     float projmatrix[16];
@@ -107,9 +116,11 @@ typedef struct S360Layout {
     size_t tiles_touched;       /* uint32[V*P] */
     size_t vis_mask;            /* uint8[P]  bit v set: Gaussian visible in view v (V <= 8).  tiles_touched is written for
                                    visible pairs only; the kernels test visibility on this byte, not on V words */
-    size_t slot_base;           /* uint32[V*P]  training calls: first instance slot of a visible pair (it owns `tiles_touched`
-                                   consecutive slots; upstream's point_offsets scan is replaced by a block-wise reservation,
-                                   so which range a pair gets is run-dependent — the ranges tile [0, num_instances)) */
+    size_t slot_base;           /* uint32[V*P][2]  word 0 (training calls): first instance slot of a visible pair (it owns
+                                   `tiles_touched` consecutive slots; upstream's point_offsets scan is replaced by a block-wise
+                                   reservation, so which range a pair gets is run-dependent — the ranges tile [0, num_instances));
+                                   word 1 (S360_FLAG_LEAN_LISTS): bit i set = tile i of the pair's rectangle (scan order, at most
+                                   32 tiles) holds an instance; the pair's slots follow its set bits */
     /* one 48-byte record per pair, stride 48 B: rec_b / rec_c = rec_a + 16 / + 32 (one cache line per gather) */
     size_t rec_a;               /* float4  x, y, -log2(e)/2 * conic.a, -log2(e) * conic.b */
     size_t rec_b;               /* float4  -log2(e)/2 * conic.c, opacity, r, g */

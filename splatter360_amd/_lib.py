@@ -26,7 +26,8 @@ FLAG_SH_CHANNEL_MAJOR = 4
 FLAG_FORWARD_ONLY = 8
 FLAG_SH_DEG4_IGNORED = 16
 FLAG_SPHERICAL = 32
-ABI_VERSION = 18
+FLAG_LEAN_LISTS = 64
+ABI_VERSION = 19
 
 
 class S360Params(C.Structure):

@@ -588,7 +588,7 @@ static int backward_composite(const BwdCtx& c, const S360View* views, const void
     {
         ProfScope ps(PS_RENDER_BWD, st);
         launch_render_bwd_em(with_depth, c.nt * 4, st, kp, views, (const uint32_t*)(ws + L.tile_start), (const float4*)(ws + L.surv),
-                             surv_count, (const uint32_t*)(ws + L.slot_base), (const float*)(ws + L.depths),
+                             surv_count, (const uint2*)(ws + L.slot_base), (const float*)(ws + L.depths),
                              (const float*)(ws + L.final_T), (const uint32_t*)(ws + L.n_contrib), dL_dimages, dL_dimages_scale,
                              dL_ddepth, c.part, (uint8_t*)c.valid_words, c.order, depth_mode,
 #ifdef S360_DBG_TIMING

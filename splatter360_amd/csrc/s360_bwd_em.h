@@ -98,7 +98,7 @@ __device__ __forceinline__ float depth_value_grad(float z, float nearp, float fa
 template <bool WITH_DEPTH>
 __global__ __launch_bounds__(64) void k_render_bwd_em(
     KParams kp, const S360View* __restrict__ views, const uint32_t* __restrict__ tile_start,
-    const float4* __restrict__ surv, const uint32_t* __restrict__ surv_count, const uint32_t* __restrict__ slot_base,
+    const float4* __restrict__ surv, const uint32_t* __restrict__ surv_count, const uint2* __restrict__ slot_info,
     const float* __restrict__ depths, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dimages, const float* __restrict__ dL_dimages_scale, const float* __restrict__ dL_ddepth,
     float4* __restrict__ part,
@@ -181,10 +181,10 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
         // the entry's instance slot (where its partial record goes) is only needed at the very end: the gather of the pair's
         // first slot flies during the pixel loop, and only SURVIVORS pay for it
         const uint32_t pair = __float_as_uint(qc.w);
-        uint32_t sbase = 0;
+        uint2 sinfo = make_uint2(0u, 0u);   // (the pair's first slot, lean lists: which tiles of its rectangle hold instances)
         float zv = 0.f;
         if (lane_ok) {
-            sbase = slot_base[pair];
+            sinfo = slot_info[pair];
             if (WITH_DEPTH) zv = depth_value(depths[pair] * inv_scale, v_near, v_far, depth_mode);
         }
         // positions descend with the lane: the group's frontmost entry sits in lane n - 1
@@ -306,7 +306,10 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
         if (lane_ok && anyc) {  // position of tile (tx,ty) inside the splat's tile rectangle, in emission order
             int minx, miny, maxx, maxy;
             tile_rect(ex, ey, erad, kp.gx, kp.gy, minx, miny, maxx, maxy);
-            inst = sbase + (uint32_t)((ty - miny) * (maxx - minx) + (tx - minx));
+            const uint32_t idx = (uint32_t)((ty - miny) * (maxx - minx) + (tx - minx));
+            // lean lists (rectangles of up to 32 tiles): the slots follow the set bits of the hit mask
+            const bool masked = (kp.flags & S360_FLAG_LEAN_LISTS) && (maxx - minx) * (maxy - miny) <= 32;
+            inst = sinfo.x + (masked ? (uint32_t)__builtin_popcount(sinfo.y & ((1u << idx) - 1u)) : idx);
         }
         if (lane_ok && anyc && inst < kp.cap) {
             const float ln2 = 0.6931471805599453f;
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
 // -fno-slp-vectorize: the pixel pairs are packed by hand above — pixel-contiguous LDS tables, pair accumulators — which
 // costs no register moves; the SLP vectoriser's own pairing of the scalar formulation paid 23 moves per half row).
 void launch_render_bwd_em(bool with_depth, int n_units, hipStream_t st, const KParams& kp, const S360View* views,
-                          const uint32_t* tile_start, const float4* surv, const uint32_t* surv_count, const uint32_t* slot_base,
+                          const uint32_t* tile_start, const float4* surv, const uint32_t* surv_count, const uint2* slot_info,
                           const float* depths, const float* final_T, const uint32_t* n_contrib, const float* dL_dimages,
                           const float* dL_dimages_scale, const float* dL_ddepth, float4* part, uint8_t* valid, const uint32_t* order, int depth_mode, uint32_t* dbg);
 

@@ -361,6 +361,24 @@ __device__ __forceinline__ bool quadrant_hit(float x, float y, float a, float b,
     return box_hit<SUB_W, SUB_H>(x, y, a, b, c, op, ka, kb, x0, y0);
 }
 
+// The same test for a whole 16x16 tile — the binning-time cull of S360_FLAG_LEAN_LISTS (k_preprocess counts and k_emit
+// places a (Gaussian, tile) instance only when it passes; both evaluate THIS function on the stored record, so the
+// histogram and the emission agree).  lop = v_log_f32(opacity), hoisted by the caller.  The margin is twice the quadrants'
+// (0.04 against 0.02 log2 units): a tile-culled entry then fails every quadrant's own test by more than the rounding error
+// of either evaluation (a quadrant's box lies inside the tile's, so its maximum cannot be larger) — the quadrants' survivor
+// sets, and with them the backward's group composition, are exactly those of the unculled list: images AND gradients stay
+// bit-identical to the upstream-compatible lists, only tiles_touched / list / n_contrib positions change.
+__device__ __forceinline__ bool tile_hit(float x, float y, float a, float b, float c, float lop, float ka, float kb, int tx, int ty) {
+    const float dh = x - (float)(16 * tx), dl = dh - 15.0f;
+    const float eh = y - (float)(16 * ty), el = eh - 15.0f;
+    const float dx1 = __builtin_amdgcn_fmed3f(0.0f, dl, dh);
+    const float dy1 = __builtin_amdgcn_fmed3f(0.0f, el, eh);
+    const float dys = __builtin_amdgcn_fmed3f(kb * dx1, el, eh);
+    const float dxs = __builtin_amdgcn_fmed3f(ka * dy1, dl, dh);
+    const float pmax = fmaxf(power2(a, b, c, dx1, dys), power2(a, b, c, dxs, dy1));
+    return !(pmax + lop + (7.994353436858858f + 0.04f) < 0.0f);   // NaN (degenerate conic) keeps the instance
+}
+
 // Per-Gaussian "colour" of the fused depth map for the reference's DepthRenderingMode
 // (cuda_splatting.py:244-251; z = camera-space depth in unscaled units).  The "log" mode reproduces the
 // reference's swapped clamp (z.minimum(near).maximum(far)) as is.

@@ -277,7 +277,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess(
     const float* __restrict__ colors, int32_t* __restrict__ radii, uint32_t* __restrict__ tiles_touched,
     float4* __restrict__ recA, float4* __restrict__ recB, float4* __restrict__ recC,
     uint8_t* __restrict__ clamped, float* __restrict__ depths, uint32_t* __restrict__ tile_count, int lds_hist,
-    const float4* __restrict__ rgbc, uint8_t* __restrict__ vis_mask) {
+    const float4* __restrict__ rgbc, uint8_t* __restrict__ vis_mask, uint2* __restrict__ slot_info) {
     // dynamic LDS: tile histogram V*T uint32 (lds_hist).  SH coefficients are NOT staged: every lane
     // streams its own Gaussian's 300-byte slab with 16-byte loads (all bytes of every cache line are
     // consumed by the same lane within a few instructions, so HBM traffic stays 1x) — this keeps the
@@ -291,6 +291,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess(
     const bool act = g0 + tid < P;
     const int g = act ? g0 + tid : P - 1;
     uint32_t* hist = reinterpret_cast<uint32_t*>(lds_sh);
+    const bool lean = (kp.flags & S360_FLAG_LEAN_LISTS) != 0;
     // lds_hist: 1 = the block's tile histogram of ALL images in LDS (V*T words <= 48 KB); 2 = one image at a time (T words <= 48 KB:
     // faces beyond 512^2 with six views), flushed after every view; 0 = global atomics per instance (a 5-ms kernel at 16 M Gaussians
     // on 1024^2 faces before mode 2 existed)
@@ -376,86 +377,108 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess(
                 tile_rect(px, py, rad, kp.gx, kp.gy, minx, miny, maxx, maxy);
                 const int area = (keep && act) ? (maxx - minx) * (maxy - miny) : 0;
                 if (area != 0) {
-                    if (USE_SH && EAGER) {
-                        if (!have_rgb) {
-                            const float4 cc = rgbc[g];
-                            rgb[0] = cc.x; rgb[1] = cc.y; rgb[2] = cc.z;
-                            clampbits = __float_as_uint(cc.w);
-                            have_rgb = true;
-                        }
-                    } else if (USE_SH && (!have_rgb || !shared_cam)) {
-                        const float dx = mx - vw.campos[0], dy = my - vw.campos[1], dz = mz - vw.campos[2];
-                        const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
-                        const float x = dx * inv, y = dy * inv, z = dz * inv;
-                        float Y[25];
-                        sh_basis(kp.deg, x, y, z, Y);
-                        const int n = (kp.deg + 1) * (kp.deg + 1);
-                        const float* sh = shs + (size_t)g * kp.M * 3;
-                        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-                        // sequential (unfused) accumulation: same rounding as the CPU oracle
-                        if (kp.M == 25 && kp.deg == 4 && ch_major) {
-                            // one colour channel (25 contiguous floats) at a time: 3x fewer live registers
-                            float acc[3];
-#pragma unroll 1
-                            for (int ch = 0; ch < 3; ++ch) {
-                                float c[25];
-                                load25(sh + 25 * ch, c);
-                                float a = 0.f;
-#pragma unroll
-                                for (int k = 0; k < 25; ++k) a += Y[k] * c[k];
-                                acc[ch] = a;
-                            }
-                            a0 = acc[0]; a1 = acc[1]; a2 = acc[2];
-                        } else if (kp.M == 25 && kp.deg == 4) {
-                            // interleaved [k][rgb]: five chunks of 5 coefficients x 3 channels (15 floats)
-#pragma unroll  // fully unrolled: Y[] indexed by constants stays in registers (a rolled loop put it in scratch)
-                            for (int q = 0; q < 5; ++q) {
-                                float c[15];
-                                load15(sh + 15 * q, c);
-#pragma unroll
-                                for (int k = 0; k < 5; ++k) {
-                                    a0 += Y[5 * q + k] * c[k * 3 + 0];
-                                    a1 += Y[5 * q + k] * c[k * 3 + 1];
-                                    a2 += Y[5 * q + k] * c[k * 3 + 2];
-                                }
-                            }
-                        } else if (ch_major) {
-                            for (int k = 0; k < n; ++k) {
-                                a0 += Y[k] * sh[k];
-                                a1 += Y[k] * sh[kp.M + k];
-                                a2 += Y[k] * sh[2 * kp.M + k];
-                            }
-                        } else {
-                            for (int k = 0; k < n; ++k) {
-                                a0 += Y[k] * sh[k * 3 + 0];
-                                a1 += Y[k] * sh[k * 3 + 1];
-                                a2 += Y[k] * sh[k * 3 + 2];
-                            }
-                        }
-                        a0 += 0.5f;
-                        a1 += 0.5f;
-                        a2 += 0.5f;
-                        clampbits = (a0 < 0.f ? 1u : 0u) | (a1 < 0.f ? 2u : 0u) | (a2 < 0.f ? 4u : 0u);
-                        rgb[0] = fmaxf(a0, 0.f);
-                        rgb[1] = fmaxf(a1, 0.f);
-                        rgb[2] = fmaxf(a2, 0.f);
-                        have_rgb = true;
-                    }
                     radius = rad;
-                    touched = (uint32_t)area;
-                    // conic stored pre-scaled for the composite: exponent in base 2, -1/2 folded in
-                    recA[3 * (size_t)(p)] = make_float4(px, py, conA * kConicDiag, conB * kConicOff);
-                    recA[3 * (size_t)(p) + 1] = make_float4(conC * kConicDiag, op, rgb[0], rgb[1]);
-                    // slopes of the two parabola-vertex lines of the composite's exact quadrant cull (quadrant_hit):
-                    // dx* = ka dy maximises the exponent on a row, dy* = kb dx on a column
+                    // conic stored pre-scaled for the composite: exponent in base 2, -1/2 folded in; ka / kb: slopes of the two
+                    // parabola-vertex lines of the exact cull (dx* = ka dy maximises the exponent on a row, dy* = kb dx on a column)
                     const float ra = conA * kConicDiag, rb = conB * kConicOff, rc_ = conC * kConicDiag;
-                    recA[3 * (size_t)(p) + 2] = make_float4(rgb[2], __int_as_float(rad), -rb / (2.0f * ra), -rb / (2.0f * rc_));
-                    depths[p] = zkey;
-                    clamped[p] = (uint8_t)clampbits;
+                    const float ka = -rb / (2.0f * ra), kb = -rb / (2.0f * rc_);
                     // block-local histogram in LDS; one global atomic per (block, touched tile) below
                     uint32_t* tc = lds_hist == 2 ? hist : (lds_hist ? hist : tile_count) + (size_t)image_of_view(kp, v) * kp.T;
-                    for (int y = miny; y < maxy; ++y)
-                        for (int x = minx; x < maxx; ++x) atomicAdd(&tc[y * kp.gx + x], 1u);
+                    uint32_t hmask = 0xFFFFFFFFu;
+                    if (lean && area <= 32) {
+                        // lean lists: count only the tiles the splat can reach (tile_hit: the composites' cull at tile size) and
+                        // remember them as one bit per tile of the rectangle, scan order — k_emit places exactly these, the
+                        // backward finds an instance's slot as the rank of its tile's bit.  Larger rectangles are binned whole.
+                        const float lop = __builtin_amdgcn_logf(op);
+                        uint32_t bit = 1u;
+                        hmask = 0u;
+                        for (int y = miny; y < maxy; ++y)
+                            for (int x = minx; x < maxx; ++x) {
+                                if (tile_hit(px, py, ra, rb, rc_, lop, ka, kb, x, y)) {
+                                    atomicAdd(&tc[y * kp.gx + x], 1u);
+                                    hmask |= bit;
+                                }
+                                bit <<= 1;
+                            }
+                        touched = (uint32_t)__builtin_popcount(hmask);
+                    } else {
+                        touched = (uint32_t)area;
+                        for (int y = miny; y < maxy; ++y)
+                            for (int x = minx; x < maxx; ++x) atomicAdd(&tc[y * kp.gx + x], 1u);
+                    }
+                    if (touched) {   // (lean: a splat too faint to reach any pixel is on no list; its radius is still reported)
+                        if (USE_SH && EAGER) {
+                            if (!have_rgb) {
+                                const float4 cc = rgbc[g];
+                                rgb[0] = cc.x; rgb[1] = cc.y; rgb[2] = cc.z;
+                                clampbits = __float_as_uint(cc.w);
+                                have_rgb = true;
+                            }
+                        } else if (USE_SH && (!have_rgb || !shared_cam)) {
+                            const float dx = mx - vw.campos[0], dy = my - vw.campos[1], dz = mz - vw.campos[2];
+                            const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+                            const float x = dx * inv, y = dy * inv, z = dz * inv;
+                            float Y[25];
+                            sh_basis(kp.deg, x, y, z, Y);
+                            const int n = (kp.deg + 1) * (kp.deg + 1);
+                            const float* sh = shs + (size_t)g * kp.M * 3;
+                            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+                            // sequential (unfused) accumulation: same rounding as the CPU oracle
+                            if (kp.M == 25 && kp.deg == 4 && ch_major) {
+                                // one colour channel (25 contiguous floats) at a time: 3x fewer live registers
+                                float acc[3];
+#pragma unroll 1
+                                for (int ch = 0; ch < 3; ++ch) {
+                                    float c[25];
+                                    load25(sh + 25 * ch, c);
+                                    float a = 0.f;
+#pragma unroll
+                                    for (int k = 0; k < 25; ++k) a += Y[k] * c[k];
+                                    acc[ch] = a;
+                                }
+                                a0 = acc[0]; a1 = acc[1]; a2 = acc[2];
+                            } else if (kp.M == 25 && kp.deg == 4) {
+                                // interleaved [k][rgb]: five chunks of 5 coefficients x 3 channels (15 floats)
+#pragma unroll  // fully unrolled: Y[] indexed by constants stays in registers (a rolled loop put it in scratch)
+                                for (int q = 0; q < 5; ++q) {
+                                    float c[15];
+                                    load15(sh + 15 * q, c);
+#pragma unroll
+                                    for (int k = 0; k < 5; ++k) {
+                                        a0 += Y[5 * q + k] * c[k * 3 + 0];
+                                        a1 += Y[5 * q + k] * c[k * 3 + 1];
+                                        a2 += Y[5 * q + k] * c[k * 3 + 2];
+                                    }
+                                }
+                            } else if (ch_major) {
+                                for (int k = 0; k < n; ++k) {
+                                    a0 += Y[k] * sh[k];
+                                    a1 += Y[k] * sh[kp.M + k];
+                                    a2 += Y[k] * sh[2 * kp.M + k];
+                                }
+                            } else {
+                                for (int k = 0; k < n; ++k) {
+                                    a0 += Y[k] * sh[k * 3 + 0];
+                                    a1 += Y[k] * sh[k * 3 + 1];
+                                    a2 += Y[k] * sh[k * 3 + 2];
+                                }
+                            }
+                            a0 += 0.5f;
+                            a1 += 0.5f;
+                            a2 += 0.5f;
+                            clampbits = (a0 < 0.f ? 1u : 0u) | (a1 < 0.f ? 2u : 0u) | (a2 < 0.f ? 4u : 0u);
+                            rgb[0] = fmaxf(a0, 0.f);
+                            rgb[1] = fmaxf(a1, 0.f);
+                            rgb[2] = fmaxf(a2, 0.f);
+                            have_rgb = true;
+                        }
+                        recA[3 * (size_t)(p)] = make_float4(px, py, ra, rb);
+                        recA[3 * (size_t)(p) + 1] = make_float4(rc_, op, rgb[0], rgb[1]);
+                        recA[3 * (size_t)(p) + 2] = make_float4(rgb[2], __int_as_float(rad), ka, kb);
+                        depths[p] = zkey;
+                        clamped[p] = (uint8_t)clampbits;
+                        if (lean) slot_info[p].y = hmask;
+                    }
                 }
             }
         }
@@ -593,7 +616,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_emit(KParams kp, const uint32_t*
                                                     const uint8_t* __restrict__ vis_mask, const float4* __restrict__ recA, const float4* __restrict__ recC,
                                                     const float* __restrict__ depths, const uint32_t* __restrict__ tile_start,
                                                     uint32_t* __restrict__ tile_cursor, uint64_t* __restrict__ keys,
-                                                    uint32_t* __restrict__ slot_base, uint32_t* __restrict__ slot_pair,
+                                                    uint2* __restrict__ slot_info, uint32_t* __restrict__ slot_pair,
                                                     uint32_t* __restrict__ slot_ticket) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_bin[];  // [T] counts/cursors, [T] bases
     __shared__ uint32_t s_scan[S360_BLOCK / 64];
@@ -603,6 +626,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_emit(KParams kp, const uint32_t*
     const size_t tb = (size_t)image_of_view(kp, v) * kp.T;
     uint32_t* cnt = lds_bin;
     uint32_t* base = lds_bin + kp.T;
+    const bool lean = (kp.flags & S360_FLAG_LEAN_LISTS) != 0;
     if (LDS_BIN) {
         for (int i = threadIdx.x; i < kp.T; i += S360_BLOCK) cnt[i] = 0u;
         __syncthreads();
@@ -625,11 +649,13 @@ __global__ __launch_bounds__(S360_BLOCK) void k_emit(KParams kp, const uint32_t*
     }
     __syncthreads();
     // this thread's pairs: compact entries tid, tid + 256, ... (usually one)
-    uint32_t pr[EMIT_PPT], tt[EMIT_PPT], rlo[EMIT_PPT], rhi[EMIT_PPT], dbits[EMIT_PPT];
+    // hm: S360_FLAG_LEAN_LISTS — the tiles of the rectangle (scan order, rectangles of up to 32 tiles) that hold an instance,
+    // as k_preprocess counted them; all ones otherwise (every tile of the rectangle)
+    uint32_t pr[EMIT_PPT], tt[EMIT_PPT], rlo[EMIT_PPT], rhi[EMIT_PPT], dbits[EMIT_PPT], hm[EMIT_PPT];
 #pragma unroll
     for (int j = 0; j < EMIT_PPT; ++j) {
         const uint32_t e = threadIdx.x + j * S360_BLOCK;
-        tt[j] = 0u; pr[j] = 0u; rlo[j] = rhi[j] = dbits[j] = 0u;
+        tt[j] = 0u; pr[j] = 0u; rlo[j] = rhi[j] = dbits[j] = 0u; hm[j] = 0xFFFFFFFFu;
         if (e < nvis) {
             const uint32_t p = s_p[e];
             const float4 rc = recA[3 * (size_t)p + 2];
@@ -641,6 +667,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_emit(KParams kp, const uint32_t*
             tile_rect(ra.x, ra.y, __float_as_int(rc.y), kp.gx, kp.gy, minx, miny, maxx, maxy);
             rlo[j] = (uint32_t)minx | ((uint32_t)miny << 16);
             rhi[j] = (uint32_t)maxx | ((uint32_t)maxy << 16);
+            if (lean && (maxx - minx) * (maxy - miny) <= 32) hm[j] = slot_info[p].y;
         }
     }
     // Training calls: the pair's instance slots — where the backward composite leaves its partial gradients, one record
@@ -669,8 +696,12 @@ __global__ __launch_bounds__(S360_BLOCK) void k_emit(KParams kp, const uint32_t*
         for (int j = 0; j < EMIT_PPT; ++j) {
             if (!tt[j]) continue;
             const int minx = rlo[j] & 0xFFFFu, miny = rlo[j] >> 16, maxx = rhi[j] & 0xFFFFu, maxy = rhi[j] >> 16;
+            uint32_t m = hm[j];
             for (int y = miny; y < maxy; ++y)
-                for (int x = minx; x < maxx; ++x) atomicAdd(&cnt[y * kp.gx + x], 1u);
+                for (int x = minx; x < maxx; ++x) {
+                    if (m & 1u) atomicAdd(&cnt[y * kp.gx + x], 1u);
+                    m = (m >> 1) | 0x80000000u;   // rectangles beyond 32 tiles: all ones
+                }
         }
         __syncthreads();
         for (int i = threadIdx.x; i < kp.T; i += S360_BLOCK) {
@@ -691,22 +722,27 @@ __global__ __launch_bounds__(S360_BLOCK) void k_emit(KParams kp, const uint32_t*
         const uint32_t p = pr[j];
         const int minx = rlo[j] & 0xFFFFu, miny = rlo[j] >> 16, maxx = rhi[j] & 0xFFFFu, maxy = rhi[j] >> 16;
         const uint64_t key = ((uint64_t)dbits[j] << 32) | (uint64_t)p;
-        // owner table of the pair's instance slots (slot = slot_base[p] + position inside the rectangle in this emission order)
+        // owner table of the pair's instance slots (slot = slot_base[p] + rank of the tile among the rectangle's instance-holding
+        // tiles in this emission order: its position inside the rectangle when every tile holds one)
         uint32_t slot = 0;
         if (slot_pair) {
             slot = sl[j] + s_slot0;
-            slot_base[p] = slot;
+            slot_info[p].x = slot;
         }
+        uint32_t m = hm[j];
         for (int y = miny; y < maxy; ++y)
             for (int x = minx; x < maxx; ++x) {
-                const int t = y * kp.gx + x;
-                const uint32_t pos = LDS_BIN ? base[t] + atomicAdd(&cnt[t], 1u)
-                                             : tile_start[tb + t] + atomicAdd(&tile_cursor[tb + t], 1u);
-                if (pos < kp.cap) keys[pos] = key;
-                if (slot_pair) {
-                    if (slot < kp.cap) slot_pair[slot] = p;
-                    ++slot;
+                if (m & 1u) {
+                    const int t = y * kp.gx + x;
+                    const uint32_t pos = LDS_BIN ? base[t] + atomicAdd(&cnt[t], 1u)
+                                                 : tile_start[tb + t] + atomicAdd(&tile_cursor[tb + t], 1u);
+                    if (pos < kp.cap) keys[pos] = key;
+                    if (slot_pair) {
+                        if (slot < kp.cap) slot_pair[slot] = p;
+                        ++slot;
+                    }
                 }
+                m = (m >> 1) | 0x80000000u;
             }
     }
 }
@@ -1395,7 +1431,7 @@ extern "C" int s360_layout(const S360Params* prm, S360Layout* out) {
     out->header = take(64 * 4);
     out->tiles_touched = take(np * 4);
     out->vis_mask = take((size_t)(prm->P > 0 ? prm->P : 1));
-    out->slot_base = take(np * 4);
+    out->slot_base = take(np * 8);   // (first slot, hit mask) per pair
     out->rec_a = take(np * 48);  // one 48-byte record per pair: rec_b / rec_c are the 2nd / 3rd float4 of it
     out->rec_b = out->rec_a + 16;
     out->rec_c = out->rec_a + 32;
@@ -1472,7 +1508,7 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
     uint32_t* header = (uint32_t*)(ws + L.header);
     uint32_t* tiles_touched = (uint32_t*)(ws + L.tiles_touched);
     uint8_t* vis_mask = (uint8_t*)(ws + L.vis_mask);
-    uint32_t* slot_base = (uint32_t*)(ws + L.slot_base);
+    uint2* slot_info = (uint2*)(ws + L.slot_base);
     uint32_t* slot_ticket = (uint32_t*)(ws + L.slot_ticket);
     float4* recA = (float4*)(ws + L.rec_a);
     float4* recB = (float4*)(ws + L.rec_b);
@@ -1530,19 +1566,19 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
             if (eager)
                 hipLaunchKernelGGL((k_preprocess<true, true, true>), dim3(nblk), dim3(S360_BLOCK), lds, st, kp, views, means3D, cov6,
                                    opacities, shs, colors_precomp, radii, tiles_touched, recA, recB, recC, clamped, depths,
-                                   tile_count, lds_hist, rgbc, vis_mask);
+                                   tile_count, lds_hist, rgbc, vis_mask, slot_info);
             else if (kp.flags & S360_FLAG_SH_CHANNEL_MAJOR)
                 hipLaunchKernelGGL((k_preprocess<true, true>), dim3(nblk), dim3(S360_BLOCK), lds, st, kp, views, means3D, cov6,
                                    opacities, shs, colors_precomp, radii, tiles_touched, recA, recB, recC, clamped, depths,
-                                   tile_count, lds_hist, rgbc, vis_mask);
+                                   tile_count, lds_hist, rgbc, vis_mask, slot_info);
             else
                 hipLaunchKernelGGL((k_preprocess<true, false>), dim3(nblk), dim3(S360_BLOCK), lds, st, kp, views, means3D, cov6,
                                    opacities, shs, colors_precomp, radii, tiles_touched, recA, recB, recC, clamped, depths,
-                                   tile_count, lds_hist, rgbc, vis_mask);
+                                   tile_count, lds_hist, rgbc, vis_mask, slot_info);
         } else {
             hipLaunchKernelGGL((k_preprocess<false, false>), dim3(nblk), dim3(S360_BLOCK), lds_hist ? hist_bytes : 0, st, kp, views,
                                means3D, cov6, opacities, shs, colors_precomp, radii, tiles_touched, recA, recB, recC, clamped,
-                               depths, tile_count, lds_hist, rgbc, vis_mask);
+                               depths, tile_count, lds_hist, rgbc, vis_mask, slot_info);
         }
         }
         S360_CHECK_LAUNCH();
@@ -1560,10 +1596,10 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
         ProfScope ps(PS_EMIT, st);
         if ((size_t)kp.T * 8 <= 64 * 1024)
             hipLaunchKernelGGL(k_emit<true>, egrid, dim3(S360_BLOCK), (size_t)kp.T * 8, st, kp, tiles_touched, vis_mask, recA, recC,
-                               depths, tile_start, tile_cursor, keys, slot_base, slot_pair, slot_ticket);
+                               depths, tile_start, tile_cursor, keys, slot_info, slot_pair, slot_ticket);
         else
             hipLaunchKernelGGL(k_emit<false>, egrid, dim3(S360_BLOCK), 0, st, kp, tiles_touched, vis_mask, recA, recC, depths, tile_start,
-                               tile_cursor, keys, slot_base, slot_pair, slot_ticket);
+                               tile_cursor, keys, slot_info, slot_pair, slot_ticket);
         }
         S360_CHECK_LAUNCH();
         ProfScope ps(PS_SORT, st);

@@ -196,7 +196,7 @@ def render_views_fused(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far
                        max_instances: Optional[int] = None, check: str = "sync", views: Optional[Tensor] = None, glue: str = "native",
                        depth_mode: Optional[DepthRenderingMode] = None, defer_sh: bool = False,
                        mse_target: Optional[Tensor] = None, mse_weight: float = 1.0, mse_count: Optional[int] = None,
-                       exchange=None):
+                       exchange=None, lean: Optional[bool] = None):
     """V <= 8 views of ONE cloud in one fused rasteriser call: means[G,3], covariances[G,3,3],
     harmonics[G,3,d_sh] (the reference's Gaussians layout, src/model/types.py:7-12, read in place),
     opacities[G] -> [V,3,h,w].  With the six face cameras of a panorama (one camera centre) and glue="torch" (the
@@ -204,8 +204,9 @@ def render_views_fused(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far
     glue agrees with it to a few ulp of the camera records (Gauss-Jordan instead of LU inverses).
     shared_campos: True = all views share one camera centre and near plane (SH colours evaluated once per
     Gaussian); False = per-view evaluation; None (default) = decided from `extrinsics` / `near`
-    (views_share_camera_centre: one small synchronising read when they live on the device, cached per camera tensor; with
+    (views_share_camera_centre: one small synchronising read when they live on the device; with
     pre-packed `views` and no extrinsics the views are taken to be independent, False).
+    lean: None = rasterizer.LEAN_LISTS (on: tile lists hold only the instances that can reach a pixel; results bit-identical).
     exchange: distributed.ExchangeConfig — multi-GPU, the gradients come back summed over the ranks (rasterize_views).
     Host synchronisation: check="sync" (default) reads the binning-overflow flag back after the forward, like
     upstream's own scan read-back, and re-renders with the exact capacity if needed; check="lazy" together with an
@@ -224,32 +225,23 @@ def render_views_fused(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far
         gaussian_means, gaussian_covariances, gaussian_opacities, gaussian_sh_coefficients, None, views=views,
         image_height=h, image_width=w, sh_degree=isqrt(n) - 1, shared_campos=shared_campos, want_radii=False,
         max_instances=max_instances, check=check, cov9=True, sh_channel_major=True, depth_mode=depth_mode,
-        defer_sh=defer_sh, mse_target=mse_target, mse_weight=mse_weight, mse_count=mse_count, exchange=exchange)
+        defer_sh=defer_sh, mse_target=mse_target, mse_weight=mse_weight, mse_count=mse_count, exchange=exchange, lean=lean)
     res = (out[0],) if depth_mode is None else (out[0], out[2])
     if mse_target is not None:
         res = res + (out[-1],)
     return res[0] if len(res) == 1 else res
 
 
-_SHARED_CACHE: dict = {}
-
-
 def views_share_camera_centre(extrinsics: Tensor, near: Tensor) -> bool:
     """True when all views have one camera centre and one near plane (the six faces of a panorama): the
     condition under which SH colours may be evaluated once per Gaussian (S360_FLAG_SHARED_CAMPOS).  For device tensors
-    the comparison costs one small synchronising read; the answer is cached per (tensor storage, version), so a camera set
-    that is reused step after step is read once.  Pass shared_campos explicitly on latency-critical paths."""
+    the comparison costs one small synchronising read per call (no cache: a tensor's address / version / shape do not identify
+    its contents — the caching allocator hands the next batch's cameras the same block).  Pass shared_campos explicitly on
+    latency-critical paths."""
     if extrinsics.shape[0] <= 1:
         return True
-    key = (extrinsics.data_ptr(), extrinsics._version, tuple(extrinsics.shape), near.data_ptr(), near._version)
-    hit = _SHARED_CACHE.get(key)
-    if hit is None:
-        t = extrinsics[..., :3, 3]
-        hit = bool(((t == t[:1]).all() & (near == near.reshape(-1)[0]).all()).item())
-        if len(_SHARED_CACHE) > 64:
-            _SHARED_CACHE.clear()
-        _SHARED_CACHE[key] = hit
-    return hit
+    t = extrinsics[..., :3, 3]
+    return bool(((t == t[:1]).all() & (near == near.reshape(-1)[0]).all()).item())
 
 
 def render_cube_faces(pano_c2w: Tensor, near: Tensor, far: Tensor, face_w: int, background: Tensor,

@@ -40,6 +40,12 @@ class GaussianRasterizationSettings(NamedTuple):
     debug: bool
 
 
+# Lean tile lists (S360_FLAG_LEAN_LISTS): a (Gaussian, tile) instance is binned only if the splat can reach alpha >= 1/255 somewhere
+# on that tile.  Images, radii and all gradients are bit-identical to the upstream-compatible lists; tiles_touched / the sorted
+# lists / num_rendered / n_contrib positions are not (they describe fewer instances).  Default on; rasterize_views(lean=False),
+# this switch or S360_LEAN_LISTS=0 select upstream's 3-sigma rectangles (what the integer-state parity tests compare).
+LEAN_LISTS = bool(int(os.environ.get("S360_LEAN_LISTS", "1")))
+
 DEPTH_MODES = {"depth": 0, "disparity": 1, "relative_disparity": 2, "log": 3}
 
 
@@ -106,20 +112,28 @@ def pack_views_spherical(pano_c2w: Tensor, background: Tensor, scale=1.0, near=0
     return v.repeat_interleave(2, dim=0).contiguous()
 
 
-_CAPACITY_HINT: dict = {}   # (P, V, H, W) -> instances of the most recent call of that shape whose count was read back
+_CAPACITY_HINT: dict = {}   # (device, P, V, H, W, lean) -> LARGEST instance count any call of that shape has read back
 
 
-def default_capacity(p: int, v: int, h: int = 0, w: int = 0) -> int:
+def _hint_key(dev, p: int, v: int, h: int, w: int, lean: bool):
+    d = torch.device(dev) if dev is not None else None
+    return (None if d is None else (d.type, d.index), p, v, h, w, bool(lean))
+
+
+def default_capacity(p: int, v: int, h: int = 0, w: int = 0, *, device=None, lean: bool = False, lazy: bool = False) -> int:
     """Capacity (instances = (Gaussian, tile) pairs) of the binning buffers and, through them, of the backward scratch
-    (192 B per instance of capacity): 1.25 x the instance count the previous call of this shape produced, once a caller has read
-    one back (check="sync" reads it with the overflow flag; RasterState.num_rendered() / overflowed() do too), else the
-    first-call guess 1.5 P V.  A call that overflows is re-rendered with the exact size in check="sync" mode; in check="lazy"
-    mode the caller must validate (last_state().overflowed()) — a scene that grows by more than a quarter between two steps
-    without anyone reading a count is the one case that needs max_instances= passed explicitly."""
-    hint = _CAPACITY_HINT.get((p, v, h, w))
+    (per instance of capacity: 24 B of keys / lists / owner table, 192 B of survivor records and 4 x 64 B of quadrant-partial
+    slots in the backward scratch).  First-call guess 1.5 P V.  Once a caller has read an instance count back for this
+    (device, shape, list mode) — check="sync" reads it with the overflow flag; RasterState.num_rendered() / overflowed() do too —
+    the size is 1.25 x the LARGEST count seen (a running maximum: one sparse scene never shrinks the buffers of the next, denser
+    one).  check="sync" re-renders an overflowing call with the exact size; check="lazy" cannot, so there the hint may only
+    RAISE the capacity above the first-call guess, never lower it — pass max_instances= explicitly to run lazy calls in less."""
+    guess = (3 * p * v) // 2 + (1 << 18)
+    hint = _CAPACITY_HINT.get(_hint_key(device, p, v, h, w, lean))
     if hint is not None:
-        return int(min(2**32 - 1, max(1 << 16, hint + hint // 4 + (1 << 16))))
-    return int(min(2**32 - 1, max(1 << 16, (3 * p * v) // 2 + (1 << 18))))
+        sized = hint + hint // 4 + (1 << 16)
+        guess = max(guess, sized) if lazy else sized
+    return int(min(2**32 - 1, max(1 << 16, guess)))
 
 
 class RasterState:
@@ -146,7 +160,8 @@ class RasterState:
             header=self.header(),
             tiles_touched=self._tiles_touched(),
             vis_mask=self._arr(l.vis_mask, p.P, torch.uint8),
-            slot_base=self._arr(l.slot_base, npair, torch.int32).view(p.V, p.P),
+            slot_base=self._arr(l.slot_base, 2 * npair, torch.int32).view(p.V, p.P, 2)[..., 0],
+            hit_mask=self._arr(l.slot_base, 2 * npair, torch.int32).view(p.V, p.P, 2)[..., 1],
             slot_pair=self._arr(l.slot_pair, cap, torch.int32),
             rec_a=self._arr(l.rec_a, npair * 12, torch.float32).view(p.V, p.P, 12)[..., 0:4],
             rec_b=self._arr(l.rec_a, npair * 12, torch.float32).view(p.V, p.P, 12)[..., 4:8],
@@ -174,7 +189,8 @@ class RasterState:
         h = self.header()[:2].cpu()          # one synchronising read for both words
         n, over = int(h[0]) & 0xFFFFFFFF, bool(int(h[1]))
         p = self.prm
-        _CAPACITY_HINT[(p.P, p.V, p.H, p.W)] = n    # sizes the next call of this shape (default_capacity)
+        key = _hint_key(self.workspace.device, p.P, p.V, p.H, p.W, bool(p.flags & _lib.FLAG_LEAN_LISTS))
+        _CAPACITY_HINT[key] = max(n, _CAPACITY_HINT.get(key, 0))    # running maximum: sizes later calls (default_capacity)
         return n, over
 
     def num_rendered(self) -> int:
@@ -238,7 +254,7 @@ class _RasterizeViews(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, cov6, views, cfg, mse_target=None):
         (h, w, sh_degree, shared_campos, max_instances, check, want_radii, cov9, sh_channel_major, keep_slots, depth_mode,
-         defer_sh, mse_weight, mse_count, spherical, exchange) = cfg
+         defer_sh, mse_weight, mse_count, spherical, exchange, lean) = cfg
         if exchange is not None and (shs is None or not (shared_campos or int(views.shape[0]) == 1) or defer_sh):
             raise RuntimeError("exchange=: the chunked gradient exchange needs SH colours and views sharing one camera centre "
                                "(and replaces defer_sh)")
@@ -267,8 +283,10 @@ class _RasterizeViews(torch.autograd.Function):
             prm.flags = (_lib.FLAG_SHARED_CAMPOS if (shared_campos or v == 1) else 0) | (
                 _lib.FLAG_COV9 if cov9 else 0) | (_lib.FLAG_SH_CHANNEL_MAJOR if sh_channel_major else 0) | (
                 0 if (needs_bwd or keep_slots) else _lib.FLAG_FORWARD_ONLY) | (
-                _lib.FLAG_SH_DEG4_IGNORED if SH_DEG4_IGNORED else 0) | (_lib.FLAG_SPHERICAL if spherical else 0)
-            prm.max_instances = int(max_instances) if max_instances else default_capacity(p, v, int(h), int(w))
+                _lib.FLAG_SH_DEG4_IGNORED if SH_DEG4_IGNORED else 0) | (_lib.FLAG_SPHERICAL if spherical else 0) | (
+                _lib.FLAG_LEAN_LISTS if lean else 0)
+            prm.max_instances = int(max_instances) if max_instances else default_capacity(
+                p, v, int(h), int(w), device=m3.device, lean=lean, lazy=(check != "sync"))
             mse = None
             if mse_target is not None:
                 tgt = _f32c(mse_target, "mse_target")
@@ -457,7 +475,8 @@ def rasterize_views(means3D: Tensor, cov6: Tensor, opacities: Tensor, shs: Optio
                     check: str = "sync", want_radii: bool = True, means2D: Optional[Tensor] = None,
                     cov9: bool = False, sh_channel_major: bool = False, keep_slots: bool = False,
                     depth_mode: Optional[str] = None, defer_sh: bool = False, mse_target: Optional[Tensor] = None,
-                    mse_weight: float = 1.0, mse_count: Optional[int] = None, spherical: bool = False, exchange=None):
+                    mse_weight: float = 1.0, mse_count: Optional[int] = None, spherical: bool = False, exchange=None,
+                    lean: Optional[bool] = None):
     """Render V views ([V,44] packed, see pack_views) of one cloud.  cov9: cov6 is [P,3,3];
     sh_channel_major: shs is [P,3,M] (the reference's Gaussians layouts, consumed without copies).
     When no input requires grad the instance-slot tables (backward-only state) are skipped unless
@@ -475,6 +494,8 @@ def rasterize_views(means3D: Tensor, cov6: Tensor, opacities: Tensor, shs: Optio
     exchange=distributed.ExchangeConfig(...) (views sharing one camera centre, SH colours): the gradients this node returns
     are SUMMED over the ranks of the process group — each rank renders its own views of the same replicated cloud — and the
     exchange runs range by range inside the backward (distributed.exchange_chunked).
+    lean (default: module switch LEAN_LISTS = True): bin a (Gaussian, tile) instance only where the splat can reach
+    alpha >= 1/255 on that tile — same images / radii / gradients bit for bit, shorter lists; lean=False = upstream's rectangles.
     spherical=True: native equirectangular splat mode (S360_FLAG_SPHERICAL; no reference counterpart, specified by the
     oracle's geo_sph): `views` = pack_views_spherical(...) — (camera, seam ghost) pairs — and the result is one
     [H,W] equirectangular image per pair; means2D gradients are in pixel units."""
@@ -484,7 +505,8 @@ def rasterize_views(means3D: Tensor, cov6: Tensor, opacities: Tensor, shs: Optio
     if depth_mode is not None and depth_mode not in DEPTH_MODES:
         raise ValueError(f"depth_mode must be one of {sorted(DEPTH_MODES)}")
     cfg = (image_height, image_width, sh_degree, shared_campos, max_instances, check, want_radii, cov9,
-           sh_channel_major, keep_slots, depth_mode, defer_sh, mse_weight, mse_count, bool(spherical), exchange)
+           sh_channel_major, keep_slots, depth_mode, defer_sh, mse_weight, mse_count, bool(spherical), exchange,
+           LEAN_LISTS if lean is None else bool(lean))
     images, radii, depth, loss, clipped = _RasterizeViews.apply(means3D, means2D, shs, colors_precomp, op2, cov6, views,
                                                                 cfg, mse_target)
     images.s360_deferred = _RasterizeViews.last_holder      # see deferred_of()

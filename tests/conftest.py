@@ -22,3 +22,15 @@ def gpu():
     from splatter360_amd import _lib
     _lib.lib()  # fail loudly if the HIP library is missing
     return torch.device("cuda:0")
+
+
+@pytest.fixture
+def parity_lists():
+    """Upstream-compatible tile lists (3-sigma rectangles) for the tests that compare tiles_touched / sorted lists / n_contrib
+    with the oracle; the product default is the lean lists (rasterizer.LEAN_LISTS), whose images and gradients are bit-identical
+    (tests/test_gpu_lean.py)."""
+    from splatter360_amd import rasterizer
+    old = rasterizer.LEAN_LISTS
+    rasterizer.LEAN_LISTS = False
+    yield
+    rasterizer.LEAN_LISTS = old

@@ -10,7 +10,7 @@ from oracle import oracle
 from splatter360_amd import rasterizer
 from test_gpu_parity import _settings_to_torch, check_forward, check_grads, run_hip
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("parity_lists")]   # integer state is compared with the oracle: upstream-compatible lists
 
 
 def _orc(S, means, cov6, shs, opac, gimg=None, colors=None):

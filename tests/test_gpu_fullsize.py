@@ -10,7 +10,7 @@ from helpers import boundary_tensors, face_settings, settings_from_views
 from oracle import oracle
 from splatter360_amd import cameras, decoder, rasterizer, stitch, synthetic
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("parity_lists")]   # integer state is compared with the oracle: upstream-compatible lists
 
 
 @pytest.fixture(scope="module")

@@ -12,7 +12,7 @@ from oracle import oracle
 from splatter360_amd import synthetic
 from test_gpu_parity import check_forward, run_hip
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("parity_lists")]   # integer state is compared with the oracle: upstream-compatible lists
 
 
 def _case(seed):

@@ -22,7 +22,7 @@ from helpers import boundary_tensors, face_settings, settings_from_views
 from oracle import oracle
 from splatter360_amd import cameras, decoder, rasterizer, synthetic
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("parity_lists")]   # integer state is compared with the oracle: upstream-compatible lists
 ROOT = Path(__file__).resolve().parent.parent
 REPORT = {}
 

@@ -10,7 +10,7 @@ from helpers import boundary_tensors, check_instance_slots, face_settings, setti
 from oracle import oracle
 from splatter360_amd import rasterizer, synthetic
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("parity_lists")]   # integer state is compared with the oracle: upstream-compatible lists
 
 
 def _settings_to_torch(S, dev):

@@ -9,7 +9,7 @@ from helpers import boundary_tensors, check_instance_slots, settings_from_views
 from oracle import oracle
 from splatter360_amd import decoder, rasterizer, synthetic
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("parity_lists")]   # integer state is compared with the oracle: upstream-compatible lists
 
 
 def _pose(pos=(0.1, -0.2, 0.05), rot=True):

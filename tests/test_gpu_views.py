@@ -6,7 +6,7 @@ import torch
 
 from splatter360_amd import cameras, decoder, rasterizer, synthetic
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("parity_lists")]   # integer state is compared with the oracle: upstream-compatible lists
 
 
 def _random_poses(n, seed):
