@@ -64,6 +64,8 @@ def parse():
                          "1.53 vs 1.44 ms); 1: record them during the K timed steps")
     ap.add_argument("--fused-loss", type=int, default=1, help="1: L2 loss + its gradient seed fused into the render epilogue; "
                     "0: the reference's torch ops on the rendered faces")
+    ap.add_argument("--defer-loss", type=int, default=1, help="fused loss: 1 (default) = the loss scalar is reduced inside the backward's first "
+                    "launch (S360_FLAG_DEFER_LOSS: a training loop reads it after the step); 0 = by a launch of its own at the end of the forward")
     ap.add_argument("--overlap-exchange", type=int, default=1,
                     help="N>1, factored: 1 (default) = a micro-batch's exchange is finished only after the next micro-batch's forward "
                          "has been queued (it overlaps with that forward: a gradient-accumulation schedule); 0 = finished right "
@@ -237,7 +239,7 @@ def main():
         ex = exchange_cfg if (chunked and not local_only[0]) else None
         kw = dict(check="lazy", shared_campos=True, views=views, defer_sh=factored and not local_only[0], exchange=ex)
         if a.mode == "fwdbwd" and a.fused_loss:   # LossMse fused into the composite store
-            faces, fm = decoder.render_views_fused(ext, K, near, far, (face_w, face_w), bg, *params, mse_target=gt, **kw)
+            faces, fm = decoder.render_views_fused(ext, K, near, far, (face_w, face_w), bg, *params, mse_target=gt, mse_defer=bool(a.defer_loss), **kw)
             loss = fm.loss
         else:
             faces = decoder.render_views_fused(ext, K, near, far, (face_w, face_w), bg, *params, **kw)
@@ -423,7 +425,8 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{cfg_name}: {G} encoder-like synthetic Gaussians (seed 0, deg-4 SH, from {a.n_context if hasattr(a, 'n_context') else 2} "
                                f"context panoramas {pano_w}x{pano_h}), {erp_w}x{erp_h} ERP = 6 faces {face_w}x{face_w} + stitch, {a.mode}"
-                               + (", L2 loss on faces" + (" (fused epilogue)" if a.fused_loss else "") if a.mode == "fwdbwd" else ""),
+                               + (", L2 loss on faces" + (" (fused epilogue" + (", scalar reduced in the backward's first launch)" if a.defer_loss else ")") if a.fused_loss else "") if a.mode == "fwdbwd" else "")
+                               + (", lean tile lists" if rasterizer.LEAN_LISTS else ", upstream-compatible tile lists"),
                    "gaussians": G, "erp": [erp_w, erp_h], "face": face_w, "views_per_gpu": views_per_step,
                    "parallelism": f"view-sharded x{world}" + (
                        "" if not (world > 1 and a.mode == "fwdbwd") else

@@ -87,6 +87,12 @@ enum {
                                          n_contrib (list positions) differ.  Flag clear = the upstream-compatible lists (what the
                                          integer-state parity tests compare with the oracle). */
 
+#define S360_FLAG_DEFER_LOSS 128u       /* s360_forward_mse on a training call with loss_out != NULL: do not launch the loss reduction at
+                                         the end of the forward; the first launch of s360_backward / _split / _composite on this
+                                         workspace performs it (same arithmetic, same fixed order).  loss_out / partials must stay
+                                         allocated until then; loss_out holds the loss only after that backward.  For training loops
+                                         that read the scalar after the backward (logging) — one launch less per step. */
+
 typedef struct S360View {
     float viewmatrix[16];
     float projmatrix[16];
@@ -129,6 +135,8 @@ typedef struct S360Layout {
     size_t depths;              /* float[V*P]   view-space z of visible pairs (sort key) */
     size_t tile_count;          /* uint32[V*T] */
     size_t slot_ticket;         /* per-image instance-slot tickets, 256 B apart (cleared together with tile_count) */
+    size_t merge_done;          /* uint32[V*T][4] completion counters of the global merge passes of the long lists
+                                   (cleared together with tile_count) */
     size_t tile_start;          /* uint32[V*T+1] exclusive scan (upstream ranges: [start[t], start[t+1])) */
     size_t tile_cursor;         /* uint32[V*T] */
     size_t chunk_start;         /* uint32[V*T+1] number of 4096-key sort chunks of long lists before tile t */

@@ -27,6 +27,7 @@ FLAG_FORWARD_ONLY = 8
 FLAG_SH_DEG4_IGNORED = 16
 FLAG_SPHERICAL = 32
 FLAG_LEAN_LISTS = 64
+FLAG_DEFER_LOSS = 128
 ABI_VERSION = 19
 
 
@@ -39,7 +40,7 @@ class S360Params(C.Structure):
 class S360Layout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in (
         "total_bytes", "header", "tiles_touched", "vis_mask", "slot_base", "rec_a", "rec_b", "rec_c",
-        "clamped", "depths", "tile_count", "slot_ticket", "tile_start", "tile_cursor", "chunk_start", "tile_order", "keys", "keys_alt", "list", "final_T", "n_contrib",
+        "clamped", "depths", "tile_count", "slot_ticket", "merge_done", "tile_start", "tile_cursor", "chunk_start", "tile_order", "keys", "keys_alt", "list", "final_T", "n_contrib",
         "tile_max_contrib", "strip_last", "slot_pair", "rgbc", "sh_jac", "surv", "surv_count", "backward_bytes")]
 
 

@@ -8,7 +8,7 @@
 //   k_tile_scan      exclusive scan of the per-tile instance counts -> tile ranges (+ sort-chunk table)
 //   k_emit           scatter (depth bits << 32 | pair) keys into their tile's bucket; training calls: reserve the
 //                    pairs' instance slots (one atomic per block) and write the slot owner table
-//   k_sort_stage1 / k_merge_pass / k_sort_tiles_global
+//   k_sort_stage1 / k_merge_all
 //                    per-tile ascending sort of the unique 64-bit keys (== stable radix sort by
 //                    (tile, depth) with ascending-index emission): LDS merge sort per list or per
 //                    4096-key chunk, global merge-path passes for multi-chunk lists
@@ -541,7 +541,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* l
 
 // single block: tile_start[0..nt] = exclusive scan of tile_count; header bookkeeping.
 // Lists longer than SORT_SHORT keys are sorted as chunks of SORT_CHUNK keys (k_sort_stage1: one 512-thread
-// workgroup per chunk) followed, when there is more than one chunk, by global merge passes (k_merge_pass);
+// workgroup per chunk) followed, when there is more than one chunk, by global merge passes (k_merge_all);
 // chunk_start[t] = number of such chunks before tile t (0 chunks for the short tiles, which have their own class).
 #ifndef S360_SORT_THREADS
 #define S360_SORT_THREADS 512   // workgroup of the sort kernels; a chunk is 8 keys per thread
@@ -551,9 +551,6 @@ constexpr uint32_t SORT_SHORT = 2048;
 constexpr uint32_t SORT_CHUNK = 8 * SORT_THREADS;
 static_assert(SORT_SHORT % SORT_THREADS == 0 && SORT_SHORT <= SORT_CHUNK, "short lists: SORT_SHORT / SORT_THREADS keys per thread");
 constexpr uint32_t MAX_PASSES = 4;
-#ifndef S360_MERGE_TAIL_GRID
-#define S360_MERGE_TAIL_GRID 128
-#endif
 
 constexpr int TS_BLOCK = 1024;  // one workgroup; 16 waves: 1 536 tiles in two sweeps (a 256-thread block needed six: 10 us of barriers)
 __global__ __launch_bounds__(TS_BLOCK) void k_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_start,
@@ -593,12 +590,12 @@ __global__ __launch_bounds__(TS_BLOCK) void k_tile_scan(const uint32_t* __restri
         header[0] = carry;                    // num_instances ("num_rendered")
         header[1] = carry > cap ? 1u : 0u;    // overflow flag
         header[2] = lds_max;                  // longest tile list
-        {   // merge passes the longest (capacity-clamped) list needs: k_merge_pass launches beyond it return at once
+        {   // merge passes the longest (capacity-clamped) list needs: k_merge_all enters no pass beyond it
             const uint32_t nmax = min(lds_max, cap);
             const uint32_t nch = nmax > SORT_SHORT ? (nmax + SORT_CHUNK - 1) / SORT_CHUNK : 0u;
             header[3] = nch <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(nch - 1);
         }
-        for (int i = 8; i < 16; ++i) header[i] = 0;  // debug counters
+        for (int i = 8; i < 24; ++i) header[i] = 0;  // debug counters; [16, 24): deferred-loss hand-over (S360_HDR_LOSS), set by k_render
     }
 }
 
@@ -850,18 +847,18 @@ __device__ __forceinline__ void block_merge_sort(const uint64_t* __restrict__ in
 // Work unit = one SORT_CHUNK-sized output chunk (t, k) of a long tile, found from the block index by a binary
 // search over chunk_start[].  A tile with c chunks needs P = ceil(log2 c) merge passes; it ping-pongs between
 // `keys` and `alt` such that the LAST pass lands in `keys`: the buffer holding the runs before pass i is
-// `alt` when (P - i) is odd.  Tiles needing more than max_passes passes are left to k_sort_tiles_global.
+// `alt` when (P - i) is odd.  Tiles needing more than max_passes passes are left to the global-memory network (sort_tiles_global_body).
 __device__ __forceinline__ uint32_t ceil_log2_u32(uint32_t x) { return x <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(x - 1); }
 
 struct ChunkUnit {
-    uint32_t s, n, k, passes;  // tile start (clamped), tile length, chunk index inside the tile, merge passes of the tile
+    uint32_t s, n, k, passes, t;  // tile start (clamped), tile length, chunk index inside the tile, merge passes of the tile, tile
     bool valid;
 };
 __device__ __forceinline__ ChunkUnit chunk_unit(const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ chunk_start,
                                                  int nt, uint32_t cap, uint32_t b) {
     ChunkUnit u;
     u.valid = b < chunk_start[nt];
-    u.s = u.n = u.k = u.passes = 0;
+    u.s = u.n = u.k = u.passes = u.t = 0;
     if (!u.valid) return u;
     // last t with chunk_start[t] <= b (chunk_start is non-decreasing, chunk_start[0] = 0): 64-ary search by the whole
     // wave — 2 dependent global round trips for up to 4 096 tiles instead of the 12 of a per-thread binary search
@@ -879,6 +876,7 @@ __device__ __forceinline__ ChunkUnit chunk_unit(const uint32_t* __restrict__ til
     u.s = min(tile_start[lo], cap);
     u.n = min(tile_start[lo + 1], cap) - u.s;
     u.k = b - chunk_start[lo];
+    u.t = (uint32_t)lo;
     u.passes = ceil_log2_u32((u.n + SORT_CHUNK - 1) / SORT_CHUNK);
     return u;
 }
@@ -920,13 +918,20 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_stage1(const uint32_t* __
 // Merge path over two sorted runs in global memory: number of A elements among the first d outputs.  Executed by
 // one whole wave as a 64-ary search (64 probes per round, the ballot of the monotone predicate locates the
 // boundary): 2-3 dependent global-memory round trips instead of the ~13 of a binary search.
+// Device-coherent 64-bit accesses (sc1: served by / written through to memory, not a per-XCD L2 line): what the persistent merge
+// kernel uses for the runs one workgroup writes and another — possibly behind a different XCD's L2 — reads in the same launch.
+// (Agent-scope release / acquire FENCES instead write back / invalidate the whole 4-MB L2: 1 024 workgroups doing that made the
+// merge stage 75 us slower than separate launches.)
+__device__ __forceinline__ uint64_t ld_dev(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_dev(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 __device__ __forceinline__ uint32_t merge_path_global_wave(const uint64_t* __restrict__ A, uint32_t la,
                                                            const uint64_t* __restrict__ B, uint32_t lb, uint32_t d, int lane) {
     uint32_t lo = d > lb ? d - lb : 0u, hi = d < la ? d : la;  // answer in [lo, hi]; pred(a) := A[a] <= B[d-1-a]  (answer > a)
     while (lo < hi) {
         const uint32_t step = (hi - lo + 63u) / 64u;
         const uint32_t a = lo + (uint32_t)lane * step;
-        const bool p = a < hi && A[a] <= B[d - 1 - a];
+        const bool p = a < hi && ld_dev(A + a) <= ld_dev(B + (d - 1 - a));
         const uint32_t cnt = (uint32_t)__popcll(__ballot(p));  // true for a prefix of the probes
         if (cnt == 0) {
             hi = lo;
@@ -939,19 +944,22 @@ __device__ __forceinline__ uint32_t merge_path_global_wave(const uint64_t* __res
     return lo;
 }
 
-__global__ __launch_bounds__(SORT_THREADS) void k_merge_pass(const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ chunk_start,
-                                                   int nt, uint64_t* __restrict__ keys, uint64_t* __restrict__ alt,
-                                                   uint32_t* __restrict__ list, uint32_t cap, uint32_t pass, uint32_t max_passes,
-                                                   const uint32_t* __restrict__ header) {
+// ONE launch for everything after the chunk sorts (round 3: four k_merge_pass launches + k_sort_tiles_global, 40 us of which
+// two and a half launches found nothing to do).  Work units = (pass, chunk) in pass-major order, handed out by a ticket counter
+// to whichever workgroup is free; a unit of pass p >= 1 waits until ALL chunks of its tile have finished pass p - 1
+// (merge_done[tile][p-1], one device-scope counter per (tile, pass); the runs themselves are written and read with
+// device-coherent accesses, so no cache-wide fence is needed: stores complete, workgroup barrier, one relaxed atomic).  A unit only ever waits for units with LOWER tickets, and a ticket is only taken by
+// a workgroup that is running, so the schedule cannot deadlock whatever share of the grid is resident.  Passes beyond header[3]
+// (what the longest list of THIS call needs) get no tickets; lists beyond SORT_CHUNK << max_passes keys fall through to the
+// global-memory network at the end of the same launch.
+#ifndef S360_MERGE_GRID
+#define S360_MERGE_GRID 1024
+#endif
+__device__ __forceinline__ void merge_unit(const ChunkUnit& u, uint32_t pass, const uint64_t* __restrict__ keys_c, uint64_t* __restrict__ keys,
+                                           uint64_t* __restrict__ alt, uint32_t* __restrict__ list, uint64_t* lds_m, uint32_t* s_part) {
     constexpr int THREADS = SORT_THREADS, E = 8;
-    extern __shared__ __attribute__((aligned(16))) uint64_t lds_m[];  // [SORT_CHUNK + SORT_CHUNK/E] skewed
-    __shared__ uint32_t s_part[2];
 #define S360_PHYS(i) ((i) + (i) / E)
-    if (pass >= header[3]) return;  // no list of this call needs this pass (the host launches the worst-case count)
-    const uint32_t nchunks = chunk_start[nt];
-    for (uint32_t blk = blockIdx.x; blk < nchunks; blk += gridDim.x) {
-    const ChunkUnit u = chunk_unit(tile_start, chunk_start, nt, cap, blk);
-    if (!u.valid || u.passes > max_passes || pass >= u.passes) continue;  // block-uniform
+    (void)keys_c;
     const uint32_t R = SORT_CHUNK << pass;
     const uint32_t o_tile = u.k * SORT_CHUNK, len = min(SORT_CHUNK, u.n - o_tile);
     const uint32_t pair0 = o_tile / (2 * R) * (2 * R);
@@ -969,7 +977,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_merge_pass(const uint32_t* __r
     __syncthreads();
     const uint32_t a0 = s_part[0], a1 = s_part[1], b0 = o - a0, b1 = o + len - a1;
     const uint32_t na = a1 - a0, nb = b1 - b0;  // na + nb == len
-    for (uint32_t i = threadIdx.x; i < len; i += THREADS) lds_m[S360_PHYS(i)] = i < na ? A[a0 + i] : B[b0 + (i - na)];
+    for (uint32_t i = threadIdx.x; i < len; i += THREADS) lds_m[S360_PHYS(i)] = ld_dev(i < na ? A + (a0 + i) : B + (b0 + (i - na)));
     __syncthreads();
     // in-LDS merge of the two pieces: logical run A = [0, na), run B = [na, na + nb)
     const uint32_t out0 = (uint32_t)threadIdx.x * E;
@@ -995,12 +1003,10 @@ __global__ __launch_bounds__(SORT_THREADS) void k_merge_pass(const uint32_t* __r
                 kb = b < nb ? lds_m[S360_PHYS(na + b)] : ~0ull;
             }
             if (out0 + q < len) {
-                dst[out0 + q] = kq;
+                st_dev(dst + (out0 + q), kq);
                 if (last_pass) lst[out0 + q] = (uint32_t)kq;
             }
         }
-    }
-    __syncthreads();  // LDS and s_part are reused by the next unit of this block
     }
 #undef S360_PHYS
 }
@@ -1009,8 +1015,9 @@ __global__ __launch_bounds__(SORT_THREADS) void k_merge_pass(const uint32_t* __r
 // the ascending-only form of the bitonic network (first sub-step of every stage compares mirrored
 // positions), which tolerates VIRTUAL +inf padding at indices >= n: an ascending compare-exchange never
 // moves a padding key inwards, so nothing outside [0, n) is ever read or written.  Rare and slow.
-__global__ __launch_bounds__(S360_BLOCK) void k_sort_tiles_global(const uint32_t* __restrict__ tile_start, uint64_t* __restrict__ keys,
-                                                                 uint32_t* __restrict__ list, uint32_t lo, uint32_t cap, int nt) {
+template <int THREADS>
+__device__ __forceinline__ void sort_tiles_global_body(const uint32_t* __restrict__ tile_start, uint64_t* __restrict__ keys,
+                                                       uint32_t* __restrict__ list, uint32_t lo, uint32_t cap, int nt) {
   for (int tile = blockIdx.x; tile < nt; tile += gridDim.x) {   // grid-stride over the tiles: almost always nothing to do
     const uint32_t s = min(tile_start[tile], cap), e = min(tile_start[tile + 1], cap);
     const uint32_t n = e - s;
@@ -1020,7 +1027,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_sort_tiles_global(const uint32_t
     uint64_t* kk = keys + s;
     for (uint32_t k = 2; k <= npad; k <<= 1) {
         const uint32_t half = k >> 1;
-        for (uint32_t t = threadIdx.x; t < (npad >> 1); t += S360_BLOCK) {
+        for (uint32_t t = threadIdx.x; t < (npad >> 1); t += THREADS) {
             const uint32_t blk = t / half, off = t - blk * half;
             const uint32_t i = blk * k + off, l = blk * k + (k - 1 - off);
             if (l < n) {
@@ -1034,7 +1041,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_sort_tiles_global(const uint32_t
         __threadfence_block();
         __syncthreads();
         for (uint32_t j = k >> 2; j > 0; j >>= 1) {
-            for (uint32_t t = threadIdx.x; t < (npad >> 1); t += S360_BLOCK) {
+            for (uint32_t t = threadIdx.x; t < (npad >> 1); t += THREADS) {
                 const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
                 if (l < n) {
                     const uint64_t a = kk[i], b = kk[l];
@@ -1048,9 +1055,47 @@ __global__ __launch_bounds__(S360_BLOCK) void k_sort_tiles_global(const uint32_t
             __syncthreads();
         }
     }
-    for (uint32_t i = threadIdx.x; i < n; i += S360_BLOCK) list[s + i] = (uint32_t)kk[i];
+    for (uint32_t i = threadIdx.x; i < n; i += THREADS) list[s + i] = (uint32_t)kk[i];
     __syncthreads();
   }
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void k_merge_all(const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ chunk_start,
+                                                  int nt, uint64_t* __restrict__ keys, uint64_t* __restrict__ alt,
+                                                  uint32_t* __restrict__ list, uint32_t cap, uint32_t max_passes,
+                                                  const uint32_t* __restrict__ header, uint32_t* __restrict__ merge_done,
+                                                  uint32_t global_lo) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds_m[];  // [SORT_CHUNK + SORT_CHUNK/E] skewed
+    __shared__ uint32_t s_part[2];
+    __shared__ uint32_t s_ticket;
+    const uint32_t npass = min(header[3], max_passes);   // merge passes the longest (capacity-clamped) list of this call needs
+    const uint32_t nchunks = npass ? chunk_start[nt] : 0u;
+    const uint32_t nunits = npass * nchunks;
+    uint32_t* const queue = merge_done + (size_t)nt * MAX_PASSES;   // the work queue's ticket counter (cleared with the counters)
+    for (;;) {
+        if (threadIdx.x == 0) s_ticket = nunits ? __hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        __syncthreads();
+        const uint32_t tk = s_ticket;
+        __syncthreads();
+        if (tk >= nunits) break;
+        const uint32_t pass = tk / nchunks, blk = tk - pass * nchunks;
+        const ChunkUnit u = chunk_unit(tile_start, chunk_start, nt, cap, blk);
+        if (!u.valid || u.passes > max_passes || pass >= u.passes) continue;  // block-uniform
+        const uint32_t nch = (u.n + SORT_CHUNK - 1) / SORT_CHUNK;
+        if (pass > 0) {
+            if (threadIdx.x == 0) {
+                while (__hip_atomic_load(&merge_done[(size_t)u.t * MAX_PASSES + pass - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nch)
+                    __builtin_amdgcn_s_sleep(4);
+            }
+            __syncthreads();
+        }
+        merge_unit(u, pass, keys, keys, alt, list, lds_m, s_part);   // runs read and written with device-coherent accesses
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // every thread's stores are complete ...
+        __syncthreads();                                              // ... before the counter says so (also: LDS and s_part are reused next)
+        if (threadIdx.x == 0 && pass + 1 < u.passes)
+            __hip_atomic_fetch_add(&merge_done[(size_t)u.t * MAX_PASSES + pass], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (header[2] > global_lo) sort_tiles_global_body<SORT_THREADS>(tile_start, keys, list, global_lo, cap, nt);
 }
 
 // ------------------------------------------------------------------------------ composite
@@ -1087,55 +1132,9 @@ struct MseEp {
 // ~2-us memory round trips after a launch (the partials were just written behind other XCDs' L2s); running the same
 // reduction in the LAST workgroup of k_render instead (write-through partials, one device-scope count per workgroup) measured
 // exactly the same 9 us at the end of k_render — built, parity-green, not kept.
-constexpr int MSE_BLOCK = 1024;
 __global__ __launch_bounds__(MSE_BLOCK) void k_mse_finish(const float* __restrict__ partials, int n_per_view, int V, float loss_scale,
                                                          float inv_elems, float* __restrict__ out) {
-    constexpr int VG = 8;  // views per sweep: their loads are independent, one round trip per 1024 partials of each
-    __shared__ float s_w[MSE_BLOCK / 64][VG][2];
-    const int lane = lane_id(), wave = threadIdx.x >> 6;
-    float total = 0.f;
-    for (int v0 = 0; v0 < V; v0 += VG) {
-        float a[VG], b[VG];
-#pragma unroll
-        for (int j = 0; j < VG; ++j) a[j] = b[j] = 0.f;
-        for (int i = threadIdx.x; i < n_per_view; i += MSE_BLOCK) {
-            float2 q[VG];
-#pragma unroll
-            for (int j = 0; j < VG; ++j)
-                q[j] = v0 + j < V ? reinterpret_cast<const float2*>(partials)[(size_t)(v0 + j) * n_per_view + i] : make_float2(0.f, 0.f);
-#pragma unroll
-            for (int j = 0; j < VG; ++j) {
-                a[j] += q[j].x;
-                b[j] += q[j].y;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < VG; ++j) {
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                a[j] += __shfl_xor(a[j], o);
-                b[j] += __shfl_xor(b[j], o);
-            }
-            if (lane == 0) {
-                s_w[wave][j][0] = a[j];
-                s_w[wave][j][1] = b[j];
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            for (int j = 0; j < VG && v0 + j < V; ++j) {
-                float sa = 0.f, sb = 0.f;
-                for (int w = 0; w < MSE_BLOCK / 64; ++w) {
-                    sa += s_w[w][j][0];
-                    sb += s_w[w][j][1];
-                }
-                total += sa;
-                out[1 + v0 + j] = sb * inv_elems;
-            }
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[0] = total * loss_scale;
+    mse_finish_body(partials, n_per_view, V, loss_scale, inv_elems, out);
 }
 
 template <bool WITH_DEPTH>
@@ -1148,7 +1147,7 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
                                                       uint32_t* __restrict__ dbg, const float* __restrict__ depths,
                                                       float* __restrict__ depth_maps, int depth_mode, MseEp ep,
                                                       const uint32_t* __restrict__ tile_order, float4* __restrict__ surv,
-                                                      uint32_t* __restrict__ surv_count) {
+                                                      uint32_t* __restrict__ surv_count, uint32_t* __restrict__ hdr_loss) {
 #ifdef S360_DBG_TIMING
     const long long t_begin = wall_clock64();
 #endif
@@ -1389,6 +1388,15 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
             ep.partials[2 * (4 * (size_t)t + wave) + 1] = s1;
         }
     }
+    if (hdr_loss && blockIdx.x == 0 && threadIdx.x == 0) {
+        // S360_FLAG_DEFER_LOSS: where the loss reduction goes, for the backward's first launch (k_order_units)
+        const uint64_t pp = (uint64_t)(uintptr_t)ep.partials, po = (uint64_t)(uintptr_t)ep.loss_out;
+        hdr_loss[0] = (uint32_t)pp; hdr_loss[1] = (uint32_t)(pp >> 32);
+        hdr_loss[2] = (uint32_t)po; hdr_loss[3] = (uint32_t)(po >> 32);
+        hdr_loss[4] = (uint32_t)(kp.T * 4); hdr_loss[5] = (uint32_t)kp.V;
+        hdr_loss[6] = __float_as_uint(0.5f * ep.grad_scale);
+        hdr_loss[7] = __float_as_uint(1.0f / (3.0f * (float)kp.H * (float)kp.W));
+    }
     const uint32_t wm = wave_max_u32(inside ? last : 0u);
     if (lane == 0) {
         strip_last[4 * t + wave] = wm;  // per-quadrant replay length (list positions)
@@ -1439,6 +1447,7 @@ extern "C" int s360_layout(const S360Params* prm, S360Layout* out) {
     out->depths = take(np * 4);
     out->tile_count = take(nt * 4);
     out->slot_ticket = take((size_t)prm->V * 256);  // per-image instance-slot tickets, 256 B apart; cleared with tile_count
+    out->merge_done = take((nt * MAX_PASSES + 1) * 4);   // completion counters of the merge passes, one per (tile, pass), + the ticket counter of their work queue; cleared with tile_count
     out->tile_start = take((nt + 1) * 4);
     out->tile_cursor = take(nt * 4);
     out->chunk_start = take((nt + 1) * 4);
@@ -1605,7 +1614,7 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
         ProfScope ps(PS_SORT, st);
         {
             // Lists of up to 2 048 keys (the bulk) are sorted by one workgroup each; longer ones as 4 096-key chunks followed,
-            // for multi-chunk lists, by `passes` global merge passes (k_merge_pass).  The number of pass launches is fixed on
+            // for multi-chunk lists, by `passes` global merge passes (k_merge_all).  The upper bound of the pass count is fixed on
             // the host (no read-back): enough for the longest possible list, capped at MAX_PASSES (4 096 << 4 = 65 536 keys);
             // passes no list of the call needs return at once (header[3]); anything longer falls through to the global network.
             const size_t cap_keys = kp.cap < (uint32_t)kp.P ? kp.cap : (size_t)kp.P;   // a tile holds a Gaussian at most once
@@ -1617,17 +1626,13 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
             const size_t lds512 = (size_t)(SORT_CHUNK + SORT_CHUNK / 8) * 8;
             hipLaunchKernelGGL(k_sort_stage1, dim3(cgrid + nt + 1), dim3(SORT_THREADS), lds512, st, tile_start, chunk_start, nt, keys, keys_alt, list,
                                kp.cap, passes, cgrid, tile_count, tile_order);
-            // every merge kernel walks the chunk table grid-stride, so its grid is a matter of speed only: pass 0 gets the full
-            // grid; the later passes — needed by lists beyond 8 192 / 16 384 / 32 768 keys, i.e. by few tiles or none, and
-            // launched unconditionally because the host never reads a list length back — get S360_MERGE_TAIL_GRID blocks (an
-            // empty 1 024-block launch costs 4.3 us, a 128-block one 2 us); same for the global-memory fallback beyond 65 536
-            const unsigned tail_grid = cgrid < (unsigned)S360_MERGE_TAIL_GRID ? cgrid : (unsigned)S360_MERGE_TAIL_GRID;
-            for (uint32_t p = 0; p < passes; ++p)
-                hipLaunchKernelGGL(k_merge_pass, dim3(p == 0 ? cgrid : tail_grid), dim3(SORT_THREADS), lds512, st, tile_start, chunk_start, nt, keys,
-                                   keys_alt, list, kp.cap, p, passes, header);
-            if ((size_t)global_lo < cap_keys)  // otherwise no list can be that long
-                hipLaunchKernelGGL(k_sort_tiles_global, dim3((unsigned)nt < tail_grid ? nt : tail_grid), dim3(S360_BLOCK), 0, st, tile_start,
-                                   keys, list, global_lo, kp.cap, nt);
+            // everything after the chunk sorts in ONE launch: persistent workgroups, pass by pass behind per-tile completion
+            // counters; passes no list of the call needs are never entered, the global-memory fallback runs in the same launch
+            if (passes > 0) {
+                const unsigned mgrid = cgrid < (unsigned)S360_MERGE_GRID ? cgrid : (unsigned)S360_MERGE_GRID;
+                hipLaunchKernelGGL(k_merge_all, dim3(mgrid), dim3(SORT_THREADS), lds512, st, tile_start, chunk_start, nt, keys, keys_alt, list,
+                                   kp.cap, passes, header, (uint32_t*)(ws + L.merge_done), (size_t)global_lo < cap_keys ? global_lo : 0xFFFFFFFFu);
+            }
         }
         S360_CHECK_LAUNCH();
     }
@@ -1642,15 +1647,19 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
 #else
         uint32_t* dbg = header + 8;           // S360_DBG_COUNT counters
 #endif
+        // S360_FLAG_DEFER_LOSS (training calls with a loss epilogue): no reduction launch here — k_render leaves the pointers in the
+        // header and the backward's first launch reduces (loss_out is complete once s360_backward* has run on this workspace)
+        const bool defer = training && kp.P > 0 && ep.target && ep.loss_out && (kp.flags & S360_FLAG_DEFER_LOSS);
+        uint32_t* hdr_loss = defer ? header + S360_HDR_LOSS : nullptr;
         if (depth_maps)
             hipLaunchKernelGGL(k_render<true>, rgrid, rblock, 0, st, kp, views, tile_start,
                                list, recA, recB, recC, images, final_T, n_contrib, tile_max_contrib, strip_last, dbg,
-                               depths, depth_maps, depth_mode, ep, kp.P > 0 ? tile_order : (const uint32_t*)nullptr, surv, surv_count);
+                               depths, depth_maps, depth_mode, ep, kp.P > 0 ? tile_order : (const uint32_t*)nullptr, surv, surv_count, hdr_loss);
         else
             hipLaunchKernelGGL(k_render<false>, rgrid, rblock, 0, st, kp, views, tile_start,
                                list, recA, recB, recC, images, final_T, n_contrib, tile_max_contrib, strip_last, dbg,
-                               depths, depth_maps, depth_mode, ep, kp.P > 0 ? tile_order : (const uint32_t*)nullptr, surv, surv_count);
-        if (ep.target && ep.loss_out)
+                               depths, depth_maps, depth_mode, ep, kp.P > 0 ? tile_order : (const uint32_t*)nullptr, surv, surv_count, hdr_loss);
+        if (ep.target && ep.loss_out && !defer)
             hipLaunchKernelGGL(k_mse_finish, dim3(1), dim3(MSE_BLOCK), 0, st, ep.partials, kp.T * 4, kp.V, 0.5f * ep.grad_scale,
                                1.0f / (3.0f * (float)kp.H * (float)kp.W), ep.loss_out);
     }

@@ -95,3 +95,28 @@ def test_fused_mse_ragged_image_and_no_grad(gpu):
     want = ((faces - gt) ** 2).mean()
     assert abs(fm.loss.item() - want.item()) <= 2e-6 * want.item()
     torch.testing.assert_close(fm.psnr(), _psnr_ref(gt, faces), rtol=1e-5, atol=1e-5)
+
+
+def test_deferred_loss_is_reduced_by_the_backward(gpu):
+    """mse_defer=True (S360_FLAG_DEFER_LOSS): no reduction launch at the end of the forward; the backward's first launch writes
+    the same loss / clipped MSE bit for bit, and the gradients do not change."""
+    ps, (ext, K, near, far), gt = _setup(gpu, seed=3)
+    bg = torch.tensor([0.0, 0.2, 0.1], device=gpu)
+    faces, fm = decoder.render_views_fused(ext, K, near, far, (64, 64), bg, *ps, mse_target=gt, mse_weight=0.8)
+    fm.loss.backward()
+    want_loss, want_clip = fm.loss.detach().clone(), fm.clipped_mse.clone()
+    want = [p.grad.clone() for p in ps]
+    for p in ps:
+        p.grad = None
+    faces2, fm2 = decoder.render_views_fused(ext, K, near, far, (64, 64), bg, *ps, mse_target=gt, mse_weight=0.8, mse_defer=True)
+    assert torch.equal(faces2, faces)
+    fm2.loss.backward()
+    torch.cuda.synchronize()
+    assert torch.equal(fm2.loss.detach(), want_loss) and torch.equal(fm2.clipped_mse, want_clip)
+    for p, w in zip(ps, want):
+        assert torch.equal(p.grad, w)
+    # an inference call ignores the flag: the loss is there without any backward
+    with torch.no_grad():
+        _, fm3 = decoder.render_views_fused(ext, K, near, far, (64, 64), bg, *[p.detach() for p in ps], mse_target=gt, mse_weight=0.8,
+                                            mse_defer=True)
+    assert torch.equal(fm3.loss, want_loss)
