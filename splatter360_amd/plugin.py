@@ -1,0 +1,129 @@
+"""Plug the fused MI355X decoder into the UNCHANGED reference through the reference's own plugin seam.
+
+The reference builds its decoder with `get_decoder(cfg.model.decoder, cfg.dataset)` (/root/reference/src/main.py:168), which looks
+the class up in the registry `DECODERS = {"splatting_cuda": DecoderSplattingCUDA}` (/root/reference/src/model/decoder/__init__.py:5-13)
+under the key `config/model/decoder/splatting_cuda.yaml:1` names.  `install()` replaces that registry entry with a subclass of the
+reference's own `Decoder` base (src/model/decoder/decoder.py:26-48: same constructor `(cfg, dataset_cfg)`, same `forward`
+contract, returns the reference's `DecoderOutput`) whose forward renders every target panorama's six faces — colour and depth
+together — in ONE rasteriser call of this library instead of twelve Python-looped drop-in calls
+(decoder_splatting_cuda.py:47-59,72-97).  Encoder, losses, Lightning wrapper, configs: untouched.
+
+    import splatter360_amd; splatter360_amd.install()        # one line before the reference's `main` runs, or
+    PYTHONPATH=/path/to/repo/examples/site python -m src.main +experiment=hm3d ...   # examples/site/sitecustomize.py does it lazily
+
+Without install() the reference still runs on this library through the drop-in module `diff_gaussian_rasterization`
+ — per face, per pass, with upstream's host synchronisations; bench.py prints both step times.
+"""
+from __future__ import annotations
+
+import importlib
+import importlib.abc
+import importlib.util
+import sys
+from typing import Optional
+
+import torch
+
+REGISTRY_MODULE = "src.model.decoder"
+REGISTRY_KEY = "splatting_cuda"
+
+
+def make_decoder_class(base_cls, output_cls, *, views_per_group: int = 6, shared_campos: Optional[bool] = None, check: str = "sync",
+                       glue: str = "native", name: str = "DecoderSplattingFusedMI355X"):
+    """A decoder class with the reference's constructor and forward contract (decoder.py:26-48) on the fused path.
+    base_cls / output_cls: the reference's `Decoder` / `DecoderOutput` (install()), or this package's mirrors (tests on a box
+    without the reference).  The options are those of decoder.DecoderSplattingFused."""
+    from . import decoder as _dec
+
+    class _Fused(base_cls):
+        def __init__(self, cfg, dataset_cfg) -> None:
+            try:
+                super().__init__(cfg, dataset_cfg)
+            except TypeError:        # a plain nn.Module base (the mirror): no (cfg, dataset_cfg) constructor
+                torch.nn.Module.__init__(self)
+                self.cfg, self.dataset_cfg = cfg, dataset_cfg
+            bg = tuple(float(c) for c in dataset_cfg.background_color)
+            self.fused = _dec.DecoderSplattingFused(background_color=bg, views_per_group=views_per_group, shared_campos=shared_campos,
+                                                    check=check, glue=glue)
+
+        @property
+        def background_color(self):          # the attribute the reference's own decoder exposes (decoder_splatting_cuda.py:28-32)
+            return self.fused.background_color
+
+        def forward(self, gaussians, extrinsics, intrinsics, near, far, image_shape, depth_mode=None):
+            out = self.fused(gaussians, extrinsics, intrinsics, near, far, tuple(int(x) for x in image_shape), depth_mode=depth_mode)
+            return output_cls(out.color, out.depth)
+
+        def render_depth(self, gaussians, extrinsics, intrinsics, near, far, image_shape, mode="depth"):
+            """decoder_splatting_cuda.py:72-97 (used by the visualisation scripts): the depth channel of the same fused pass."""
+            return self.forward(gaussians, extrinsics, intrinsics, near, far, image_shape, depth_mode=mode).depth
+
+    _Fused.__name__ = _Fused.__qualname__ = name
+    return _Fused
+
+
+def _patch(pkg, **opts):
+    base = importlib.import_module(REGISTRY_MODULE + ".decoder")
+    cls = make_decoder_class(base.Decoder, base.DecoderOutput, **opts)
+    cls.replaced = pkg.DECODERS.get(REGISTRY_KEY)       # the reference's own class stays reachable
+    pkg.DECODERS[REGISTRY_KEY] = cls
+    return cls
+
+
+class _LazyPatcher(importlib.abc.MetaPathFinder):
+    """Patches the registry right after the reference's decoder package has been imported by whoever imports it first."""
+
+    def __init__(self, opts):
+        self.opts, self.busy = opts, False
+
+    def find_spec(self, fullname, path, target=None):
+        if fullname != REGISTRY_MODULE or self.busy:
+            return None
+        self.busy = True
+        try:
+            spec = importlib.util.find_spec(fullname)
+        finally:
+            self.busy = False
+        if spec is None or spec.loader is None:
+            return None
+        loader, opts, finder = spec.loader, self.opts, self
+
+        class _Loader(importlib.abc.Loader):
+            def create_module(self, s):
+                return loader.create_module(s)
+
+            def exec_module(self, module):
+                loader.exec_module(module)
+                if finder in sys.meta_path:
+                    sys.meta_path.remove(finder)
+                _patch(module, **opts)
+
+        spec.loader = _Loader()
+        return spec
+
+
+def install(*, lazy: bool = False, **opts):
+    """Register the fused decoder under the reference's registry key "splatting_cuda".  Returns the class (lazy=False) or None.
+
+    lazy=False: imports `src.model.decoder` now (the reference must be importable: its repository root on sys.path) and patches
+    its DECODERS dict in place — `get_decoder` reads the dict at call time, so every later `get_decoder(cfg, dataset_cfg)` builds
+    the fused decoder.  lazy=True: only installs an import hook that patches the registry when the reference itself first imports
+    the package (for a sitecustomize that runs before sys.path is set up).  Idempotent.
+    opts: views_per_group (6), shared_campos (None = checked per group with one small read per forward), check ("sync"), glue."""
+    if lazy:
+        if REGISTRY_MODULE in sys.modules:
+            return _patch(sys.modules[REGISTRY_MODULE], **opts)
+        if not any(isinstance(f, _LazyPatcher) for f in sys.meta_path):
+            sys.meta_path.insert(0, _LazyPatcher(opts))
+        return None
+    return _patch(importlib.import_module(REGISTRY_MODULE), **opts)
+
+
+def uninstall() -> None:
+    """Put the reference's own decoder class back (and drop a pending lazy hook)."""
+    sys.meta_path[:] = [f for f in sys.meta_path if not isinstance(f, _LazyPatcher)]
+    pkg = sys.modules.get(REGISTRY_MODULE)
+    if pkg is not None:
+        cur = pkg.DECODERS.get(REGISTRY_KEY)
+        if getattr(cur, "replaced", None) is not None:
+            pkg.DECODERS[REGISTRY_KEY] = cur.replaced

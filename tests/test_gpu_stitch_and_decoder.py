@@ -197,3 +197,20 @@ def test_fused_depth_map_is_differentiable_like_the_second_pass(gpu, mode):
         out = decoder.DecoderSplattingFused().to(gpu)(gs, ext, k, near, far, (fw, fw), depth_mode=mode)
         (out.depth * wd).sum().backward()       # depth-only loss: used to raise / give zero gradient
         assert gs.means.grad.abs().max().item() > 0 and gs.harmonics.grad.abs().max().item() == 0
+
+
+@pytest.mark.parametrize("fw,eh,ew", [(256, 512, 1024), (512, 1024, 2048)])
+def test_cube2equirec_values_at_headline_sizes_match_reference_golden(gpu, fw, eh, ew):
+    """ERP VALUES of the stitch at the headline (256 -> 1024x512) and configs[4] (512 -> 2048x1024) sizes against strided rows /
+    columns of the reference's own Cube2Equirec.forward output on a seeded cube (/root/reference/src/geometry/layers.py:108-116;
+    fixture: tests/golden/make_golden_decoder.py) — the smaller fixtures pin the grid only up to 64-px faces."""
+    z = np.load(G / f"cube2equirec_{fw}_{eh}_{ew}_erp.npz")
+    cube = np.random.default_rng(int(z["seed"])).standard_normal((1, 3, fw, 6 * fw)).astype(np.float32)
+    assert float(cube.astype(np.float64).sum()) == float(z["cube_sum64"])      # the regenerated input IS the fixture's input
+    c2e = stitch.Cube2Equirec(fw, eh, ew).to(gpu)
+    erp = c2e(torch.tensor(cube, device=gpu))[0].cpu().numpy()
+    rs, cs = int(z["row_stride"]), int(z["col_stride"])
+    # trilinear weights in float32: the HIP kernel and torch's grid_sample order the eight products differently
+    np.testing.assert_allclose(erp[:, ::rs], z["rows"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(erp[:, :, ::cs], z["cols"], rtol=0, atol=2e-6)
+    assert abs(float(erp.astype(np.float64).sum()) - float(z["erp_sum64"])) <= 1e-6 * erp.size

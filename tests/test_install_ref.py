@@ -1,0 +1,94 @@
+"""`splatter360_amd.install()` against the reference's own plugin seam (build container only: needs /root/reference).
+
+The reference's decoder package is imported for real (its __init__ runs: DECODERS, get_decoder —
+/root/reference/src/model/decoder/__init__.py:5-13) under the SURVEY Appendix-B stubs for the absent third-party modules; the
+rasteriser it imports is THIS repository's drop-in `diff_gaussian_rasterization`.  Runs on CPU: construction and registry only —
+the forward of the registered class is exercised on the GPU from the committed capture (tests/test_gpu_install.py)."""
+import importlib
+import subprocess
+import sys
+import textwrap
+import types
+from pathlib import Path
+from types import SimpleNamespace
+
+import pytest
+
+REF = Path("/root/reference")
+ROOT = Path(__file__).resolve().parent.parent
+pytestmark = pytest.mark.skipif(not (REF / "src/model/decoder/__init__.py").exists(), reason="the reference is only present in the build container")
+
+PRELUDE = textwrap.dedent(f"""
+    import sys, types
+    from pathlib import Path
+    REF = {str(REF)!r}
+    jt = types.ModuleType("jaxtyping")
+    class _Ann:
+        def __getitem__(self, item):
+            return object
+    for name in ("Float", "Int", "Int64", "Int32", "UInt8", "Bool", "Shaped"):
+        setattr(jt, name, _Ann())
+    sys.modules["jaxtyping"] = jt
+    sys.modules["cv2"] = types.ModuleType("cv2")
+    ds = types.ModuleType("src.dataset"); ds.__path__ = [REF + "/src/dataset"]; ds.DatasetCfg = object
+    sys.modules["src.dataset"] = ds
+    for pkg in ("src.model.encoder", "src.model.encoder.costvolume"):
+        m = types.ModuleType(pkg); m.__path__ = [REF + "/" + pkg.replace(".", "/")]; sys.modules[pkg] = m
+    sys.path.insert(0, REF)
+    sys.path.insert(0, {str(ROOT)!r})
+    from types import SimpleNamespace
+    cfg, dcfg = SimpleNamespace(name="splatting_cuda"), SimpleNamespace(background_color=[0.1, 0.2, 0.3])
+""")
+
+
+def _run(body: str) -> str:
+    r = subprocess.run([sys.executable, "-c", PRELUDE + textwrap.dedent(body)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return r.stdout
+
+
+def test_install_registers_the_fused_decoder_under_the_reference_key():
+    out = _run("""
+        import splatter360_amd
+        cls = splatter360_amd.install()
+        from src.model.decoder import DECODERS, get_decoder
+        from src.model.decoder.decoder import Decoder, DecoderOutput
+        import diff_gaussian_rasterization, splatter360_amd.rasterizer as R
+        assert diff_gaussian_rasterization.GaussianRasterizer is R.GaussianRasterizer     # the reference imports THIS drop-in
+        dec = get_decoder(cfg, dcfg)
+        assert type(dec) is cls and DECODERS["splatting_cuda"] is cls and isinstance(dec, Decoder)
+        assert cls.replaced.__name__ == "DecoderSplattingCUDA"
+        assert [round(float(x), 4) for x in dec.background_color] == [0.1, 0.2, 0.3]
+        assert dec.cfg is cfg and dec.dataset_cfg is dcfg
+        # the forward contract is the reference's (decoder.py:37-48): same parameter names, in order
+        import inspect
+        want = list(inspect.signature(Decoder.forward).parameters)
+        assert list(inspect.signature(cls.forward).parameters) == want, want
+        # no CPU path: a CPU call fails loudly instead of falling back
+        import torch
+        from src.model.types import Gaussians
+        g = Gaussians(torch.zeros(1, 4, 3), torch.eye(3).expand(1, 4, 3, 3).contiguous(), torch.zeros(1, 4, 3, 25), torch.ones(1, 4))
+        e = torch.eye(4).expand(1, 6, 4, 4).contiguous(); k = torch.eye(3).expand(1, 6, 3, 3).contiguous()
+        try:
+            dec.forward(g, e, k, torch.full((1, 6), 0.1), torch.full((1, 6), 10.0), (16, 16))
+            raise SystemExit("a CPU call must raise")
+        except RuntimeError as ex:
+            assert "GPU" in str(ex) or "libs360" in str(ex), ex
+        splatter360_amd.uninstall()
+        assert DECODERS["splatting_cuda"].__name__ == "DecoderSplattingCUDA"
+        print("ok")
+    """)
+    assert out.strip().endswith("ok")
+
+
+def test_lazy_install_patches_when_the_reference_imports_its_decoder_package():
+    out = _run("""
+        import splatter360_amd
+        assert splatter360_amd.install(lazy=True) is None
+        assert "src.model.decoder" not in sys.modules
+        from src.model.decoder import get_decoder            # the reference's own import (src/main.py:33)
+        dec = get_decoder(cfg, dcfg)
+        assert type(dec).__name__ == "DecoderSplattingFusedMI355X", type(dec)
+        print("ok")
+    """)
+    assert out.strip().endswith("ok")
