@@ -78,6 +78,10 @@ def parse():
                     help="fwdbwd mode: 1 (default) = K more forward-only steps after the timed region, reported as `forward_only` "
                          "(BASELINE configs[1]); 0 = skip them (the rocprofv3 passes of scripts/collect_profiles.sh: per-kernel averages "
                          "then hold the training form of every kernel only)")
+    ap.add_argument("--workloads", type=int, default=1,
+                    help="fwdbwd, 1 GPU: 1 (default) = after the headline measurement, time the same step on two more clouds of the same size "
+                         "(SURVEY 8(d)'s uniform-random stress cloud and a surface-like cloud: coherent depth, opacity >= 0.9) and the "
+                         "per-face drop-in training step of the unchanged reference (`dropin_train`); 0 = skip them")
     ap.add_argument("--dry-run", type=int, default=0,
                     help="1: launch / rendezvous / collectives only (no GPU work, value = null): lets the CPU test suite exercise "
                          "`python bench.py --gpus N` end to end with the gloo backend")
@@ -200,8 +204,11 @@ def main():
     face_w = a.face or pano_h // 2
     cloud = synthetic.encoder_like_cloud(pano_h, pano_w, n_context=2, d_sh=25, seed=0)
     G = cloud["means"].shape[0]
-    params = [torch.tensor(cloud[k], device=dev, requires_grad=(a.mode == "fwdbwd"))
-              for k in ("means", "covariances", "harmonics", "opacities")]
+    def to_params(c):
+        return [torch.tensor(c[k], device=dev, requires_grad=(a.mode == "fwdbwd")) for k in ("means", "covariances", "harmonics", "opacities")]
+
+    params = to_params(cloud)
+    cur = {"params": params, "check": "lazy"}     # what step_train renders (the extra workloads swap the cloud in)
     # one target panorama per rank (identity rotation, small per-rank offsets)
     pose = torch.tensor(synthetic.target_pano_pose((0.05 * rank, 0.02 * rank, -0.03 * rank)), device=dev)
     # what the reference's dataloader hands the decoder for one target panorama: 6 face cameras
@@ -233,11 +240,12 @@ def main():
     local_only = [False]   # N > 1: steps without the exchange, to quote how much of it a step exposes
 
     def step_train():
+        params = cur["params"]
         for p in params:
             p.grad = None
         views = decoder.pack_camera_views(ext, K, near, far, bg)  # camera glue of this step: one kernel (s360_pack_views)
         ex = exchange_cfg if (chunked and not local_only[0]) else None
-        kw = dict(check="lazy", shared_campos=True, views=views, defer_sh=factored and not local_only[0], exchange=ex)
+        kw = dict(check=cur["check"], shared_campos=True, views=views, defer_sh=factored and not local_only[0], exchange=ex)
         if a.mode == "fwdbwd" and a.fused_loss:   # LossMse fused into the composite store
             faces, fm = decoder.render_views_fused(ext, K, near, far, (face_w, face_w), bg, *params, mse_target=gt, mse_defer=bool(a.defer_loss), **kw)
             loss = fm.loss
@@ -287,6 +295,7 @@ def main():
     sync()
     dt = distributed.max_over_ranks(time.perf_counter() - t0, dev)
     ms_per_step = dt / a.steps * 1e3
+    st_timed = rasterizer.last_state()     # workspace of the last timed step (a training workspace in fwdbwd mode)
 
     extra = {}
     if a.mode == "fwdbwd" and a.forward_figure:
@@ -335,6 +344,14 @@ def main():
     tt = st.tensors()
     visible_pairs = int((tt["tiles_touched"] > 0).sum().item())
     assert torch.isfinite(out["faces"]).all() and torch.isfinite(out["erp"]).all()
+    # contributing (pixel, entry) pairs of this step's render and the pairs the backward evaluates for them (measurement aid)
+    n_contrib_pairs, n_bwd_pairs = st_timed.count_contributions() if a.mode == "fwdbwd" else (None, None)
+    # the same call with upstream's 3-sigma rectangles: how much the lean lists remove (identical images; tests/test_gpu_lean.py)
+    L_upstream = L
+    if rasterizer.LEAN_LISTS and a.mode != "eval":
+        with torch.no_grad():
+            decoder.render_views_fused(ext, K, near, far, (face_w, face_w), bg, *[p.detach() for p in params], shared_campos=True, lean=False)
+        L_upstream = rasterizer.last_state().num_rendered()
 
     # ---- per-kernel durations: HIP events around every kernel group, recorded on the stream the kernels run on,
     # in a second pass of the same K steps (default) or inside the timed region itself (--events-in-timed-region 1)
@@ -402,22 +419,27 @@ def main():
         cfg_name = "BASELINE configs[4] single-rank shape" + (" (G = 2 context panoramas at 2048x1024)" if G == 1 << 22 else " (resolution-decoupled cloud)")
     else:
         cfg_name = "non-BASELINE size"
-    hbm_nominal = {"achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                   "note": f"{per_splat:.1f} B/splat (SURVEY 8d, {'fwd' if dom in FWD_KERNELS else 'bwd'} phase) x {G} splats / avg launch "
-                           f"{kernels[dom]['avg_us']:.1f} us of the dominant kernel group"}
-    if dom in VALU_BOUND:
-        # the composites are bound by VALU instruction issue, not by HBM or MFMA: their roofline is the issue rate.  achieved =
-        # wave64 VALU instructions per launch (SQ_INSTS_VALU of the hash-matched profile) / the launch time measured here
-        a_inst = None if valu_insts is None else valu_insts / dom_s / 1e9
-        roofline = {"bound": "valu", "kernel": dom, "achieved": a_inst, "peak": VALU_PEAK_GINST, "unit": "G wave64-inst/s",
-                    "frac": None if a_inst is None else a_inst / VALU_PEAK_GINST, "traffic": traffic,
-                    "valu_busy_frac": valu_busy, "valu_insts_per_launch": valu_insts, "hbm_nominal": hbm_nominal,
-                    "note": "dominant kernel group = an alpha composite: VALU-issue-bound (one wave64 instruction per 4 cycles per SIMD, "
-                            "1024 SIMDs, 2.4 GHz); hbm_nominal = the contract's algorithmic-bytes figure for the same launch, kept as a "
-                            "second number; see DESIGN.md section 4; " + pmc_note}
-    else:
-        roofline = {"bound": "hbm", "kernel": dom, **hbm_nominal, "traffic": traffic, "valu_busy_frac": valu_busy,
-                    "valu_insts_per_launch": valu_insts, "note": hbm_nominal["note"] + "; " + pmc_note}
+    # ---- roofline, exactly as the measurement contract defines it: ALGORITHMIC bytes of the dominant kernel's phase (SURVEY 8(d):
+    # 350.5 B/splat forward, 684.5 B/splat backward at this workload) x the splats one launch processes / that launch's duration
+    # (HIP events on the launch stream), against the 8 TB/s HBM peak.  frac_path = the whole step's algorithmic bytes / step time.
+    # The dominant kernels are alpha composites, whose own limit is VALU issue, so two VALU figures follow as extra keys:
+    # valu_issue_frac = EXECUTED wave64 VALU instructions / issue peak (rises if the kernel executes more instructions: a
+    # utilisation, not an efficiency) and valu_work_frac = the instructions the contributing (pixel, entry) pairs NEED
+    # (pairs x MIN_INST lane-slots / 64) / issue peak — executing more instructions cannot raise that one.
+    MIN_INST = {"render": 26, "render_bwd": 68}   # VALU issue slots per contributing pair (v_exp / v_rcp = 4 slots); DESIGN.md section 4
+    a_inst = None if valu_insts is None else valu_insts / dom_s / 1e9
+    work_inst = None if (n_contrib_pairs is None or dom not in MIN_INST) else n_contrib_pairs * views_per_step * MIN_INST[dom] / 64.0
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": traffic,
+                "frac_path": bytes_step / (dt / a.steps) / 1e9 / HBM_PEAK_GBPS,
+                "algorithmic_bytes_per_launch": per_splat * G, "launch_us": kernels[dom]["avg_us"],
+                "valu_issue_frac": None if a_inst is None else a_inst / VALU_PEAK_GINST, "valu_insts_per_launch": valu_insts,
+                "valu_work_frac": None if work_inst is None else work_inst / dom_s / 1e9 / VALU_PEAK_GINST,
+                "valu_work_insts_per_launch": work_inst, "contributing_pairs": n_contrib_pairs, "backward_evaluated_pairs": n_bwd_pairs,
+                "valu_peak_Ginst_per_s": VALU_PEAK_GINST, "valu_busy_frac": valu_busy,
+                "note": f"frac = {per_splat:.1f} B/splat (SURVEY 8d, {'fwd' if dom in FWD_KERNELS else 'bwd'} phase) x {G} splats / "
+                        f"{kernels[dom]['avg_us']:.1f} us (avg launch of the dominant kernel group, HIP events) / 8 TB/s; the group is an alpha "
+                        "composite, VALU-issue-bound (DESIGN.md section 4): valu_* are the figures against 1024 SIMDs x 2.4 GHz / 4; " + pmc_note}
     res = {
         "metric": f"Msplats/s {what} @{gm} Gaussians, {erp_w}x{erp_h} ERP",
         "value": value, "unit": "Msplats/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -433,7 +455,8 @@ def main():
                        f", RCCL chunked exchange inside the backward ({a.chunks} Gaussian ranges: all-reduce 40 B/G packed + all-gather dRGB 16 B/G/rank)" if chunked else
                        ", RCCL factored grad exchange (all-reduce 40 B/G packed + all-gather dRGB 16 B/G/rank" + (", overlapped with the next micro-batch's forward" if a.overlap_exchange else "") + ")" if factored else
                        ", RCCL all-reduce of Gaussian grads"),
-                   "num_rendered": L, "visible_pairs": visible_pairs},
+                   "num_rendered": L, "num_rendered_upstream_lists": L_upstream, "lean_over_upstream": L / max(L_upstream, 1),
+                   "visible_pairs": visible_pairs},
         "roofline": roofline,
         "path_roofline": {"bytes_per_step": bytes_step, "achieved_GBps": bytes_step / (dt / a.steps) / 1e9,
                           "frac_of_8TBps": bytes_step / (dt / a.steps) / 1e9 / HBM_PEAK_GBPS,
@@ -459,6 +482,64 @@ def main():
                 dec(gs, e18, k18, n18, f18, (face_w, face_w), depth_mode="depth")
             torch.cuda.synchronize(dev)
         res["per_face_dropin_ms_per_step"] = (time.perf_counter() - t0) / 3 * 1e3
+    if world == 1 and a.mode == "fwdbwd" and a.workloads:
+        # ---- the same training step on two more clouds of the same size (every tuning decision of rounds 1-3 was taken on the
+        # encoder-like cloud alone): SURVEY 8(d)'s uniform-random stress cloud, and a surface-like cloud (what a trained encoder
+        # emits: spatially coherent depth, opacity >= 0.9 — the first surface hides most of what lies behind it)
+        k2 = max(3, min(a.steps, 10))
+        res["workloads"] = {}
+        for name, make in (("uniform_U[-5,5]^3", lambda: synthetic.uniform_cloud(G, seed=0, extent=5.0)),
+                           ("surface_like", lambda: synthetic.surface_like_cloud(pano_h, pano_w, n_context=2, seed=0))):
+            cur["params"], cur["check"] = to_params(make()), "sync"
+            step()                       # sizes the binning buffers (one synchronising call, re-rendered if the guess was short)
+            cur["check"] = "lazy"
+            for _ in range(2):
+                step()
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(k2):
+                step()
+            sync()
+            dtw = (time.perf_counter() - t1) / k2
+            stw = rasterizer.last_state()
+            _lib.profile_enable(True)     # per-kernel averages of this workload (second pass, HIP events, like the headline's)
+            for _ in range(k2):
+                step()
+            torch.cuda.synchronize(dev)
+            kw_us = {k: round(ms / n * 1e3, 1) for k, (ms, n) in _lib.profile_collect().items() if n}
+            _lib.profile_enable(False)
+            res["workloads"][name] = {"value": G / dtw / 1e6, "unit": "Msplats/s", "ms_per_step": dtw * 1e3, "steps": k2,
+                                      "num_rendered": stw.num_rendered(), "overflowed": stw.overflowed(),
+                                      "visible_pairs": int((stw.tensors()["tiles_touched"] > 0).sum().item()),
+                                      "finite": bool(torch.isfinite(out["faces"]).all()), "kernels_avg_us": kw_us}
+            cur["params"] = None
+            torch.cuda.empty_cache()
+        cur["params"], cur["check"] = params, "lazy"
+        # ---- the path a user of the UNCHANGED reference is on without splatter360_amd.install(): its own decoder loop — one drop-in
+        # `diff_gaussian_rasterization` call per face with the reference's torch camera glue and upstream's host synchronisation
+        # (decoder_splatting_cuda.py:47-59 -> cuda_splatting.py:47-127), torch L2 loss on the faces, backward
+        from types import SimpleNamespace
+        gs = SimpleNamespace(means=params[0][None], covariances=params[1][None], harmonics=params[2][None], opacities=params[3][None])
+        dec = decoder.DecoderSplattingCUDA().to(dev)
+
+        def step_dropin():
+            for p in params:
+                p.grad = None
+            colors = dec(gs, ext[None], K[None], near[None], far[None], (face_w, face_w)).color
+            ((colors[0] - gt) ** 2).mean().backward()
+
+        step_dropin()
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(3):
+            step_dropin()
+        torch.cuda.synchronize(dev)
+        dtd = (time.perf_counter() - t1) / 3
+        res["dropin_train"] = {"value": G / dtd / 1e6, "unit": "Msplats/s", "ms_per_step": dtd * 1e3, "steps": 3,
+                               "fused_over_dropin": dtd / (dt / a.steps),
+                               "what": "the same training step through the unchanged reference's decoder loop: six per-face drop-in rasteriser "
+                                       "calls (torch camera glue, host sync per call), torch L2 loss, backward — what a user gets without "
+                                       "splatter360_amd.install()"}
     if rank == 0 and world == 1 and a.cpu_baseline and a.mode != "eval":
         res["cpu_baseline"] = cpu_baseline(cloud, face_w, 0.1, 10.0, a.mode)
         try:

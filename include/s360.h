@@ -118,7 +118,8 @@ typedef struct S360Params {
  * for parity tests: upstream's geomBuffer / binningBuffer / imgBuffer). */
 typedef struct S360Layout {
     size_t total_bytes;         /* forward workspace size */
-    size_t header;              /* uint32[64]: [0]=num_instances [1]=overflow flag [2]=max tile list length */
+    size_t header;              /* uint32[64]: [0]=num_instances [1]=overflow flag [2]=max tile list length [3]=merge passes needed
+                                   [4]=pairs with more than 32 instance slots */
     size_t tiles_touched;       /* uint32[V*P] */
     size_t vis_mask;            /* uint8[P]  bit v set: Gaussian visible in view v (V <= 8).  tiles_touched is written for
                                    visible pairs only; the kernels test visibility on this byte, not on V words */
@@ -150,6 +151,8 @@ typedef struct S360Layout {
     size_t strip_last;          /* uint32[V*T*4] max n_contrib of each of the four 8x8 quadrants of a tile */
     size_t slot_pair;           /* uint32[max_instances] pair index p of every instance slot (training calls): lets the backward
                                    sum the per-(instance, quadrant) partial gradients slot-parallel */
+    size_t long_pairs;          /* uint32[max_instances/32 + 1]  training calls: the pairs that own more than 32 instance slots
+                                   (header[4] of them, in no particular order): the backward sums their slots wave-parallel */
     size_t rgbc;                /* float4[P]  SH colour of every Gaussian (r, g, b, clamp bits) when the views share a camera
                                    centre: evaluated once per call by a streaming kernel ahead of the geometry pass */
     size_t sh_jac;              /* float[P,3,3] d(rgb_c)/d(mean) through the view direction (training calls only): lets the
@@ -377,6 +380,11 @@ int s360_cube2erp_backward(const float* d_erp, const float* grid, float* d_faces
  * on those events and returns, per slot, the summed milliseconds and the number of launches since
  * the previous collect.  Arrays must hold s360_profile_slots() entries.
  */
+/* Second measurement aid: counts[0] = (pixel, list entry) pairs that contribute to the images rendered into a TRAINING workspace
+ * (alpha >= 1/255, in front of the pixel's last contributor), counts[1] = pairs the backward composite evaluates for them
+ * (survivor records in front of each 8x8 quadrant's last contributor x 64 pixels).  counts: DEVICE uint64[2], written
+ * asynchronously on `stream`.  bench.py derives the work-based VALU fraction of the composites from it. */
+int s360_count_contributions(const S360Params* prm, const void* workspace, size_t workspace_bytes, uint64_t* counts, void* stream);
 int s360_profile_slots(void);
 const char* s360_profile_slot_name(int slot);
 int s360_profile_enable(int on);

@@ -41,11 +41,11 @@ class S360Layout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in (
         "total_bytes", "header", "tiles_touched", "vis_mask", "slot_base", "rec_a", "rec_b", "rec_c",
         "clamped", "depths", "tile_count", "slot_ticket", "merge_done", "tile_start", "tile_cursor", "chunk_start", "tile_order", "keys", "keys_alt", "list", "final_T", "n_contrib",
-        "tile_max_contrib", "strip_last", "slot_pair", "rgbc", "sh_jac", "surv", "surv_count", "backward_bytes")]
+        "tile_max_contrib", "strip_last", "slot_pair", "long_pairs", "rgbc", "sh_jac", "surv", "surv_count", "backward_bytes")]
 
 
 EXPORTS = ("s360_abi_version", "s360_error_string", "s360_layout", "s360_forward", "s360_forward_depth", "s360_forward_mse", "s360_backward", "s360_backward_split", "s360_backward_composite", "s360_backward_gaussians", "s360_unpack_gradients", "s360_sh_backward", "s360_pack_views", "s360_adapter_forward", "s360_adapter_backward", "s360_sh_rotation_blocks",
-           "s360_cube2erp_forward", "s360_cube2erp_backward", "s360_profile_slots", "s360_profile_slot_name",
+           "s360_cube2erp_forward", "s360_cube2erp_backward", "s360_count_contributions", "s360_profile_slots", "s360_profile_slot_name",
            "s360_profile_enable", "s360_profile_collect")
 
 
@@ -166,6 +166,8 @@ def lib() -> C.CDLL:
     l.s360_cube2erp_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(C.c_int64), vp]
     l.s360_cube2erp_backward.restype = C.c_int
     l.s360_cube2erp_backward.argtypes = [vp, vp, vp, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(C.c_int64), vp]
+    l.s360_count_contributions.restype = C.c_int
+    l.s360_count_contributions.argtypes = [C.POINTER(S360Params), vp, sz, vp, vp]
     l.s360_profile_slot_name.restype = C.c_char_p
     l.s360_profile_slot_name.argtypes = [C.c_int]
     l.s360_profile_enable.argtypes = [C.c_int]

@@ -167,12 +167,51 @@ def adapter_tail(extrinsics: Tensor, depths: Tensor, opacities: Tensor, raw_gaus
     return AdapterGaussians(means, cov, scales, rots, harm, opacities)
 
 
+_E3NN_CHECKED: dict = {}     # (device, d_sh) -> True once the native matrices have been compared with e3nn's on this device
+
+
+def selfcheck_sh_rotation_against_e3nn(device, d_sh: int, tol: float = 2e-5) -> Optional[bool]:
+    """Where e3nn IS importable (a real training environment of the reference), compare s360_sh_rotation_blocks with the
+    reference's own construction (sh_rotation.py:19-24: e3nn.o3.wigner_D of matrix_to_angles) on a fixed set of probe
+    rotations, once per (device, d_sh), and RAISE on a mismatch: a wrong axis / sign convention in the natively built matrices
+    would corrupt every view-dependent colour of a real checkpoint while all synthetic tests stay green.  Returns True (checked,
+    equal), or None where e3nn is absent (this build image: the convention is then pinned by properties only)."""
+    key = (str(device), int(d_sh))
+    if key in _E3NN_CHECKED:
+        return _E3NN_CHECKED[key]
+    try:
+        import e3nn.o3  # noqa: F401, PLC0415
+    except Exception:
+        _E3NN_CHECKED[key] = None
+        return None
+    g = torch.Generator().manual_seed(360)
+    q = torch.randn(16, 4, generator=g)
+    q = q / q.norm(dim=-1, keepdim=True)
+    w, x, y, z = q.unbind(-1)
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                     2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                     2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], -1).reshape(16, 3, 3)
+    R = torch.cat([R, torch.eye(3)[None]])                     # identity included: D must be the identity
+    want = wigner_blocks_e3nn(R, d_sh).float()
+    got = sh_rotation_blocks(R.to(device), d_sh).float().cpu()
+    err = (got - want).abs().max().item()
+    if not err <= tol:
+        raise RuntimeError(
+            f"splatter360_amd: the natively built SH rotation matrices differ from e3nn's wigner_D by {err:.3e} (> {tol}) — the "
+            "restated e3nn convention is wrong for this e3nn version.  Construct GaussianAdapterERP(..., sh_rotation='e3nn') to use the "
+            "reference's own construction and report this.")
+    _E3NN_CHECKED[key] = True
+    return True
+
+
 class GaussianAdapterERP(torch.nn.Module):
     """Drop-in for the reference module (gaussian_adapter_erp.py:31-137): same constructor fields and forward
     arguments (dataset_name, extrinsics[b,v,1,1,1,4,4], depths[b,v,r,srf,spp], opacities, raw_gaussians[b,v,r,srf,1,c],
     image_shape), same result container with the reference's shapes.  `sh_rotation`: "native" (default: the matrices of
     rotate_sh from s360_sh_rotation_blocks), "e3nn" (wigner_blocks_e3nn: the reference's own construction, needs e3nn),
-    "identity", or a callable c2w_rotations[V,3,3] -> [V,d_sh,d_sh].  GPU tensors only.  differentiable_means: see
+    "identity", or a callable c2w_rotations[V,3,3] -> [V,d_sh,d_sh].  With "native", the first forward on a device compares the
+    native matrices with e3nn's on 17 probe rotations WHEN e3nn is importable and raises on a mismatch
+    (selfcheck_sh_rotation_against_e3nn).  GPU tensors only.  differentiable_means: see
     adapter_tail (default False = the reference's detached means)."""
 
     def __init__(self, gaussian_scale_min: float, gaussian_scale_max: float, sh_degree: int, sh_rotation="native",
@@ -204,6 +243,7 @@ class GaussianAdapterERP(torch.nn.Module):
         if self.sh_rotation == "identity":
             rot = None
         elif self.sh_rotation == "native":
+            selfcheck_sh_rotation_against_e3nn(ext.device, self.d_sh)      # once per device; a no-op where e3nn is absent
             rot = sh_rotation_blocks(ext, self.d_sh)
         elif self.sh_rotation == "e3nn":
             rot = wigner_blocks_e3nn(ext[:, :3, :3], self.d_sh)

@@ -49,46 +49,92 @@ __device__ __forceinline__ void slot_sum(const float4* __restrict__ part, const 
     }
 }
 
+// Pairs with more than 32 instance slots (footprints of more than 32 tiles: splats close to the camera) are NOT summed by their
+// owner thread — a serial chain of up to a whole image's tiles, 375 us of this kernel on the uniform stress cloud whose nearest
+// splats cover 256 tiles — but by a whole wave in a second phase of the same launch: lane l adds slots l, l + 64, ... of the
+// pair (rectangle order), then a fixed shuffle tree.  k_emit lists those pairs (header[4] of them, any order: each pair's sum is
+// self-contained, so the result is deterministic).  Rectangles beyond 32 tiles are binned whole in either list mode, so these
+// sums are the same with lean and with upstream-compatible lists.
+constexpr uint32_t LONG_PAIR_SLOTS = 32;
 __global__ __launch_bounds__(S360_BLOCK) void k_gather_slots(uint32_t cap, const uint32_t* __restrict__ header,
                                                             const uint32_t* __restrict__ slot_pair, const float4* __restrict__ part,
-                                                            const uint32_t* __restrict__ valid_words, float4* __restrict__ pairgrad) {
+                                                            const uint32_t* __restrict__ valid_words, float4* __restrict__ pairgrad,
+                                                            const uint32_t* __restrict__ long_pairs, const uint2* __restrict__ slot_info,
+                                                            const uint32_t* __restrict__ tiles_touched) {
     __shared__ float s_val[S360_BLOCK][11];  // 11: odd stride, conflict-free column access
     __shared__ uint32_t s_pair[S360_BLOCK];
     const uint32_t L = min(header[0], cap);
     const uint32_t i0 = blockIdx.x * S360_BLOCK;
-    if (i0 >= L) return;
     const int tid = threadIdx.x;
-    const uint32_t i = i0 + tid;
-    float s[10];
-    uint32_t p = 0xFFFFFFFFu;
-    if (i < L) {
-        p = slot_pair[i];
-        slot_sum(part, valid_words, i, s);
+    if (i0 < L) {   // block-uniform
+        const uint32_t i = i0 + tid;
+        float s[10];
+        uint32_t p = 0xFFFFFFFFu;
+        if (i < L) {
+            p = slot_pair[i];
+            slot_sum(part, valid_words, i, s);
 #pragma unroll
-        for (int k = 0; k < 10; ++k) s_val[tid][k] = s[k];
-    }
-    s_pair[tid] = p;
-    __syncthreads();
-    if (i >= L) return;
-    const bool owner = tid == 0 ? (i == 0 || slot_pair[i - 1] != p) : s_pair[tid - 1] != p;
-    if (!owner) return;
-    for (uint32_t j = i + 1; j < L; ++j) {  // the pair's remaining slots, in slot order
-        const uint32_t tj = j - i0;
-        float t[10];
-        if (tj < S360_BLOCK) {
-            if (s_pair[tj] != p) break;
-#pragma unroll
-            for (int k = 0; k < 10; ++k) t[k] = s_val[tj][k];
-        } else {
-            if (slot_pair[j] != p) break;
-            slot_sum(part, valid_words, j, t);
+            for (int k = 0; k < 10; ++k) s_val[tid][k] = s[k];
         }
+        s_pair[tid] = p;
+        __syncthreads();
+        bool owner = i < L && (tid == 0 ? (i == 0 || slot_pair[i - 1] != p) : s_pair[tid - 1] != p);
+        if (owner) {
+            for (uint32_t j = i + 1; j < L; ++j) {  // the pair's remaining slots, in slot order
+                const uint32_t tj = j - i0;
+                if ((tj < S360_BLOCK ? s_pair[tj] : slot_pair[j]) != p) break;
+                if (j - i >= LONG_PAIR_SLOTS) {     // a 33rd slot: this pair is left to the wave-parallel phase below
+                    owner = false;
+                    break;
+                }
+                float t[10];
+                if (tj < S360_BLOCK) {
 #pragma unroll
-        for (int k = 0; k < 10; ++k) s[k] += t[k];
+                    for (int k = 0; k < 10; ++k) t[k] = s_val[tj][k];
+                } else {
+                    slot_sum(part, valid_words, j, t);
+                }
+#pragma unroll
+                for (int k = 0; k < 10; ++k) s[k] += t[k];
+            }
+        }
+        if (owner) {
+            pairgrad[(size_t)p * 3] = make_float4(s[0], s[1], s[2], s[3]);
+            pairgrad[(size_t)p * 3 + 1] = make_float4(s[4], s[5], s[6], s[7]);
+            pairgrad[(size_t)p * 3 + 2] = make_float4(s[8], s[9], 0.f, 0.f);
+        }
     }
-    pairgrad[(size_t)p * 3] = make_float4(s[0], s[1], s[2], s[3]);
-    pairgrad[(size_t)p * 3 + 1] = make_float4(s[4], s[5], s[6], s[7]);
-    pairgrad[(size_t)p * 3 + 2] = make_float4(s[8], s[9], 0.f, 0.f);
+    // ---- phase 2: the long pairs, one wave each
+    const uint32_t n_long = min(header[4], cap / LONG_PAIR_SLOTS + 1u);
+    const int lane = tid & 63, wave = tid >> 6;
+    for (uint32_t k = blockIdx.x * (S360_BLOCK / 64) + wave; k < n_long; k += gridDim.x * (S360_BLOCK / 64)) {
+        const uint32_t p = long_pairs[k];
+        const uint32_t base = slot_info[p].x, n = tiles_touched[p];
+        // 64 slots at a time: the loads (the latency) in parallel, one slot per lane; the ADDS stay the owner thread's serial
+        // left fold in slot order, fed by v_readlane — bit-identical to the single-thread sum (a float32 shuffle tree, and even a
+        // float64 one, moved one fuzz scene's means2D error from below 5e-4 to 5.9e-4 of the largest gradient: the centre sums of
+        // a large elongated splat cancel across its tiles, and the tests' bar was set with the serial order)
+        float s[10];
+#pragma unroll
+        for (int q = 0; q < 10; ++q) s[q] = 0.f;
+        for (uint32_t j0 = 0; j0 < n; j0 += 64) {
+            float t[10];
+#pragma unroll
+            for (int q = 0; q < 10; ++q) t[q] = 0.f;
+            const uint32_t j = j0 + (uint32_t)lane;
+            if (j < n && base + j < L) slot_sum(part, valid_words, base + j, t);
+            const int m = (int)min(64u, n - j0);
+            for (int l = 0; l < m; ++l) {
+#pragma unroll
+                for (int q = 0; q < 10; ++q) s[q] += rl(t[q], l);
+            }
+        }
+        if (lane == 0) {
+            pairgrad[(size_t)p * 3] = make_float4(s[0], s[1], s[2], s[3]);
+            pairgrad[(size_t)p * 3 + 1] = make_float4(s[4], s[5], s[6], s[7]);
+            pairgrad[(size_t)p * 3 + 2] = make_float4(s[8], s[9], 0.f, 0.f);
+        }
+    }
 }
 
 // SH_PASS = true : SH backward inside this kernel (slab through LDS; required when the views have different
@@ -600,7 +646,8 @@ static int backward_composite(const BwdCtx& c, const S360View* views, const void
     S360_CHECK_LAUNCH();
     ProfScope ps(PS_GATHER, st);
     hipLaunchKernelGGL(k_gather_slots, dim3((unsigned)(((size_t)kp.cap + S360_BLOCK - 1) / S360_BLOCK)), dim3(S360_BLOCK), 0, st,
-                       kp.cap, header, (const uint32_t*)(ws + L.slot_pair), c.part, c.valid_words, c.pairgrad);
+                       kp.cap, header, (const uint32_t*)(ws + L.slot_pair), c.part, c.valid_words, c.pairgrad,
+                       (const uint32_t*)(ws + L.long_pairs), (const uint2*)(ws + L.slot_base), (const uint32_t*)(ws + L.tiles_touched));
     S360_CHECK_LAUNCH();
     return S360_OK;
 }
@@ -760,6 +807,52 @@ extern "C" int s360_backward_gaussians(const S360Params* prm, const S360View* vi
 }
 
 namespace s360 {
+// Measurement aid (no reference counterpart): how many (pixel, list entry) pairs actually CONTRIBUTE to the rendered images of a
+// training workspace — alpha >= 1/255, in front of the pixel's last contributor: what the composites' arithmetic is for.  One
+// wave per (tile, quadrant) replays the forward's survivor records with the forward's own accept test.  out[0] += contributing
+// pairs, out[1] += pairs the backward composite evaluates (survivor records in front of the quadrant's last contributor x 64
+// pixels), out[2] += survivor records (all).  bench.py turns these into the work-based VALU figure next to the issue-rate one.
+__global__ __launch_bounds__(64) void k_count_pairs(KParams kp, const uint32_t* __restrict__ tile_start, const float4* __restrict__ surv,
+                                                   const uint32_t* __restrict__ surv_count, const uint32_t* __restrict__ n_contrib,
+                                                   unsigned long long* __restrict__ out) {
+    __shared__ uint32_t s_last[64];
+    const uint32_t unit = blockIdx.x;
+    const uint32_t n_surv = surv_count[unit];
+    const int t = (int)(unit >> 2), wave = (int)(unit & 3u), lane = threadIdx.x;
+    const int v = t / kp.T, rem = t - v * kp.T;
+    const int ty = rem / kp.gx, tx = rem - ty * kp.gx;
+    const int qx = tx * 16 + sub_ox(wave), qy = ty * 16 + sub_oy(wave);
+    const uint32_t start = min(tile_start[t], kp.cap), end = min(tile_start[t + 1], kp.cap);
+    const float4* const sv = surv + 3 * ((size_t)4 * start + (size_t)wave * (end - start));
+    {
+        const int px = qx + (lane & 7), py = qy + (lane >> 3);
+        s_last[lane] = (px < kp.W && py < kp.H) ? n_contrib[((size_t)v * kp.H + py) * kp.W + px] : 0u;
+    }
+    __syncthreads();
+    uint32_t cnt = 0;
+    for (uint32_t g0 = 0; g0 < n_surv; g0 += 64) {
+        const bool ok = g0 + lane < n_surv;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, c = a;
+        if (ok) {
+            const float4* r = sv + 3 * (size_t)(g0 + lane);
+            a = r[0]; b = r[1]; c = r[2];
+        }
+        const uint32_t pos = ok ? __float_as_uint(c.z) : 0xFFFFFFFFu;
+        for (int p = 0; p < 64; ++p) {
+            const float dx = a.x - (float)(qx + (p & 7)), dy = a.y - (float)(qy + (p >> 3));
+            const float power = power2(a.z, a.w, b.x, dx, dy);
+            const float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(power));
+            cnt += (pos < s_last[p] && !(power > 0.0f) && !(alpha < 1.0f / 255.0f)) ? 1u : 0u;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, o);
+    if (lane == 0) {
+        atomicAdd(&out[0], (unsigned long long)cnt);
+        atomicAdd(&out[1], (unsigned long long)n_surv * 64ull);
+    }
+}
+
 // [P,10] packed gradients (3 mean + 6 unique covariance entries + 1 opacity) -> the three tensors of the reference's layouts
 __global__ __launch_bounds__(S360_BLOCK) void k_unpack_gradients(const float* __restrict__ packed, int P, int cov9,
                                                                  float* __restrict__ d_means, float* __restrict__ d_cov,
@@ -787,6 +880,28 @@ extern "C" int s360_unpack_gradients(const float* packed, int32_t P, int32_t cov
     if (P == 0) return S360_OK;
     hipLaunchKernelGGL(s360::k_unpack_gradients, dim3((P + S360_BLOCK - 1) / S360_BLOCK), dim3(S360_BLOCK), 0, (hipStream_t)stream_,
                        packed, P, cov9, d_means3D, d_cov, d_opacities);
+    S360_CHECK_LAUNCH();
+    return S360_OK;
+}
+
+extern "C" int s360_count_contributions(const S360Params* prm, const void* workspace, size_t workspace_bytes, uint64_t* counts, void* stream_) {
+    if (!prm || !workspace || !counts) return S360_E_BADARG;
+    if (prm->flags & S360_FLAG_FORWARD_ONLY) return S360_E_BADARG;   // survivor records exist in training workspaces only
+    S360Layout L;
+    const int rc = s360_layout(prm, &L);
+    if (rc) return rc;
+    if (workspace_bytes < L.total_bytes) return S360_E_WORKSPACE;
+    KParams kp;
+    kp.P = prm->P; kp.V = prm->V; kp.H = prm->H; kp.W = prm->W; kp.deg = s360_effective_degree(prm); kp.M = prm->M;
+    kp.gx = (prm->W + 15) / 16; kp.gy = (prm->H + 15) / 16; kp.T = kp.gx * kp.gy;
+    kp.flags = prm->flags; kp.cap = prm->max_instances;
+    const int nt = ((kp.flags & S360_FLAG_SPHERICAL) ? kp.V / 2 : kp.V) * kp.T;
+    const char* ws = (const char*)workspace;
+    hipStream_t st = (hipStream_t)stream_;
+    if (hipMemsetAsync(counts, 0, 2 * sizeof(uint64_t), st) != hipSuccess) return S360_E_LAUNCH;
+    if (prm->P == 0) return S360_OK;
+    hipLaunchKernelGGL(s360::k_count_pairs, dim3(nt * 4), dim3(64), 0, st, kp, (const uint32_t*)(ws + L.tile_start), (const float4*)(ws + L.surv),
+                       (const uint32_t*)(ws + L.surv_count), (const uint32_t*)(ws + L.n_contrib), (unsigned long long*)counts);
     S360_CHECK_LAUNCH();
     return S360_OK;
 }

@@ -361,6 +361,37 @@ __device__ __forceinline__ bool quadrant_hit(float x, float y, float a, float b,
     return box_hit<SUB_W, SUB_H>(x, y, a, b, c, op, ka, kb, x0, y0);
 }
 
+// The same test against a box given at run time: origin (x0, y0) and extent (w1, h1) = (columns - 1, rows - 1) in pixels.  With
+// the full quadrant, (x0, y0, 7, 7), it is quadrant_hit() operation for operation.  k_render culls every chunk against the
+// bounding box of the pixels of its quadrant that are still UNSATURATED: an entry that fails it is below 1/255 on every pixel that
+// can still take a contribution, so neither the forward nor the backward (whose survivor records these are) loses anything.
+__device__ __forceinline__ bool box_hit_rt(float x, float y, float a, float b, float c, float op, float ka, float kb,
+                                           float x0, float y0, float w1, float h1) {
+    const float dh = x - x0, dl = dh - w1;
+    const float eh = y - y0, el = eh - h1;
+    const float dx1 = __builtin_amdgcn_fmed3f(0.0f, dl, dh);
+    const float dy1 = __builtin_amdgcn_fmed3f(0.0f, el, eh);
+    const float dys = __builtin_amdgcn_fmed3f(kb * dx1, el, eh);
+    const float dxs = __builtin_amdgcn_fmed3f(ka * dy1, dl, dh);
+    const float pmax = fmaxf(power2(a, b, c, dx1, dys), power2(a, b, c, dxs, dy1));
+    return pmax + __builtin_amdgcn_logf(op) + (7.994353436858858f + 0.02f) >= 0.0f;
+}
+
+// Bounding box of the set bits of an 8x8 quadrant mask (lane = 8 * row + column): scalar bit tricks, no vector work.
+__device__ __forceinline__ void mask_bbox8(unsigned long long m, int& c0, int& c1, int& r0, int& r1) {
+    uint32_t cols = (uint32_t)(m | (m >> 32));
+    cols |= cols >> 16;
+    cols |= cols >> 8;
+    cols &= 0xFFu;                                   // bit c: some row has column c set
+    unsigned long long t = m | (m >> 4);
+    t |= t >> 2;
+    t |= t >> 1;
+    t &= 0x0101010101010101ull;                      // bit 8 r: row r is non-empty
+    const uint32_t rows = (uint32_t)((t * 0x0102040810204080ull) >> 56);
+    c0 = __builtin_ctz(cols); c1 = 31 - __builtin_clz(cols);
+    r0 = __builtin_ctz(rows); r1 = 31 - __builtin_clz(rows);
+}
+
 // The same test for a whole 16x16 tile — the binning-time cull of S360_FLAG_LEAN_LISTS (k_preprocess counts and k_emit
 // places a (Gaussian, tile) instance only when it passes; both evaluate THIS function on the stored record, so the
 // histogram and the emission agree).  lop = v_log_f32(opacity), hoisted by the caller.  The margin is twice the quadrants'

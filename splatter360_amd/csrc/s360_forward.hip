@@ -595,6 +595,7 @@ __global__ __launch_bounds__(TS_BLOCK) void k_tile_scan(const uint32_t* __restri
             const uint32_t nch = nmax > SORT_SHORT ? (nmax + SORT_CHUNK - 1) / SORT_CHUNK : 0u;
             header[3] = nch <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(nch - 1);
         }
+        header[4] = 0;                        // pairs with more than 32 instance slots (k_emit counts and lists them)
         for (int i = 8; i < 24; ++i) header[i] = 0;  // debug counters; [16, 24): deferred-loss hand-over (S360_HDR_LOSS), set by k_render
     }
 }
@@ -614,7 +615,8 @@ __global__ __launch_bounds__(S360_BLOCK) void k_emit(KParams kp, const uint32_t*
                                                     const float* __restrict__ depths, const uint32_t* __restrict__ tile_start,
                                                     uint32_t* __restrict__ tile_cursor, uint64_t* __restrict__ keys,
                                                     uint2* __restrict__ slot_info, uint32_t* __restrict__ slot_pair,
-                                                    uint32_t* __restrict__ slot_ticket) {
+                                                    uint32_t* __restrict__ slot_ticket, uint32_t* __restrict__ header,
+                                                    uint32_t* __restrict__ long_pairs) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_bin[];  // [T] counts/cursors, [T] bases
     __shared__ uint32_t s_scan[S360_BLOCK / 64];
     __shared__ uint32_t s_slot0;
@@ -725,6 +727,10 @@ __global__ __launch_bounds__(S360_BLOCK) void k_emit(KParams kp, const uint32_t*
         if (slot_pair) {
             slot = sl[j] + s_slot0;
             slot_info[p].x = slot;
+            if (tt[j] > 32u) {   // more than 32 slots: summed by a whole wave in the backward (k_gather_slots, second phase)
+                const uint32_t k = atomicAdd(&header[4], 1u);
+                if (k < kp.cap / 32u + 1u) long_pairs[k] = p;
+            }
         }
         uint32_t m = hm[j];
         for (int y = miny; y < maxy; ++y)
@@ -1162,6 +1168,8 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
     // otherwise form the tail of the kernel): 249 -> 224 us.  (Single-wave workgroups per (tile, quadrant), as in
     // the backward, bring nothing more here: 229 us.)
     const int t = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;
+    // (s_setprio by launch-order quartile — the longest lists take the SIMD's issue slots first, all 6 144 waves being resident at
+    // once — measured no change: 141.5 vs 141.8 us; the slowest waves are ordinary tiles whose pixels never saturate.)
     const int v = t / kp.T, rem = t - v * kp.T;
     const int ty = rem / kp.gx, tx = rem - ty * kp.gx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1201,7 +1209,8 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
         if (WITH_DEPTH) nz = depths[p_n1];
     }
     for (uint32_t b = start; b < end; b += 64) {
-        if (__ballot(!done) == 0ull) break;
+        const unsigned long long act = __ballot(!done);
+        if (act == 0ull) break;
         const float4 ea = na, eb = nb;
         // fused depth "colour" of this lane's entry: camera z in unscaled units, then the reference's mode
         float ez = 0.f;
@@ -1219,6 +1228,12 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
         }
         if (b + 128 + lane < end) p_n2 = list[b + 128 + lane];
 
+        // (Round 4 culled each chunk against the bounding box of the quadrant's still-unsaturated pixels instead — mask_bbox8 /
+        // box_hit_rt in s360_device.h — so that a clump of splats on already saturated pixels is dropped: on the surface-like
+        // cloud the backward went 445 -> 323 us (fewer survivor records), on the headline cloud forward +4 / backward -8 us.  Not
+        // kept: the unsaturated set at a chunk's start depends on where the chunk boundaries fall, i.e. on the list mode, so the
+        // survivor records — and with them the rounding of the backward's scans — were no longer identical between the lean
+        // and the upstream-compatible lists.)
         const bool hit = ev && quadrant_hit(ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, eka, ekb, x0, ys0);
         unsigned long long m = __ballot(hit);
 #ifdef S360_DBG_COUNT
@@ -1236,7 +1251,6 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
             o[1] = eb;
             o[2] = make_float4(ec, erad, __uint_as_float(rel + (uint32_t)lane), __uint_as_float(epair));
         }
-        const unsigned long long act = __ballot(!done);
         if (__popcll(act) > SPARSE_PIXELS) {
             // Survivors are COMPACTED into the wave's LDS slice (rank = prefix count of the cull ballot) and padded with
             // null records (opacity 0 => alpha 0 => rejected like any other miss) to a multiple of four, so the loop below is
@@ -1430,6 +1444,7 @@ extern "C" int s360_layout(const S360Params* prm, S360Layout* out) {
     const size_t nt = (size_t)prm->V * gx * gy;
     const size_t cap = prm->max_instances ? prm->max_instances : 1;
     const size_t npix = (size_t)prm->V * prm->H * prm->W;
+    const bool fwd_only = (prm->flags & S360_FLAG_FORWARD_ONLY) != 0;  // inference calls keep no backward state
     size_t o = 0;
     auto take = [&](size_t bytes) {
         size_t r = o;
@@ -1460,9 +1475,9 @@ extern "C" int s360_layout(const S360Params* prm, S360Layout* out) {
     out->tile_max_contrib = take(nt * 4);
     out->strip_last = take(nt * 4 * 4);
     out->slot_pair = take(cap * 4);
+    out->long_pairs = take(fwd_only ? 16 : (cap / 32 + 1) * 4);
     out->rgbc = take((size_t)(prm->P > 0 ? prm->P : 1) * 16);
     out->sh_jac = take((size_t)(prm->P > 0 ? prm->P : 1) * 36);
-    const bool fwd_only = (prm->flags & S360_FLAG_FORWARD_ONLY) != 0;  // inference calls keep no survivor records
     out->surv = take(fwd_only ? 16 : cap * 4 * 48);
     out->surv_count = take(nt * 4 * 4);
     out->total_bytes = o;
@@ -1605,10 +1620,10 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
         ProfScope ps(PS_EMIT, st);
         if ((size_t)kp.T * 8 <= 64 * 1024)
             hipLaunchKernelGGL(k_emit<true>, egrid, dim3(S360_BLOCK), (size_t)kp.T * 8, st, kp, tiles_touched, vis_mask, recA, recC,
-                               depths, tile_start, tile_cursor, keys, slot_info, slot_pair, slot_ticket);
+                               depths, tile_start, tile_cursor, keys, slot_info, slot_pair, slot_ticket, header, (uint32_t*)(ws + L.long_pairs));
         else
             hipLaunchKernelGGL(k_emit<false>, egrid, dim3(S360_BLOCK), 0, st, kp, tiles_touched, vis_mask, recA, recC, depths, tile_start,
-                               tile_cursor, keys, slot_info, slot_pair, slot_ticket);
+                               tile_cursor, keys, slot_info, slot_pair, slot_ticket, header, (uint32_t*)(ws + L.long_pairs));
         }
         S360_CHECK_LAUNCH();
         ProfScope ps(PS_SORT, st);

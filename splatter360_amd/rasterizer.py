@@ -193,6 +193,17 @@ class RasterState:
         _CAPACITY_HINT[key] = max(n, _CAPACITY_HINT.get(key, 0))    # running maximum: sizes later calls (default_capacity)
         return n, over
 
+    def count_contributions(self):
+        """(contributing (pixel, entry) pairs, pairs the backward composite evaluates): s360_count_contributions on this training
+        workspace (host read; a measurement aid, see include/s360.h)."""
+        out = torch.zeros(2, dtype=torch.int64, device=self.workspace.device)
+        with torch.cuda.device(self.workspace.device):
+            stream = C.c_void_p(torch.cuda.current_stream(self.workspace.device).cuda_stream)
+            _lib.check(_lib.lib().s360_count_contributions(C.byref(self.prm), _ptr(self.workspace), self.layout.total_bytes, _ptr(out), stream),
+                       "s360_count_contributions")
+        a, b = out.cpu().tolist()
+        return int(a), int(b)
+
     def num_rendered(self) -> int:
         """Host read of num_instances (synchronises)."""
         return self._read_header()[0]

@@ -73,6 +73,37 @@ def encoder_like_cloud(pano_h: int = 512, pano_w: int = 1024, n_context: int = 2
                 opacities=opac.astype(f))
 
 
+def surface_like_cloud(pano_h: int = 512, pano_w: int = 1024, n_context: int = 2, d_sh: int = 25, seed: int = 0) -> dict:
+    """What a TRAINED encoder emits rather than a random one (cf. /root/reference/src/model/encoder/encoder_costvolume.py:490-507:
+    per-pixel depth from a cost volume, opacity from the matching confidence): a spatially coherent depth field per context
+    panorama — a few low-frequency waves over (theta, phi) in log depth, 1.2 ... 6 units — with a little per-pixel noise, opacity
+    >= 0.9, footprints of about one to two context pixels.  Same layouts and SH statistics as encoder_like_cloud.  The second
+    context panorama sees (mostly) the same surface from 0.8 units away, so most of its Gaussians are hidden behind the first's:
+    long lists, early saturation."""
+    rng = np.random.default_rng(seed)
+    centres = [np.array([-0.4, 0.0, 0.1]), np.array([0.4, 0.0, -0.1]), np.array([0.0, 0.3, 0.4]), np.array([0.1, -0.3, -0.4])]
+    dirs = erp_ray_directions(pano_h, pano_w).reshape(-1, 3)
+    n = dirs.shape[0]
+    theta = np.arctan2(dirs[:, 0], dirs[:, 2])
+    phi = np.arcsin(np.clip(dirs[:, 1], -1, 1))
+    means, covs = [], []
+    for c in range(n_context):
+        logd = math.log(2.7) + 0.45 * np.sin(2 * theta + 0.3 * c) * np.cos(phi) + 0.25 * np.cos(3 * theta - phi) + 0.12 * np.sin(5 * phi + c)
+        depth = np.exp(logd + 0.01 * rng.standard_normal(n))
+        means.append(centres[c % 4] + dirs * depth[:, None])
+        s = (0.8 + 1.7 / (1 + np.exp(-rng.standard_normal((n, 3))))) * depth[:, None] * (math.pi / pano_h) * 0.5
+        r = _random_rotations(rng, n)
+        covs.append(np.einsum("nij,nj,nkj->nik", r, s * s, r))
+    means = np.concatenate(means)
+    covs = np.concatenate(covs)
+    g = means.shape[0]
+    sh = rng.standard_normal((g, 3, d_sh)) * sh_band_mask(d_sh)
+    sh[:, :, 0] = sh[:, :, 0] * 0.6
+    opac = rng.uniform(0.9, 0.99, g)
+    f = np.float32
+    return dict(means=means.astype(f), covariances=covs.astype(f), harmonics=sh.astype(f), opacities=opac.astype(f))
+
+
 def uniform_cloud(g: int, d_sh: int = 25, seed: int = 0, extent: float = 5.0,
                   scale_range=(0.01, 0.15)) -> dict:
     """Stress / small-test variant: means U[-extent,extent]^3, log-uniform scales."""

@@ -247,3 +247,24 @@ def test_lean_overflow_is_flagged_and_resized(gpu):
     # sync: re-rendered with the exact size, identical result
     again = _fused(params, cams, 128, gpu, True, max_instances=max(1024, L // 3))
     _fused_equal(full, again)
+
+
+def test_large_footprint_pairs_are_gathered_wave_parallel_and_agree_with_the_oracle(gpu):
+    """Pairs with more than 32 instance slots take k_gather_slots' second phase (a wave per pair, lane-strided sums + a fixed
+    shuffle tree instead of the owner thread's serial chain): gradients against the float64 oracle, run-to-run bit-identical, and
+    the same in both list modes (rectangles beyond 32 tiles are binned whole either way)."""
+    from oracle import oracle
+    S, means, cov6, shs, opac = small_front_scene(n=60, seed=12, h=176, w=160, srange=(0.4, 3.0), zrange=(2.5, 5.0))
+    gimg = np.random.default_rng(12).standard_normal((3, 176, 160)).astype(np.float32)
+    runs = [_dropin(S, means, cov6, shs, opac, gpu, lean, gimg) for lean in (True, True, False)]
+    assert int((runs[0]["t"]["tiles_touched"] > 32).sum()) > 20
+    _equal_all(runs[0], runs[1])
+    _equal_all(runs[0], runs[2])
+    o64 = oracle.rasterize(S, means3D=means, cov3D_precomp=cov6, opacities=opac, shs=shs, dtype=np.float64)
+    o64.forward()
+    g64 = o64.backward(gimg)
+    got = dict(zip(("means3D", "means2D", "cov3D", "opacities", "shs"), runs[0]["grads"]))
+    for k in ("means3D", "cov3D", "opacities", "shs"):
+        w = np.asarray(g64[k], np.float64).reshape(-1)
+        e = np.abs(got[k].cpu().numpy().astype(np.float64).reshape(-1) - w).max() / (np.abs(w).max() + 1e-30)
+        assert e <= 2e-4, (k, e)
