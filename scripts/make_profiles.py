@@ -2,7 +2,7 @@
 import collections, csv, glob, json, os, shutil, subprocess, sys
 from pathlib import Path
 R = Path(__file__).resolve().parent.parent
-ROUND = os.environ.get("ROUND", "r03")
+ROUND = os.environ.get("ROUND", "r04")
 O = R / "gpurun_out" / ROUND
 P = R / "profiles"
 P.mkdir(exist_ok=True)
@@ -47,6 +47,9 @@ meta = json.loads((O / "meta.json").read_text())   # kernel-source hash + worklo
 meta.update(pm.get("_meta", {}))
 meta["round"] = ROUND
 pm["_meta"] = meta
+for n in ("bwd_unit_timing.txt", "fwd_unit_timing_encoder_like.txt", "fwd_unit_timing_surface_like.txt"):
+    if (O / n).exists():
+        shutil.copy(O / n, P / f"{ROUND}_{n}")
 calib = R / "gpurun_out" / "calib" / "calibration.json"
 if calib.exists():
     shutil.copy(calib, P / "fetch_write_calibration.json")
