@@ -78,6 +78,8 @@ def parse():
                     help="fwdbwd mode: 1 (default) = K more forward-only steps after the timed region, reported as `forward_only` "
                          "(BASELINE configs[1]); 0 = skip them (the rocprofv3 passes of scripts/collect_profiles.sh: per-kernel averages "
                          "then hold the training form of every kernel only)")
+    ap.add_argument("--atomic-grads", type=int, default=0, help="1: S360_FLAG_ATOMIC_GRADS (float32 atomics in the backward composite instead of the "
+                    "deterministic partial-record gather; opt-in, not the headline configuration)")
     ap.add_argument("--workloads", type=int, default=1,
                     help="fwdbwd, 1 GPU: 1 (default) = after the headline measurement, time the same step on two more clouds of the same size "
                          "(SURVEY 8(d)'s uniform-random stress cloud and a surface-like cloud: coherent depth, opacity >= 0.9) and the "
@@ -188,6 +190,7 @@ def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(a)      # does not return
+    rasterizer.ATOMIC_GRADS = bool(a.atomic_grads)
     rank, local_rank, world = distributed.init()
     if a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} but the launcher started {world} rank(s)")
@@ -448,7 +451,8 @@ def main():
         "config": {"workload": f"{cfg_name}: {G} encoder-like synthetic Gaussians (seed 0, deg-4 SH, from {a.n_context if hasattr(a, 'n_context') else 2} "
                                f"context panoramas {pano_w}x{pano_h}), {erp_w}x{erp_h} ERP = 6 faces {face_w}x{face_w} + stitch, {a.mode}"
                                + (", L2 loss on faces" + (" (fused epilogue" + (", scalar reduced in the backward's first launch)" if a.defer_loss else ")") if a.fused_loss else "") if a.mode == "fwdbwd" else "")
-                               + (", lean tile lists" if rasterizer.LEAN_LISTS else ", upstream-compatible tile lists"),
+                               + (", lean tile lists" if rasterizer.LEAN_LISTS else ", upstream-compatible tile lists")
+                               + (", ATOMIC gradient accumulation (opt-in, non-deterministic)" if rasterizer.ATOMIC_GRADS and a.mode == "fwdbwd" else ""),
                    "gaussians": G, "erp": [erp_w, erp_h], "face": face_w, "views_per_gpu": views_per_step,
                    "parallelism": f"view-sharded x{world}" + (
                        "" if not (world > 1 and a.mode == "fwdbwd") else

@@ -93,6 +93,14 @@ enum {
                                          allocated until then; loss_out holds the loss only after that backward.  For training loops
                                          that read the scalar after the backward (logging) — one launch less per step. */
 
+#define S360_FLAG_ATOMIC_GRADS 256u     /* opt-in, training calls: the backward composite adds its per-(entry, quadrant) sums straight
+                                         into the pair's raster-gradient record with return-less float32 atomics instead of leaving
+                                         one partial record per (instance slot, quadrant) for a deterministic gather.  No partial
+                                         slots, no validity flags, no gather launch: s360_layout's backward_bytes drops from
+                                         ~256 B per instance of capacity to 48 B per (view, Gaussian) pair.  The summation ORDER is
+                                         then run-dependent: gradients are NOT bit-reproducible (upstream's backward is atomic and
+                                         non-deterministic too).  Default (flag clear): no float atomics anywhere. */
+
 typedef struct S360View {
     float viewmatrix[16];
     float projmatrix[16];

@@ -28,6 +28,7 @@ FLAG_SH_DEG4_IGNORED = 16
 FLAG_SPHERICAL = 32
 FLAG_LEAN_LISTS = 64
 FLAG_DEFER_LOSS = 128
+FLAG_ATOMIC_GRADS = 256
 ABI_VERSION = 19
 
 

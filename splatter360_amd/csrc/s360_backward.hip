@@ -610,9 +610,15 @@ static int bwd_ctx(const S360Params* prm, const void* workspace, size_t workspac
     c.nt = (sph ? kp.V / 2 : kp.V) * kp.T;
     // backward scratch: [cap] x 4 quadrant partial records of 48 B, [cap] x 4 validity bytes, the launch order, one gathered
     // 48-byte record per pair, [P] summed dL/dRGB
-    c.part = (float4*)bwd_workspace;
-    c.valid_words = (uint32_t*)((char*)bwd_workspace + (size_t)kp.cap * 4 * GREC * 4);
-    c.order = c.valid_words + kp.cap;
+    if (kp.flags & S360_FLAG_ATOMIC_GRADS) {   // no partial slots, no validity flags: order table, then the pair records
+        c.part = nullptr;
+        c.valid_words = nullptr;
+        c.order = (uint32_t*)bwd_workspace;
+    } else {
+        c.part = (float4*)bwd_workspace;
+        c.valid_words = (uint32_t*)((char*)bwd_workspace + (size_t)kp.cap * 4 * GREC * 4);
+        c.order = c.valid_words + kp.cap;
+    }
     c.pairgrad = (float4*)((char*)(c.order + c.nt * 4) + 256 - ((uintptr_t)(c.order + c.nt * 4) & 255));
     return S360_OK;
 }
@@ -629,7 +635,8 @@ static int backward_composite(const BwdCtx& c, const S360View* views, const void
     const uint32_t* surv_count = (const uint32_t*)(ws + L.surv_count);  // per-unit replay length: also the work estimate
     {
         ProfScope ps(PS_ORDER, st);
-        hipLaunchKernelGGL(k_order_units, dim3(1 + 512), dim3(1024), 0, st, surv_count, c.order, c.nt * 4, c.valid_words, header, kp.cap);
+        hipLaunchKernelGGL(k_order_units, dim3(1 + 512), dim3(1024), 0, st, surv_count, c.order, c.nt * 4, c.valid_words, header, kp.cap,
+                           (kp.flags & S360_FLAG_ATOMIC_GRADS) ? c.pairgrad : (float4*)nullptr, (const uint8_t*)(ws + L.vis_mask), kp.P, kp.V);
     }
     {
         ProfScope ps(PS_RENDER_BWD, st);
@@ -637,6 +644,7 @@ static int backward_composite(const BwdCtx& c, const S360View* views, const void
                              surv_count, (const uint2*)(ws + L.slot_base), (const float*)(ws + L.depths),
                              (const float*)(ws + L.final_T), (const uint32_t*)(ws + L.n_contrib), dL_dimages, dL_dimages_scale,
                              dL_ddepth, c.part, (uint8_t*)c.valid_words, c.order, depth_mode,
+                             (kp.flags & S360_FLAG_ATOMIC_GRADS) ? (float*)c.pairgrad : (float*)nullptr,
 #ifdef S360_DBG_TIMING
                              (uint32_t*)(ws + L.keys_alt));  // the forward's merge buffer is free by now
 #else
@@ -644,6 +652,7 @@ static int backward_composite(const BwdCtx& c, const S360View* views, const void
 #endif
     }
     S360_CHECK_LAUNCH();
+    if (kp.flags & S360_FLAG_ATOMIC_GRADS) return S360_OK;   // the pair records are complete: nothing to gather
     ProfScope ps(PS_GATHER, st);
     hipLaunchKernelGGL(k_gather_slots, dim3((unsigned)(((size_t)kp.cap + S360_BLOCK - 1) / S360_BLOCK)), dim3(S360_BLOCK), 0, st,
                        kp.cap, header, (const uint32_t*)(ws + L.slot_pair), c.part, c.valid_words, c.pairgrad,

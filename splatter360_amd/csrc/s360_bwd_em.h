@@ -102,7 +102,8 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
     const float* __restrict__ depths, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dimages, const float* __restrict__ dL_dimages_scale, const float* __restrict__ dL_ddepth,
     float4* __restrict__ part,
-    uint8_t* __restrict__ valid, const uint32_t* __restrict__ order, int depth_mode, uint32_t* __restrict__ dbg) {
+    uint8_t* __restrict__ valid, const uint32_t* __restrict__ order, int depth_mode, float* __restrict__ pairgrad_atomic,
+    uint32_t* __restrict__ dbg) {
 #ifdef S360_DBG_TIMING
     const long long t_begin = wall_clock64();
 #endif
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
         uint2 sinfo = make_uint2(0u, 0u);   // (the pair's first slot, lean lists: which tiles of its rectangle hold instances)
         float zv = 0.f;
         if (lane_ok) {
-            sinfo = slot_info[pair];
+            if (!pairgrad_atomic) sinfo = slot_info[pair];
             if (WITH_DEPTH) zv = depth_value(depths[pair] * inv_scale, v_near, v_far, depth_mode);
         }
         // positions descend with the lane: the group's frontmost entry sits in lane n - 1
@@ -302,6 +303,23 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
                 }
             }
         }
+        if (pairgrad_atomic) {   // S360_FLAG_ATOMIC_GRADS (wave-uniform): ten return-less float32 atomics into the pair's record
+            if (lane_ok && anyc) {
+                const float ln2 = 0.6931471805599453f;
+                float* pg = pairgrad_atomic + 12 * (size_t)pair;
+                unsafeAtomicAdd(pg + 0, ln2 * (X.x + X.y));
+                unsafeAtomicAdd(pg + 1, ln2 * (Y.x + Y.y));
+                unsafeAtomicAdd(pg + 2, -0.5f * (XX.x + XX.y));
+                unsafeAtomicAdd(pg + 3, -(XY.x + XY.y));
+                unsafeAtomicAdd(pg + 4, -0.5f * (YY.x + YY.y));
+                unsafeAtomicAdd(pg + 5, g_op.x + g_op.y);
+                unsafeAtomicAdd(pg + 6, g_r.x + g_r.y);
+                unsafeAtomicAdd(pg + 7, g_g.x + g_g.y);
+                unsafeAtomicAdd(pg + 8, g_b.x + g_b.y);
+                if (WITH_DEPTH) unsafeAtomicAdd(pg + 9, g_z.x + g_z.y);
+            }
+            continue;
+        }
         uint32_t inst = 0xFFFFFFFFu;
         if (lane_ok && anyc) {  // position of tile (tx,ty) inside the splat's tile rectangle, in emission order
             int minx, miny, maxx, maxy;
@@ -338,6 +356,7 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
 void launch_render_bwd_em(bool with_depth, int n_units, hipStream_t st, const KParams& kp, const S360View* views,
                           const uint32_t* tile_start, const float4* surv, const uint32_t* surv_count, const uint2* slot_info,
                           const float* depths, const float* final_T, const uint32_t* n_contrib, const float* dL_dimages,
-                          const float* dL_dimages_scale, const float* dL_ddepth, float4* part, uint8_t* valid, const uint32_t* order, int depth_mode, uint32_t* dbg);
+                          const float* dL_dimages_scale, const float* dL_ddepth, float4* part, uint8_t* valid, const uint32_t* order, int depth_mode,
+                          float* pairgrad_atomic, uint32_t* dbg);
 
 }  // namespace s360

@@ -616,7 +616,8 @@ __device__ __forceinline__ void mse_finish_body(const float* __restrict__ partia
 
 static __global__ __launch_bounds__(1024) void k_order_units(const uint32_t* __restrict__ weight, uint32_t* __restrict__ order, int n,
                                                      uint32_t* __restrict__ valid_words, const uint32_t* __restrict__ header,
-                                                     uint32_t cap) {
+                                                     uint32_t cap, float4* __restrict__ pairgrad_atomic,
+                                                     const uint8_t* __restrict__ vis_mask, int P, int V) {
     if (blockIdx.x == 1) {   // S360_FLAG_DEFER_LOSS: the forward left its loss reduction to this launch
         const uint64_t pp = (uint64_t)header[S360_HDR_LOSS] | ((uint64_t)header[S360_HDR_LOSS + 1] << 32);
         const uint64_t po = (uint64_t)header[S360_HDR_LOSS + 2] | ((uint64_t)header[S360_HDR_LOSS + 3] << 32);
@@ -625,8 +626,17 @@ static __global__ __launch_bounds__(1024) void k_order_units(const uint32_t* __r
                             __uint_as_float(header[S360_HDR_LOSS + 6]), __uint_as_float(header[S360_HDR_LOSS + 7]), reinterpret_cast<float*>(po));
     }
     if (blockIdx.x > 0) {
-        const size_t nv = (size_t)min(header[0], cap);
         const size_t stride = (size_t)(gridDim.x - 1) * 1024;
+        if (pairgrad_atomic) {   // S360_FLAG_ATOMIC_GRADS: the composite ADDS into the visible pairs' records — start them at zero
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (size_t g = (size_t)(blockIdx.x - 1) * 1024 + threadIdx.x; g < (size_t)P; g += stride)
+                for (uint32_t m = vis_mask[g]; m; m &= m - 1) {
+                    float4* r = pairgrad_atomic + 3 * ((size_t)__builtin_ctz(m) * P + g);
+                    r[0] = z; r[1] = z; r[2] = z;
+                }
+            return;
+        }
+        const size_t nv = (size_t)min(header[0], cap);
         for (size_t i = (size_t)(blockIdx.x - 1) * 1024 + threadIdx.x; i < nv; i += stride) valid_words[i] = 0u;
         return;
     }

@@ -1483,8 +1483,11 @@ extern "C" int s360_layout(const S360Params* prm, S360Layout* out) {
     out->total_bytes = o;
     // backward scratch: 4 quadrant-partial raster-gradient records (12 floats) + 4 validity bytes per instance
     // ... + tile order [V*T] + one gathered 48-byte record per (view, Gaussian) pair
-    out->backward_bytes = align_up(cap * 4 * (size_t)(16 * S360_PREC_F4)) + align_up(cap * 4) + align_up(nt * 4 * 4) + 512 + align_up(np * 48) +
-                          align_up((size_t)(prm->P > 0 ? prm->P : 1) * 16) + 256;
+    // ... + tile order [V*T] + one gathered 48-byte record per (view, Gaussian) pair.  S360_FLAG_ATOMIC_GRADS: the composite
+    // adds into the pair records directly — no partial slots, no validity flags
+    const bool atomic = (prm->flags & S360_FLAG_ATOMIC_GRADS) != 0;
+    out->backward_bytes = (atomic ? 0 : align_up(cap * 4 * (size_t)(16 * S360_PREC_F4)) + align_up(cap * 4)) + align_up(nt * 4 * 4) + 512 +
+                          align_up(np * 48) + align_up((size_t)(prm->P > 0 ? prm->P : 1) * 16) + 256;
     return S360_OK;
 }
 

@@ -46,6 +46,10 @@ class GaussianRasterizationSettings(NamedTuple):
 # this switch or S360_LEAN_LISTS=0 select upstream's 3-sigma rectangles (what the integer-state parity tests compare).
 LEAN_LISTS = bool(int(os.environ.get("S360_LEAN_LISTS", "1")))
 
+# Opt-in (S360_FLAG_ATOMIC_GRADS): the backward composite accumulates with float32 atomics instead of the deterministic
+# partial-record gather — a quarter of the backward scratch, one launch less, gradients no longer bit-reproducible run to run.
+ATOMIC_GRADS = bool(int(os.environ.get("S360_ATOMIC_GRADS", "0")))
+
 DEPTH_MODES = {"depth": 0, "disparity": 1, "relative_disparity": 2, "log": 3}
 
 
@@ -265,7 +269,7 @@ class _RasterizeViews(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, cov6, views, cfg, mse_target=None):
         (h, w, sh_degree, shared_campos, max_instances, check, want_radii, cov9, sh_channel_major, keep_slots, depth_mode,
-         defer_sh, mse_weight, mse_count, spherical, exchange, lean, mse_defer) = cfg
+         defer_sh, mse_weight, mse_count, spherical, exchange, lean, mse_defer, atomic_grads) = cfg
         if exchange is not None and (shs is None or not (shared_campos or int(views.shape[0]) == 1) or defer_sh):
             raise RuntimeError("exchange=: the chunked gradient exchange needs SH colours and views sharing one camera centre "
                                "(and replaces defer_sh)")
@@ -296,7 +300,8 @@ class _RasterizeViews(torch.autograd.Function):
                 0 if (needs_bwd or keep_slots) else _lib.FLAG_FORWARD_ONLY) | (
                 _lib.FLAG_SH_DEG4_IGNORED if SH_DEG4_IGNORED else 0) | (_lib.FLAG_SPHERICAL if spherical else 0) | (
                 _lib.FLAG_LEAN_LISTS if lean else 0) | (
-                _lib.FLAG_DEFER_LOSS if (mse_defer and mse_target is not None and needs_bwd) else 0)
+                _lib.FLAG_DEFER_LOSS if (mse_defer and mse_target is not None and needs_bwd) else 0) | (
+                _lib.FLAG_ATOMIC_GRADS if (atomic_grads and needs_bwd) else 0)
             prm.max_instances = int(max_instances) if max_instances else default_capacity(
                 p, v, int(h), int(w), device=m3.device, lean=lean, lazy=(check != "sync"))
             mse = None
@@ -488,7 +493,7 @@ def rasterize_views(means3D: Tensor, cov6: Tensor, opacities: Tensor, shs: Optio
                     cov9: bool = False, sh_channel_major: bool = False, keep_slots: bool = False,
                     depth_mode: Optional[str] = None, defer_sh: bool = False, mse_target: Optional[Tensor] = None,
                     mse_weight: float = 1.0, mse_count: Optional[int] = None, spherical: bool = False, exchange=None,
-                    lean: Optional[bool] = None, mse_defer: bool = False):
+                    lean: Optional[bool] = None, mse_defer: bool = False, atomic_grads: Optional[bool] = None):
     """Render V views ([V,44] packed, see pack_views) of one cloud.  cov9: cov6 is [P,3,3];
     sh_channel_major: shs is [P,3,M] (the reference's Gaussians layouts, consumed without copies).
     When no input requires grad the instance-slot tables (backward-only state) are skipped unless
@@ -509,6 +514,8 @@ def rasterize_views(means3D: Tensor, cov6: Tensor, opacities: Tensor, shs: Optio
     mse_defer=True (with mse_target, on a call that will be back-propagated): the loss reduction runs inside the backward's first
     launch instead of as a launch of its own at the end of the forward (S360_FLAG_DEFER_LOSS) — FusedMse.loss / clipped_mse hold
     their values only AFTER .backward(); for training loops that read the scalar for logging after the step.
+    atomic_grads (default: module switch ATOMIC_GRADS = False): S360_FLAG_ATOMIC_GRADS — float32 atomics in the backward
+    composite instead of the deterministic gather (less scratch, one launch less; gradients not bit-reproducible).
     lean (default: module switch LEAN_LISTS = True): bin a (Gaussian, tile) instance only where the splat can reach
     alpha >= 1/255 on that tile — same images / radii / gradients bit for bit, shorter lists; lean=False = upstream's rectangles.
     spherical=True: native equirectangular splat mode (S360_FLAG_SPHERICAL; no reference counterpart, specified by the
@@ -521,7 +528,7 @@ def rasterize_views(means3D: Tensor, cov6: Tensor, opacities: Tensor, shs: Optio
         raise ValueError(f"depth_mode must be one of {sorted(DEPTH_MODES)}")
     cfg = (image_height, image_width, sh_degree, shared_campos, max_instances, check, want_radii, cov9,
            sh_channel_major, keep_slots, depth_mode, defer_sh, mse_weight, mse_count, bool(spherical), exchange,
-           LEAN_LISTS if lean is None else bool(lean), bool(mse_defer))
+           LEAN_LISTS if lean is None else bool(lean), bool(mse_defer), ATOMIC_GRADS if atomic_grads is None else bool(atomic_grads))
     images, radii, depth, loss, clipped = _RasterizeViews.apply(means3D, means2D, shs, colors_precomp, op2, cov6, views,
                                                                 cfg, mse_target)
     images.s360_deferred = _RasterizeViews.last_holder      # see deferred_of()

@@ -1,0 +1,78 @@
+"""S360_FLAG_ATOMIC_GRADS (opt-in): the backward composite accumulates into the pair records with float32 atomics instead of
+leaving partial records for the deterministic gather.  Same images; gradients equal the deterministic path's up to float32
+summation order, and meet the same float64-oracle bars; the backward scratch shrinks as the header promises.
+(Upstream's backward is atomic and non-deterministic as well: SURVEY App. A.4-11.)"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import boundary_tensors, face_settings
+from oracle import oracle
+from splatter360_amd import _lib, decoder, rasterizer, synthetic
+from test_gpu_lean import _dropin
+
+pytestmark = pytest.mark.gpu
+
+
+def _fused(params, cams, fw, dev, atomic, depth_mode="depth"):
+    ps = [p.clone().requires_grad_(True) for p in params]
+    ext, K, near, far = cams
+    col, dep = decoder.render_views_fused(ext, K, near, far, (fw, fw), torch.zeros(3, device=dev), *ps, shared_campos=True,
+                                          depth_mode=depth_mode, atomic_grads=atomic)
+    st = rasterizer.last_state()
+    w = torch.randn(col.shape, generator=torch.Generator().manual_seed(5)).to(dev)
+    ((col * w).sum() + 0.01 * (dep * dep).mean()).backward()
+    return col.detach(), dep.detach(), [p.grad for p in ps], st
+
+
+def test_atomic_mode_matches_deterministic_mode_and_shrinks_the_scratch(gpu):
+    cloud = synthetic.encoder_like_cloud(128, 256, seed=2)
+    params = [torch.tensor(cloud[k], device=gpu) for k in ("means", "covariances", "harmonics", "opacities")]
+    cams = decoder.cube_cameras(torch.tensor(synthetic.target_pano_pose((0.03, 0.0, -0.02)), device=gpu), 0.1, 10.0)
+    c0, d0, g0, s0 = _fused(params, cams, 64, gpu, False)
+    c1, d1, g1, s1 = _fused(params, cams, 64, gpu, True)
+    assert torch.equal(c0, c1) and torch.equal(d0, d1)
+    assert bool(s1.prm.flags & _lib.FLAG_ATOMIC_GRADS) and not (s0.prm.flags & _lib.FLAG_ATOMIC_GRADS)
+    assert s1.layout.backward_bytes < 0.45 * s0.layout.backward_bytes
+    for a, b in zip(g0, g1):
+        assert (a - b).abs().max().item() <= 2e-5 * (a.abs().max().item() + 1e-20)
+
+
+@pytest.mark.parametrize("face", [0, 2])
+def test_atomic_mode_against_the_float64_oracle(gpu, face):
+    cloud = synthetic.uniform_cloud(10_000, seed=3, extent=3.0, scale_range=(0.02, 0.3))
+    S = face_settings(face, 64, 64)
+    means, cov6, shs, opac = boundary_tensors(cloud, S["scale"])
+    gimg = np.random.default_rng(face).standard_normal((3, 64, 64)).astype(np.float32)
+    old = rasterizer.ATOMIC_GRADS
+    rasterizer.ATOMIC_GRADS = True
+    try:
+        got = _dropin(S, means, cov6, shs, opac, gpu, True, gimg)
+    finally:
+        rasterizer.ATOMIC_GRADS = old
+    o32 = oracle.rasterize(S, means3D=means, cov3D_precomp=cov6, opacities=opac, shs=shs)
+    o32.forward()
+    g32 = o32.backward(gimg)
+    o64 = oracle.rasterize(S, means3D=means, cov3D_precomp=cov6, opacities=opac, shs=shs, dtype=np.float64)
+    o64.forward()
+    g64 = o64.backward(gimg)
+    for k, t in zip(("means3D", "means2D", "cov3D", "opacities", "shs"), got["grads"]):
+        ref = np.asarray(g64[k], np.float64).reshape(-1)
+        scale = np.abs(ref).max() + 1e-30
+        e = np.abs(t.cpu().numpy().astype(np.float64).reshape(-1) - ref).max() / scale
+        e32 = np.abs(np.asarray(g32[k], np.float64).reshape(-1) - ref).max() / scale
+        assert e <= max(5e-4, 2.0 * e32), (k, e, e32)      # the bar of tests/test_gpu_fuzz.py
+
+
+def test_atomic_mode_at_the_headline_shape(gpu):
+    """1 048 576 Gaussians, six 256x256 faces: same images, gradients within float32 summation noise of the deterministic path,
+    backward scratch <= 0.4 GB."""
+    cloud = synthetic.encoder_like_cloud(512, 1024, seed=0)
+    params = [torch.tensor(cloud[k], device=gpu) for k in ("means", "covariances", "harmonics", "opacities")]
+    cams = decoder.cube_cameras(torch.eye(4, device=gpu), 0.1, 10.0)
+    c0, d0, g0, s0 = _fused(params, cams, 256, gpu, False)
+    c1, d1, g1, s1 = _fused(params, cams, 256, gpu, True)
+    assert torch.equal(c0, c1) and torch.equal(d0, d1)
+    assert s1.layout.backward_bytes <= 0.4e9, s1.layout.backward_bytes
+    for a, b in zip(g0, g1):
+        assert (a - b).abs().max().item() <= 1e-4 * (a.abs().max().item() + 1e-20)
