@@ -214,30 +214,37 @@ def exchange_chunked(p: int, packed: Tensor, rgb: Tensor, rep_view: Tensor, prod
     communicator so that they do not queue behind the all-reduces of earlier ranges.  Works for world size 1 (no collectives).
     Per rank and step at N ranks: receives 2 (N-1)/N * 40 B + (N-1) * 16 B per Gaussian (0.19 GB at N = 8, 1 M Gaussians) —
     what it can hide under: the tail kernels of the following ranges and the dL/dSH rebuilds of the preceding ones (a few hundred
-    microseconds at 1 M, N = 8) — DESIGN.md section 5 does the arithmetic."""
+    microseconds at 1 M, N = 8) — DESIGN.md section 5 does the arithmetic.
+    rebuild_sh=None (harmonics frozen on EVERY rank): the dL/dRGB factors are neither gathered nor rebuilt — only the packed
+    all-reduces run.  The collectives are issued from inside the caller's backward: every rank of `group` must run this backward
+    the same number of times with the same p / n_chunks / rebuild_sh-or-None, or the ranks that did wait forever."""
     world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
     bounds = chunk_bounds(p, n_chunks)
     if world == 1:
         for lo, hi in bounds:
             produce(lo, hi)
         rep_all = rep_view.reshape(1, -1)
-        for lo, hi in bounds:
-            rebuild_sh(lo, hi, rgb[lo:hi].reshape(1, hi - lo, 4), rep_all)
+        if rebuild_sh is not None:
+            for lo, hi in bounds:
+                rebuild_sh(lo, hi, rgb[lo:hi].reshape(1, hi - lo, 4), rep_all)
         return
     gg = group_gather if group_gather is not None else group
-    rep_all = torch.empty((world * rep_view.numel(),), dtype=rep_view.dtype, device=rep_view.device)
-    work_rep = dist.all_gather_into_tensor(rep_all, rep_view.reshape(-1).contiguous(), group=gg, async_op=True)
     gathers, reduces = [], []
+    if rebuild_sh is not None:
+        rep_all = torch.empty((world * rep_view.numel(),), dtype=rep_view.dtype, device=rep_view.device)
+        work_rep = dist.all_gather_into_tensor(rep_all, rep_view.reshape(-1).contiguous(), group=gg, async_op=True)
     for lo, hi in bounds:
         produce(lo, hi)
-        buf = torch.empty((world * (hi - lo), 4), dtype=rgb.dtype, device=rgb.device)      # dim-0 concat: gloo-compatible
-        gathers.append((buf, dist.all_gather_into_tensor(buf, rgb[lo:hi], group=gg, async_op=True)))
+        if rebuild_sh is not None:
+            buf = torch.empty((world * (hi - lo), 4), dtype=rgb.dtype, device=rgb.device)      # dim-0 concat: gloo-compatible
+            gathers.append((buf, dist.all_gather_into_tensor(buf, rgb[lo:hi], group=gg, async_op=True)))
         reduces.append(dist.all_reduce(packed[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True))
-    work_rep.wait()
-    rep_all = rep_all.reshape(world, -1)
-    for (lo, hi), (buf, w) in zip(bounds, gathers):
-        w.wait()
-        rebuild_sh(lo, hi, buf.view(world, hi - lo, 4), rep_all)
+    if rebuild_sh is not None:
+        work_rep.wait()
+        rep_all = rep_all.reshape(world, -1)
+        for (lo, hi), (buf, w) in zip(bounds, gathers):
+            w.wait()
+            rebuild_sh(lo, hi, buf.view(world, hi - lo, 4), rep_all)
     for w in reduces:
         w.wait()
     if timings is not None:
@@ -247,7 +254,10 @@ def exchange_chunked(p: int, packed: Tensor, rgb: Tensor, rep_view: Tensor, prod
 class ExchangeConfig:
     """Hand this to rasterize_views(..., exchange=ExchangeConfig(...)) (views sharing one camera centre): the node's backward
     then returns the per-Gaussian gradients SUMMED over the ranks of `group` (every rank renders its own panorama of the same
-    replicated cloud), exchanged range by range inside the backward itself — see exchange_chunked."""
+    replicated cloud), exchanged range by range inside the backward itself — see exchange_chunked.  `group` must be the group
+    (or the default group) all participating ranks initialised; EVERY rank of it must run the node's backward (a rank whose loss
+    does not reach the render would leave the others waiting in the collectives).  Frozen harmonics (no gradient required on any
+    rank) skip the dL/dRGB gathers and the dL/dSH rebuild."""
 
     def __init__(self, group=None, n_chunks: int = 4, group_gather=None):
         self.group, self.n_chunks, self.group_gather = group, int(n_chunks), group_gather

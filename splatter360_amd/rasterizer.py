@@ -383,8 +383,6 @@ class _RasterizeViews(torch.autograd.Function):
                 _lib.check(rc, "s360_backward_composite")
                 packed = torch.empty((p, 10), dtype=torch.float32, device=dev)
                 rgb = torch.empty((p, 4), dtype=torch.float32, device=dev)
-                if d_sh is None:
-                    d_sh = torch.empty_like(sh)
                 rank = ex.rank()
 
                 def produce(lo, hi):
@@ -404,13 +402,14 @@ class _RasterizeViews(torch.autograd.Function):
                                                     C.c_void_p(m3.data_ptr() + 12 * lo), _ptr(rgb_all.contiguous()),
                                                     C.c_void_p(d_sh.data_ptr() + 4 * slab * lo), st2), "s360_sh_backward")
 
-                distributed.exchange_chunked(p, packed, rgb, vw[0], produce, rebuild_sh, n_chunks=ex.n_chunks, group=ex.group,
-                                             group_gather=ex.group_gather)
+                # harmonics frozen (need[2] False — on every rank, it is the same model): no dL/dRGB gathers, no dL/dSH rebuild
+                distributed.exchange_chunked(p, packed, rgb, vw[0], produce, rebuild_sh if d_sh is not None else None,
+                                             n_chunks=ex.n_chunks, group=ex.group, group_gather=ex.group_gather)
                 _lib.check(lib.s360_unpack_gradients(_ptr(packed), p, int(c6.dim() == 3), _ptr(d_m3), _ptr(d_c6), _ptr(d_op), stream),
                            "s360_unpack_gradients")
                 if d_m2 is not None:
                     d_m2 = d_m2.sum(0) if v > 1 else d_m2[0]
-                return d_m3, d_m2, (d_sh if need[2] else None), None, d_op.view(-1, 1), d_c6, None, None, None
+                return d_m3, d_m2, d_sh, None, d_op.view(-1, 1), d_c6, None, None, None
             if ctx.defer_sh:
                 # multi-GPU factored form: no SH pass here; the caller exchanges d_rgb_sum and finishes with
                 # finish_deferred_sh() (see distributed.sync_gradients_factored)

@@ -311,13 +311,17 @@ def _chunked_worker(rank, world, port, q, p, n_chunks, two_groups):
         rebuilt.append((lo, hi))
         d_sh[lo:hi] = _sh_pass_restated(None, rep_all, torch.tensor(m3[lo:hi]), d_sh[lo:hi], rgb_all)
 
-    D.exchange_chunked(p, packed, rgb, rep, produce, rebuild_sh, n_chunks=n_chunks, group=None, group_gather=gg)
-    assert produced == rebuilt == D.chunk_bounds(p, n_chunks) and produced[0][0] == 0 and produced[-1][1] == p
+    frozen = n_chunks < 0        # harmonics frozen on every rank: no dL/dRGB gathers, no rebuild — only the packed all-reduces
+    n_chunks = abs(n_chunks)
+    D.exchange_chunked(p, packed, rgb, rep, produce, None if frozen else rebuild_sh, n_chunks=n_chunks, group=None, group_gather=gg)
+    assert produced == D.chunk_bounds(p, n_chunks) and produced[0][0] == 0 and produced[-1][1] == p
+    assert rebuilt == ([] if frozen else produced)
     q.put((rank, packed.numpy(), d_sh.double().numpy(), len(produced)))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,p,n_chunks,two_groups", [(8, 1000, 4, False), (8, 1000, 4, True), (3, 700, 8, False), (2, 100, 4, False)])
+@pytest.mark.parametrize("world,p,n_chunks,two_groups", [(8, 1000, 4, False), (8, 1000, 4, True), (3, 700, 8, False), (2, 100, 4, False),
+                                                         (3, 700, -3, False)])   # negative: harmonics frozen (no SH exchange)
 def test_chunked_exchange_sums_every_range_over_the_ranks(world, p, n_chunks, two_groups):
     """distributed.exchange_chunked at world size 8 (gloo): ragged Gaussian ranges (1000 = 3 x 256 + 232), more ranges asked
     for than the cloud has workgroups, a cloud smaller than one workgroup, all-gathers on their own process group — every
@@ -342,9 +346,12 @@ def test_chunked_exchange_sums_every_range_over_the_ranks(world, p, n_chunks, tw
     want_sh = _sh_pass_restated(None, views, torch.tensor(m3), torch.zeros((p, 25, 3)), rgb).double().numpy()
     from splatter360_amd.distributed import chunk_bounds
     for rank, packed, d_sh, n in outs:
-        assert n == len(chunk_bounds(p, n_chunks))
+        assert n == len(chunk_bounds(p, abs(n_chunks)))
         np.testing.assert_allclose(packed, want_packed, rtol=1e-12, atol=1e-12)
-        np.testing.assert_allclose(d_sh, want_sh, rtol=1e-5, atol=1e-5)
+        if n_chunks < 0:
+            assert not d_sh.any()         # frozen harmonics: nothing gathered, nothing rebuilt
+        else:
+            np.testing.assert_allclose(d_sh, want_sh, rtol=1e-5, atol=1e-5)
 
 
 def test_chunked_exchange_single_process_and_bounds():

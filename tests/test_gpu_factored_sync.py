@@ -96,6 +96,23 @@ def test_chunked_exchange_world_size_one_is_the_plain_backward_bit_for_bit(gpu, 
         assert torch.equal(p.grad, w)
 
 
+def test_chunked_exchange_with_frozen_harmonics_skips_the_sh_exchange(gpu):
+    """Harmonics that do not require grad: the exchange path neither gathers dL/dRGB nor rebuilds dL/dSH, the other
+    three gradients are those of the plain backward — including the view-direction term of dL/dmean, which needs no dL/dSH."""
+    from splatter360_amd import distributed as D
+    ps = _cloud(gpu)
+    ps[2] = ps[2].detach()                       # frozen harmonics
+    _render_backward(gpu, ps, POSITIONS[0], 6, False)
+    want = [p.grad.clone() if p.requires_grad else None for p in ps]
+    for p in ps:
+        p.grad = None
+    _render_backward(gpu, ps, POSITIONS[0], 6, False, exchange=D.ExchangeConfig(n_chunks=3))
+    assert ps[2].grad is None
+    for p, w in zip(ps, want):
+        if w is not None:
+            assert torch.equal(p.grad, w)
+
+
 def test_chunked_exchange_with_depth_gradient_and_upstream_layouts(gpu):
     """The in-backward exchange on the other input forms: the fused depth map's gradient (dL_ddepth through
     s360_backward_gaussians) and the upstream rasteriser layouts ([P,6] covariance, [P,25,3] harmonics) — world size 1, so the
