@@ -268,3 +268,41 @@ def test_large_footprint_pairs_are_gathered_wave_parallel_and_agree_with_the_ora
         w = np.asarray(g64[k], np.float64).reshape(-1)
         e = np.abs(got[k].cpu().numpy().astype(np.float64).reshape(-1) - w).max() / (np.abs(w).max() + 1e-30)
         assert e <= 2e-4, (k, e)
+
+
+def test_count_contributions_matches_a_recount_from_the_workspace(gpu):
+    """s360_count_contributions (the measurement aid behind bench.py's work-based VALU figure): contributing (pixel, entry) pairs
+    recounted in numpy from the same workspace — sorted lists, splat records, n_contrib — with the composite's accept test
+    (alpha >= 1/255, power <= 0, in front of the pixel's last contributor)."""
+    S, means, cov6, shs, opac = small_front_scene(n=150, seed=4, h=48, w=64, srange=(0.03, 0.4))
+    t = lambda a: torch.tensor(np.asarray(a, np.float32), device=gpu, requires_grad=True)
+    rast = rasterizer.GaussianRasterizer(_settings_to_torch(S, gpu))
+    m = t(means)
+    img, _ = rast(means3D=m, means2D=torch.zeros_like(m), shs=t(shs), opacities=t(opac), cov3D_precomp=t(cov6))
+    st = rasterizer.last_state()
+    got, evaluated = st.count_contributions()
+    tt = st.tensors()
+    ts = tt["tile_start"].cpu().numpy().astype(np.int64)
+    lst = tt["list"].cpu().numpy().astype(np.int64)
+    ra, rb = tt["rec_a"][0].cpu().numpy().astype(np.float64), tt["rec_b"][0].cpu().numpy().astype(np.float64)
+    nc = tt["n_contrib"][0].cpu().numpy().astype(np.int64)
+    gx = (64 + 15) // 16
+    want = 0
+    borderline = 0
+    for tile in range(len(ts) - 1):
+        ent = lst[ts[tile]:ts[tile + 1]]
+        if ent.size == 0:
+            continue
+        ys, xs = np.mgrid[0:16, 0:16]
+        py, px = 16 * (tile // gx) + ys, 16 * (tile % gx) + xs
+        ok = (py < 48) & (px < 64)
+        last = np.where(ok, nc[np.minimum(py, 47), np.minimum(px, 63)], 0)
+        for pos, g in enumerate(ent):
+            dx, dy = ra[g, 0] - px, ra[g, 1] - py
+            power = ra[g, 2] * dx * dx + ra[g, 3] * dx * dy + rb[g, 0] * dy * dy
+            alpha = np.minimum(0.99, rb[g, 1] * np.exp2(power))
+            sel = ok & (pos < last) & (power <= 0)
+            want += int((sel & (alpha >= 1.0 / 255.0)).sum())
+            borderline += int((sel & (np.abs(alpha - 1.0 / 255.0) < 1e-6)).sum())
+    assert abs(got - want) <= borderline + 1, (got, want, borderline)
+    assert want > 1000 and evaluated >= got and evaluated % 64 == 0
