@@ -128,7 +128,7 @@ def render_cuda_orthographic(extrinsics: Tensor, width: Tensor, height: Tensor, 
 
 
 def _depth_colors(extrinsics, means, near, far, mode):
-    cam = torch.einsum("bij,bgj->bgi", extrinsics.inverse(),
+    cam = torch.einsum("bij,bgj->bgi", cameras._inverse_nosync(extrinsics),   # same LU as .inverse(), without its info read-back
                        torch.cat([means, torch.ones_like(means[..., :1])], dim=-1))
     z = cam[..., 2]
     if mode == "disparity":

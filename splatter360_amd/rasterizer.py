@@ -50,6 +50,11 @@ LEAN_LISTS = bool(int(os.environ.get("S360_LEAN_LISTS", "1")))
 # partial-record gather — a quarter of the backward scratch, one launch less, gradients no longer bit-reproducible run to run.
 ATOMIC_GRADS = bool(int(os.environ.get("S360_ATOMIC_GRADS", "0")))
 
+# The drop-in GaussianRasterizer reads the binning-overflow flag back after every call ("sync": one host synchronisation, like
+# upstream's own scan read-back, and an automatic re-render at the exact size).  S360_DROPIN_CHECK=lazy (or this switch) removes
+# that synchronisation from an unchanged reference's per-face loop; the caller then owns the check (last_state().overflowed()).
+DROPIN_CHECK = os.environ.get("S360_DROPIN_CHECK", "sync")
+
 DEPTH_MODES = {"depth": 0, "disparity": 1, "relative_disparity": 2, "log": 3}
 
 
@@ -575,5 +580,5 @@ class GaussianRasterizer(nn.Module):
         views = pack_views(s.viewmatrix, s.projmatrix, s.campos, s.tanfovx, s.tanfovy, s.bg)
         images, radii = rasterize_views(
             means3D, cov3D_precomp, opacities, shs, colors_precomp, views=views, image_height=s.image_height,
-            image_width=s.image_width, sh_degree=s.sh_degree, shared_campos=True, means2D=means2D)
+            image_width=s.image_width, sh_degree=s.sh_degree, shared_campos=True, means2D=means2D, check=DROPIN_CHECK)
         return images[0], radii[0]
