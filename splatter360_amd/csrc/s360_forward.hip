@@ -385,7 +385,15 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess(
                     // block-local histogram in LDS; one global atomic per (block, touched tile) below
                     uint32_t* tc = lds_hist == 2 ? hist : (lds_hist ? hist : tile_count) + (size_t)image_of_view(kp, v) * kp.T;
                     uint32_t hmask = 0xFFFFFFFFu;
-                    if (lean && area <= 32) {
+                    // lean_safe: the bit-identity of the lean lists rests on a 0.02-log2 margin between the tile test
+                    // and the quadrants' tests over the float32 rounding of power2().  The cancelling terms a dx^2, b dx dy,
+                    // c dy^2 of a thin diagonal splat that spans many tiles reach 1e4 ... 1e5, where that rounding approaches
+                    // 1e-2 (at the bound below: <= 1e4 x 4 roundings x 6e-8 = 2.4e-3): such a splat (an axis ratio beyond ~30:1 at a
+                    // 5 x 6-tile footprint — none in any workload here) is binned
+                    // whole, like the rectangles beyond 32 tiles.  Bound: every |dx|, |dy| inside the rectangle is < rad + 16.
+                    const float rext = (float)rad + 16.0f;
+                    const bool lean_safe = (fabsf(ra) + fabsf(rb) + fabsf(rc_)) * (rext * rext) < 1.0e4f;
+                    if (lean && area <= 32 && lean_safe) {
                         // lean lists: count only the tiles the splat can reach (tile_hit: the composites' cull at tile size) and
                         // remember them as one bit per tile of the rectangle, scan order — k_emit places exactly these, the
                         // backward finds an instance's slot as the rank of its tile's bit.  Larger rectangles are binned whole.
@@ -1096,8 +1104,14 @@ __global__ __launch_bounds__(SORT_THREADS) void k_merge_all(const uint32_t* __re
             __syncthreads();
         }
         merge_unit(u, pass, keys, keys, alt, list, lds_m, s_part);   // runs read and written with device-coherent accesses
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // every thread's stores are complete ...
-        __syncthreads();                                              // ... before the counter says so (also: LDS and s_part are reused next)
+        // Every thread DRAINS its own write-through stores (s_waitcnt vmcnt(0): a store's counter is released when the memory side
+        // has acknowledged it) before the workgroup barrier, and only then does thread 0 publish the pass.  A workgroup-scope
+        // release fence alone compiles to `s_waitcnt lgkmcnt(0)` on gfx950 — the sc1 global stores were not waited on, and a
+        // workgroup behind another XCD could read a run before it had landed.  No cache-wide write-back is
+        // needed: the stores are device-coherent themselves.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();                                              // (also: LDS and s_part are reused next)
         if (threadIdx.x == 0 && pass + 1 < u.passes)
             __hip_atomic_fetch_add(&merge_done[(size_t)u.t * MAX_PASSES + pass], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -1410,6 +1424,9 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
         hdr_loss[4] = (uint32_t)(kp.T * 4); hdr_loss[5] = (uint32_t)kp.V;
         hdr_loss[6] = __float_as_uint(0.5f * ep.grad_scale);
         hdr_loss[7] = __float_as_uint(1.0f / (3.0f * (float)kp.H * (float)kp.W));
+        // until the backward has reduced them, loss / clipped MSE read as NaN — a premature read (a NaN guard, a logger, Lightning's
+        // returned loss) is then visibly wrong instead of uninitialised memory
+        for (int i = 0; i <= kp.V; ++i) ep.loss_out[i] = __uint_as_float(0x7FC00000u);
     }
     const uint32_t wm = wave_max_u32(inside ? last : 0u);
     if (lane == 0) {

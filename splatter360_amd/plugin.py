@@ -77,7 +77,23 @@ class _LazyPatcher(importlib.abc.MetaPathFinder):
         self.opts, self.busy = opts, False
 
     def find_spec(self, fullname, path, target=None):
-        if fullname != REGISTRY_MODULE or self.busy:
+        if self.busy:
+            return None
+        if fullname != REGISTRY_MODULE:
+            # ANY later import is a chance to patch: the reference imports its packages inside jaxtyping's install_import_hook
+            # (/root/reference/src/main.py:22-36), whose own finder is inserted at sys.meta_path[0] afterwards and resolves every
+            # `src.*` module by calling PathFinder directly — this finder is then never asked for `src.model.decoder` itself
+            # (ADVICE r04), but it is asked for the first non-`src` module imported after it (the encoder's third-party
+            # imports, still inside that `with` block and long before get_decoder runs at main.py:168).
+            pkg = sys.modules.get(REGISTRY_MODULE)
+            if pkg is not None and isinstance(getattr(pkg, "DECODERS", None), dict) and REGISTRY_KEY in pkg.DECODERS:
+                if self in sys.meta_path:
+                    sys.meta_path.remove(self)
+                self.busy = True
+                try:
+                    _patch(pkg, **self.opts)
+                finally:
+                    self.busy = False
             return None
         self.busy = True
         try:

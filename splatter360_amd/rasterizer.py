@@ -54,6 +54,8 @@ ATOMIC_GRADS = bool(int(os.environ.get("S360_ATOMIC_GRADS", "0")))
 # upstream's own scan read-back, and an automatic re-render at the exact size).  S360_DROPIN_CHECK=lazy (or this switch) removes
 # that synchronisation from an unchanged reference's per-face loop; the caller then owns the check (last_state().overflowed()).
 DROPIN_CHECK = os.environ.get("S360_DROPIN_CHECK", "sync")
+if DROPIN_CHECK not in ("sync", "lazy"):     # a typo must not silently select the mode without the overflow re-render
+    raise RuntimeError(f"S360_DROPIN_CHECK must be 'sync' or 'lazy', got {DROPIN_CHECK!r}")
 
 DEPTH_MODES = {"depth": 0, "disparity": 1, "relative_disparity": 2, "log": 3}
 

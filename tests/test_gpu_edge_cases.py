@@ -80,6 +80,34 @@ def test_tile_list_longer_than_every_lds_sort_class(gpu, n):
     check_forward(hh, f, n, 32, 32)
 
 
+def test_many_multichunk_tiles_merge_is_race_free_over_repeated_runs(gpu):
+    """k_merge_all published a finished merge pass before its write-through stores had been waited on, so a
+    workgroup behind another XCD could merge stale keys.  Stress: 64 tiles of ~9 500 keys each (3 chunks, 2 passes, hundreds of
+    (pass, chunk) units in flight across every XCD), forty calls; the list of every call must equal the host's stable sort of
+    the emitted (tile, depth, pair) keys — the first call is also put against the oracle."""
+    rng = np.random.default_rng(11)
+    n, hw = 9500, 128
+    S, _, _, _, _ = small_front_scene(n=2, seed=0, h=hw, w=hw)
+    z = rng.uniform(2.0, 30.0, n)
+    means = np.stack([rng.uniform(-0.05, 0.05, n) * z, rng.uniform(-0.05, 0.05, n) * z, z], 1)
+    cov6 = np.tile(np.array([[1.0, 0, 0, 1.0, 0, 1.0]]), (n, 1)) * (z[:, None] ** 2)   # 3-sigma radius > the image: every tile
+    colors = rng.uniform(0, 1, (n, 3))
+    opac = rng.uniform(0.001, 0.01, (n, 1))
+    f, _ = _orc(S, means, cov6, None, opac, colors=colors)
+    assert (np.diff(f["ranges"], axis=1) > 8192).sum() == 64
+    hh = run_hip(S, means, cov6, None, opac, gpu, colors=colors)
+    check_forward(hh, f, n, hw, hw)
+    want = torch.tensor(f["values"].astype(np.int64), device=gpu)
+    t = lambda a: torch.tensor(np.asarray(a, np.float32), device=gpu)
+    st = _settings_to_torch(S, gpu)
+    views = rasterizer.pack_views(st.viewmatrix, st.projmatrix, st.campos, st.tanfovx, st.tanfovy, st.bg)
+    args = (t(means), t(cov6), t(opac), None, t(colors))
+    for it in range(40):
+        rasterizer.rasterize_views(*args, views=views, image_height=hw, image_width=hw, sh_degree=0, shared_campos=True)
+        got = rasterizer.last_state().tensors()["list"][: want.numel()].to(torch.int64) & 0xFFFFFFFF
+        assert torch.equal(got, want), it
+
+
 def test_equal_depth_ties_keep_index_order(gpu):
     S, _, _, _, _ = small_front_scene(n=2, seed=0, h=32, w=32)
     n = 600

@@ -110,6 +110,8 @@ def test_deferred_loss_is_reduced_by_the_backward(gpu):
         p.grad = None
     faces2, fm2 = decoder.render_views_fused(ext, K, near, far, (64, 64), bg, *ps, mse_target=gt, mse_weight=0.8, mse_defer=True)
     assert torch.equal(faces2, faces)
+    # before the backward the deferred scalars read as NaN, never as uninitialised memory
+    assert bool(torch.isnan(fm2.loss.detach()).all()) and bool(torch.isnan(fm2.clipped_mse).all())
     fm2.loss.backward()
     torch.cuda.synchronize()
     assert torch.equal(fm2.loss.detach(), want_loss) and torch.equal(fm2.clipped_mse, want_clip)

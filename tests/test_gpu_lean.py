@@ -136,6 +136,42 @@ def test_lean_large_footprints(gpu):
     assert torch.equal(par["radii"], lean["radii"])      # radii are upstream's (the rectangle's), not the lists'
 
 
+@pytest.mark.parametrize("seed", [0, 1])
+def test_lean_thin_diagonal_splats_near_the_32_tile_limit(gpu, seed):
+    """needle-like diagonal splats (axis ratios 20:1 ... 300:1) whose rectangles span close to 32 tiles — the
+    exponent's cancelling terms a dx^2, b dx dy, c dy^2 reach 1e4 ... 1e5 there and float32 rounding approaches the lean cull's
+    margin.  Beyond the bound in k_preprocess (lean_safe) such a splat is binned whole; everything observable stays bit-identical
+    and every dropped instance is still invisible in float64."""
+    rng = np.random.default_rng(100 + seed)
+    n, hw = 160, 160
+    S, _, _, shs, _ = small_front_scene(n=n, seed=seed, h=hw, w=hw)
+    z = rng.uniform(3.0, 6.0, n)
+    means = np.stack([rng.uniform(-0.45, 0.45, n) * z, rng.uniform(-0.45, 0.45, n) * z, z], 1)
+    ang = np.pi / 4 + rng.uniform(-0.3, 0.3, n) + (rng.integers(0, 2, n) * np.pi / 2)
+    major = rng.uniform(22.0, 47.0, n) / 3.0 / (hw / 2) * z          # 3-sigma half-length of 22 ... 47 pixels: up to 6 tiles a side
+    minor = major / np.exp(rng.uniform(np.log(20.0), np.log(300.0), n))
+    c, s_ = np.cos(ang), np.sin(ang)
+    R = np.zeros((n, 3, 3))
+    R[:, 0, 0], R[:, 0, 1], R[:, 1, 0], R[:, 1, 1], R[:, 2, 2] = c, -s_, s_, c, 1.0
+    sc = np.stack([major, minor, minor], 1)
+    cov = np.einsum("nij,nj,nkj->nik", R, sc * sc, R)
+    rr, cc = np.triu_indices(3)
+    cov6 = cov[:, rr, cc]
+    opac = rng.uniform(0.3, 0.99, (n, 1))
+    gimg = rng.standard_normal((3, hw, hw)).astype(np.float32)
+    par = _dropin(S, means, cov6, shs, opac, gpu, False, gimg)
+    lean = _dropin(S, means, cov6, shs, opac, gpu, True, gimg)
+    tt, ttl = par["t"]["tiles_touched"][0], lean["t"]["tiles_touched"][0]
+    ra, rb = (par["t"][k][0].double() for k in ("rec_a", "rec_b"))
+    rad = par["t"]["rec_c"][0][:, 1].contiguous().view(torch.int32).double()
+    mag = (ra[:, 2].abs() + ra[:, 3].abs() + rb[:, 0].abs()) * (rad + 16.0) ** 2          # the bound k_preprocess evaluates
+    risky = (mag >= 1.0e4) & (tt > 0) & (tt <= 32)
+    assert int(((tt > 12) & (tt <= 32)).sum()) > 20 and int(risky.sum()) > 3      # the regime the finding is about is populated
+    assert torch.equal(ttl[risky], tt[risky])                                      # ... and those splats are binned whole
+    _equal_all(par, lean)
+    _check_lists(par, lean, n, hw, hw)
+
+
 def _fused(params, cams, fw, dev, lean, depth_mode="depth", target=None, max_instances=None, check="sync"):
     ps = [p.clone().requires_grad_(True) for p in params]
     ext, K, near, far = cams

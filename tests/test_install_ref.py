@@ -92,3 +92,28 @@ def test_lazy_install_patches_when_the_reference_imports_its_decoder_package():
         print("ok")
     """)
     assert out.strip().endswith("ok")
+
+
+def test_lazy_install_survives_a_competing_finder_that_resolves_src_itself():
+    """jaxtyping's install_import_hook (src/main.py:22-36) puts its own finder at sys.meta_path[0] and resolves `src.*`
+    through PathFinder directly, so the lazy patcher never sees `src.model.decoder`.  Emulated here; the registry must still be
+    patched by the time the imports of that `with` block are over (any non-`src` import after the package triggers it)."""
+    out = _run("""
+        import importlib.abc, importlib.machinery
+        import splatter360_amd
+        assert splatter360_amd.install(lazy=True) is None
+        class Competing(importlib.abc.MetaPathFinder):          # what jaxtyping's hook does: first in line, PathFinder for src.*
+            def find_spec(self, fullname, path, target=None):
+                if fullname == "src" or fullname.startswith("src."):
+                    return importlib.machinery.PathFinder.find_spec(fullname, path, target)
+                return None
+        sys.meta_path.insert(0, Competing())
+        from src.model.decoder import DECODERS, get_decoder
+        assert DECODERS["splatting_cuda"].__name__ == "DecoderSplattingCUDA"      # not patched yet: the patcher was bypassed
+        import colorsys                                                            # any later non-src import (main.py: the encoder's)
+        dec = get_decoder(cfg, dcfg)
+        assert type(dec).__name__ == "DecoderSplattingFusedMI355X", type(dec)
+        assert not any(type(f).__name__ == "_LazyPatcher" for f in sys.meta_path)
+        print("ok")
+    """)
+    assert out.strip().endswith("ok")
