@@ -84,6 +84,12 @@ def parse():
                     help="fwdbwd, 1 GPU: 1 (default) = after the headline measurement, time the same step on two more clouds of the same size "
                          "(SURVEY 8(d)'s uniform-random stress cloud and a surface-like cloud: coherent depth, opacity >= 0.9) and the "
                          "per-face drop-in training step of the unchanged reference (`dropin_train`); 0 = skip them")
+    ap.add_argument("--split-lists", type=int, default=1, help="1 (default): S360_FLAG_SPLIT_LISTS — long tile lists whose pixels do not saturate are "
+                    "composited segment-parallel (forward and backward); 0: every list is one sequential chain")
+    ap.add_argument("--single-rank-rccl", type=int, default=0,
+                    help="1 (with --gpus 1): create a ONE-rank process group with backend nccl (= RCCL) and run the chunked exchange through "
+                         "its collective branch (distributed.ExchangeConfig(force_collectives=True)) — the all-reduces / all-gathers really "
+                         "go through RCCL on its own streams beside the backward's kernels; what a one-GPU box can show of the N > 1 path")
     ap.add_argument("--dry-run", type=int, default=0,
                     help="1: launch / rendezvous / collectives only (no GPU work, value = null): lets the CPU test suite exercise "
                          "`python bench.py --gpus N` end to end with the gloo backend")
@@ -191,7 +197,18 @@ def main():
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(a)      # does not return
     rasterizer.ATOMIC_GRADS = bool(a.atomic_grads)
+    rasterizer.SPLIT_LONG_LISTS = bool(a.split_lists)
     rank, local_rank, world = distributed.init()
+    if a.single_rank_rccl and world == 1 and not a.dry_run:
+        import socket
+        import torch.distributed as dist
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sock.getsockname()[1]))
+        sock.close()
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(0)
+        dist.init_process_group(backend="nccl", rank=0, world_size=1)
     if a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} but the launcher started {world} rank(s)")
     if a.dry_run:
@@ -270,9 +287,10 @@ def main():
                 distributed.allreduce_gradients([p.grad for p in params])
         out["faces"] = faces
 
+    forced = bool(a.single_rank_rccl) and world == 1     # one RCCL rank, collectives really issued
     factored = world > 1 and a.mode == "fwdbwd" and a.grad_sync == "factored"
-    chunked = world > 1 and a.mode == "fwdbwd" and a.grad_sync == "chunked"
-    exchange_cfg = distributed.ExchangeConfig(n_chunks=a.chunks) if chunked else None
+    chunked = (world > 1 or forced) and a.mode == "fwdbwd" and a.grad_sync == "chunked"
+    exchange_cfg = distributed.ExchangeConfig(n_chunks=a.chunks, force_collectives=forced) if chunked else None
     step = step_eval if a.mode == "eval" else step_train
     views_per_step = 3 if a.mode == "eval" else 1
 
@@ -284,8 +302,12 @@ def main():
     for _ in range(a.warmup):
         step()
     finish_pending()
-    if a.warmup:   # one read of the instance count (outside the timed region): the following calls size their binning buffers
-        rasterizer.last_state().num_rendered()   # and backward scratch from it (x 1.25) instead of the first-call guess 1.5 G V
+    if a.warmup:
+        # check="lazy" calls size their binning buffers and backward scratch from the instance count the PREVIOUS call of the shape
+        # reported into pinned host memory (S360Params.header_mirror; x 1.25 instead of the first-call guess 1.5 G V) — no read-back,
+        # no synchronisation in the loop.  The warm-up has been through that; one more step so that the timed steps all run at the
+        # steady-state size even if the host ran ahead of the device during the warm-up.
+        torch.cuda.synchronize(dev)
         step()
         finish_pending()
     sync()
@@ -322,7 +344,7 @@ def main():
         extra["forward_only"] = {"value": G * world / (dt_f / a.steps) / 1e6, "unit": "Msplats/s", "ms_per_step": dt_f / a.steps * 1e3,
                                  "steps": a.steps, "what": "BASELINE configs[1]: fused six-face forward + stitch, inference form of the call"}
     if a.mode == "fwdbwd":
-        if world > 1:
+        if world > 1 or forced:
             # (2) how much of the gradient exchange a step exposes: the same K steps without it
             local_only[0] = True
             for _ in range(2):
@@ -344,6 +366,8 @@ def main():
     if st.overflowed():
         raise SystemExit("binning capacity overflowed during the timed region: result invalid")
     L = st.num_rendered()
+    ws_fwd, ws_bwd = int(st_timed.layout.total_bytes), int(st_timed.layout.backward_bytes)   # scratch of a timed step (check="lazy")
+    n_split = int(st_timed.header()[5].item()) if a.split_lists else 0
     tt = st.tensors()
     visible_pairs = int((tt["tiles_touched"] > 0).sum().item())
     assert torch.isfinite(out["faces"]).all() and torch.isfinite(out["erp"]).all()
@@ -434,6 +458,9 @@ def main():
     work_inst = None if (n_contrib_pairs is None or dom not in MIN_INST) else n_contrib_pairs * views_per_step * MIN_INST[dom] / 64.0
     roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic,
+                # what the kernel REALLY moves through HBM per unit time (PMC counter bytes / launch time / peak): `frac` prices the
+                # phase's algorithmic bytes against the kernel's duration, as the contract defines it — it is not "42 % of HBM"
+                "hbm_frac_kernel": None if traffic is None else traffic / dom_s / 1e9 / HBM_PEAK_GBPS,
                 "frac_path": bytes_step / (dt / a.steps) / 1e9 / HBM_PEAK_GBPS,
                 "algorithmic_bytes_per_launch": per_splat * G, "launch_us": kernels[dom]["avg_us"],
                 "valu_issue_frac": None if a_inst is None else a_inst / VALU_PEAK_GINST, "valu_insts_per_launch": valu_insts,
@@ -460,7 +487,9 @@ def main():
                        ", RCCL factored grad exchange (all-reduce 40 B/G packed + all-gather dRGB 16 B/G/rank" + (", overlapped with the next micro-batch's forward" if a.overlap_exchange else "") + ")" if factored else
                        ", RCCL all-reduce of Gaussian grads"),
                    "num_rendered": L, "num_rendered_upstream_lists": L_upstream, "lean_over_upstream": L / max(L_upstream, 1),
-                   "visible_pairs": visible_pairs},
+                   "visible_pairs": visible_pairs, "split_lists": bool(a.split_lists), "split_quadrants": n_split,
+                   "workspace_bytes_forward": ws_fwd, "workspace_bytes_backward": ws_bwd if a.mode == "fwdbwd" else 0,
+                   "max_instances": int(st_timed.prm.max_instances)},
         "roofline": roofline,
         "path_roofline": {"bytes_per_step": bytes_step, "achieved_GBps": bytes_step / (dt / a.steps) / 1e9,
                           "frac_of_8TBps": bytes_step / (dt / a.steps) / 1e9 / HBM_PEAK_GBPS,
@@ -514,6 +543,8 @@ def main():
             _lib.profile_enable(False)
             res["workloads"][name] = {"value": G / dtw / 1e6, "unit": "Msplats/s", "ms_per_step": dtw * 1e3, "steps": k2,
                                       "num_rendered": stw.num_rendered(), "overflowed": stw.overflowed(),
+                                      "split_quadrants": int(stw.header()[5].item()) if a.split_lists else 0,
+                                      "workspace_bytes_forward": int(stw.layout.total_bytes), "workspace_bytes_backward": int(stw.layout.backward_bytes),
                                       "visible_pairs": int((stw.tensors()["tiles_touched"] > 0).sum().item()),
                                       "finite": bool(torch.isfinite(out["faces"]).all()), "kernels_avg_us": kw_us}
             cur["params"] = None
@@ -544,7 +575,7 @@ def main():
                                "what": "the same training step through the unchanged reference's decoder loop: six per-face drop-in rasteriser "
                                        "calls (torch camera glue, host sync per call), torch L2 loss, backward — what a user gets without "
                                        "splatter360_amd.install()"}
-    if rank == 0 and world == 1 and a.cpu_baseline and a.mode != "eval":
+    if rank == 0 and a.cpu_baseline and a.mode != "eval":    # N > 1 too: rank 0's host cores, the other ranks wait at the teardown
         res["cpu_baseline"] = cpu_baseline(cloud, face_w, 0.1, 10.0, a.mode)
         try:
             res["cpu_baseline_torch"] = cpu_baseline_torch()
@@ -554,7 +585,7 @@ def main():
         res["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if world > 1 or forced:
         torch.distributed.destroy_process_group()
 
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define S360_ABI_VERSION 19
+#define S360_ABI_VERSION 20
 #define S360_MAX_VIEWS 8
 #define S360_TILE 16
 
@@ -101,6 +101,23 @@ enum {
                                          then run-dependent: gradients are NOT bit-reproducible (upstream's backward is atomic and
                                          non-deterministic too).  Default (flag clear): no float atomics anywhere. */
 
+#define S360_FLAG_SPLIT_LISTS 512u      /* long tile lists are composited SEGMENT-PARALLEL (forward and backward).  Upstream's composite (and this
+                                         library's without the flag) walks a tile's depth-sorted list front to back as ONE sequential
+                                         chain per pixel block; a tile list of 10-17 K entries whose pixels do not saturate — the pole
+                                         clumps of a panorama: the 1 024 Gaussians of every polar ERP row land on a few face pixels,
+                                         /root/reference/src/geometry/utils360.py:93-104 — then costs one wave hundreds of microseconds
+                                         while the rest of the chip idles.  With the flag, an 8x8 quadrant that is still busy (more
+                                         than six unsaturated pixels) after the first 2 048 entries of a list with at least 1 024 more
+                                         hands the rest over in segments of 1 024 entries: one wave per segment composites it from
+                                         T = 1, a per-pixel combine applies C += T C_k, T *= T_k in list order, and a pixel whose stop
+                                         test `T (1 - alpha) < 1e-4` can trip inside a segment replays that segment sequentially from
+                                         its exact incoming state.  The backward composites the same segments in parallel from the
+                                         forward's per-segment transmittance and the colour accumulated behind each segment.  What
+                                         changes: floating-point association inside split quadrants only (<= 1e-6 per pixel measured,
+                                         north_star's bar is 1e-5); n_contrib, the stop decisions and every integer stay those of the
+                                         sequential walk.  Quadrants that do not split — every list up to 3 071 entries, and every
+                                         quadrant that saturates within its first 2 048 — are bit-identical with and without the flag. */
+
 typedef struct S360View {
     float viewmatrix[16];
     float projmatrix[16];
@@ -120,6 +137,11 @@ typedef struct S360Params {
     int32_t M;              /* SH coefficients stored per Gaussian per channel (shs.shape[1]); 0 = colors_precomp */
     uint32_t flags;         /* S360_FLAG_* */
     uint32_t max_instances; /* capacity of the binning buffers ((Gaussian,tile) pairs, "num_rendered") */
+    void* header_mirror;    /* NULL, or a HOST-visible (pinned / mapped) 8-byte aligned address: the forward also stores
+                               (num_instances | overflow flag << 32) there as one 64-bit word — the caller can size its next
+                               call from the previous call's count without a device synchronisation (upstream reads the count
+                               back synchronously inside every forward; this library's callers may run without that read,
+                               and this is how they learn the count and the overflow flag anyway) */
 } S360Params;
 
 /* Byte offsets of every array inside the forward workspace (state kept for backward and exposed
@@ -127,7 +149,7 @@ typedef struct S360Params {
 typedef struct S360Layout {
     size_t total_bytes;         /* forward workspace size */
     size_t header;              /* uint32[64]: [0]=num_instances [1]=overflow flag [2]=max tile list length [3]=merge passes needed
-                                   [4]=pairs with more than 32 instance slots */
+                                   [4]=pairs with more than 32 instance slots [5]=split (tile, quadrant) units of this call */
     size_t tiles_touched;       /* uint32[V*P] */
     size_t vis_mask;            /* uint8[P]  bit v set: Gaussian visible in view v (V <= 8).  tiles_touched is written for
                                    visible pairs only; the kernels test visibility on this byte, not on V words */
@@ -146,6 +168,10 @@ typedef struct S360Layout {
     size_t slot_ticket;         /* per-image instance-slot tickets, 256 B apart (cleared together with tile_count) */
     size_t merge_done;          /* uint32[V*T][4] completion counters of the global merge passes of the long lists
                                    (cleared together with tile_count) */
+    size_t seg_flag;            /* uint32[V*T*4] S360_FLAG_SPLIT_LISTS: 1 = this (tile, quadrant) handed the rest of its list over to
+                                   segment waves after SEG_HEAD entries (cleared together with tile_count) */
+    size_t seg_arrive;          /* uint32[V*T*4] segment waves of a split quadrant that have delivered their partial result: the last
+                                   one to arrive runs the per-pixel combine (cleared together with tile_count) */
     size_t tile_start;          /* uint32[V*T+1] exclusive scan (upstream ranges: [start[t], start[t+1])) */
     size_t tile_cursor;         /* uint32[V*T] */
     size_t chunk_start;         /* uint32[V*T+1] number of 4096-key sort chunks of long lists before tile t */
@@ -171,6 +197,19 @@ typedef struct S360Layout {
                                    [4 start_t + q n_t, ... + n_t), n_t = the tile's list length.  The backward composite
                                    streams them back to front instead of walking and culling the tile list a second time */
     size_t surv_count;          /* uint32[V*T*4] survivor records of a unit that lie in front of its last contributor */
+    /* S360_FLAG_SPLIT_LISTS state.  Segment SLOT s = 4 * chunk_start[t] + k is segment k (list positions [1024 k, 1024 (k+1)))
+     * of long tile t; NSEG = 4 (max_instances / 2048 + 1) slots.  Slots k = 0 of a split quadrant hold what its head wave
+     * published (the exact sequential state after 2 048 entries); k >= 2 the segment waves' partial results. */
+    size_t part_c;              /* float4[NSEG*4*64]  per (slot, quadrant, pixel): colour (r, g, b, depth) composited from T = 1 */
+    size_t part_t;              /* float [NSEG*4*64]  ... transmittance of the segment alone */
+    size_t part_l;              /* uint32[NSEG*4*64]  ... last contributing list position + 1 (0: none) | stopped << 31 */
+    size_t part_n;              /* uint32[NSEG*4]     survivor records the segment appended (slot k = 1: the head's count when no
+                                   later segment contributes) */
+    size_t seg_c;               /* float4[NSEG*4*64]  after the combine: colour accumulated BEHIND the segment (what the backward
+                                   starts its colour-behind sum from) */
+    size_t seg_t;               /* float [NSEG*4*64]  after the combine: transmittance behind the segment's last entry */
+    size_t seg_cnt;             /* uint32[NSEG*4]     survivor records of the segment the backward replays (0: none / not split) */
+    size_t seg_info;            /* uint32[NSEG][2]    (tile, segment index k) of a slot */
     size_t backward_bytes;      /* size of the separate backward scratch workspace */
 } S360Layout;
 

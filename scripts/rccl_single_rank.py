@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""The N > 1 gradient exchange driven through RCCL on ONE GPU: a process group of world size 1 with backend
+"nccl" (= RCCL on ROCm), `force_collectives=True` so that exchange_chunked / start_factored_exchange take their collective branch
+instead of the world-size-1 short cut.  The all-reduces / all-gathers then really run as RCCL work on the communicator's streams
+beside the ctypes-launched kernels on torch's current stream — in-place all-reduces of packed[lo:hi] while the next produce()
+writes the neighbouring rows, the per-range dL/dSH rebuilds waiting on their all-gathers.  Results must equal the one-call
+backward BIT FOR BIT (one rank: every sum has a single term).  Reference behaviour replaced: Lightning DDP's gradient all-reduce,
+/root/reference/src/main.py:117-130.
+
+    python scripts/rccl_single_rank.py            # prints "rccl single rank ok ..."
+    rocprofv3 --kernel-trace --stats -d <dir> -- python scripts/rccl_single_rank.py     # the trace kept under profiles/
+"""
+import os
+import socket
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path[:0] = [str(ROOT), str(ROOT / "tests")]
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def main():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+    from splatter360_amd import distributed as D
+    from test_gpu_factored_sync import POSITIONS, _cloud, _render_backward
+    dev = torch.device("cuda:0")
+    w = int(os.environ.get("S360_RCCL_TEST_W", "128"))
+    ps = _cloud(dev, w=w)
+    _render_backward(dev, ps, POSITIONS[1], 5, False)
+    want = [p.grad.clone() for p in ps]
+    checked = 0
+    for n_chunks in (1, 3, 7):          # 7: ragged, uneven Gaussian ranges
+        for rep in range(3):            # repeated: a stream-ordering bug shows up as run-to-run differences
+            for p in ps:
+                p.grad = None
+            _render_backward(dev, ps, POSITIONS[1], 5, False, exchange=D.ExchangeConfig(n_chunks=n_chunks, force_collectives=True))
+            for p, g in zip(ps, want):
+                assert torch.equal(p.grad, g), (n_chunks, rep)
+            checked += 1
+    # a second communicator for the all-gathers (they then do not queue behind earlier ranges' all-reduces)
+    gg = dist.new_group(ranks=[0], backend="nccl")
+    for p in ps:
+        p.grad = None
+    _render_backward(dev, ps, POSITIONS[1], 5, False, exchange=D.ExchangeConfig(n_chunks=4, group_gather=gg, force_collectives=True))
+    for p, g in zip(ps, want):
+        assert torch.equal(p.grad, g)
+    # frozen harmonics: only the packed all-reduces run
+    ps2 = [ps[0], ps[1], ps[2].detach(), ps[3]]
+    for p in ps:
+        p.grad = None
+    _render_backward(dev, ps2, POSITIONS[1], 5, False, exchange=D.ExchangeConfig(n_chunks=3, force_collectives=True))
+    for i in (0, 1, 3):
+        assert torch.equal(ps[i].grad, want[i])
+    # the one-exchange-per-step form (start / finish around other work)
+    for p in ps:
+        p.grad = None
+    d = _render_backward(dev, ps, POSITIONS[1], 5, True)
+    ex = D.start_factored_exchange(*ps, d, force_collectives=True)
+    assert ex.works_ag and ex.work_ar is not None       # the collectives were really issued
+    junk = torch.randn(1 << 20, device=dev).sum()        # compute-stream work between start and finish
+    got = ex.finish()
+    for g, wgt in zip(got, want):
+        assert (g.reshape(wgt.shape) - wgt).abs().max().item() <= 1e-6 * (wgt.abs().max().item() + 1e-20)
+    torch.cuda.synchronize()
+    float(junk)
+    print(f"rccl single rank ok: backend {dist.get_backend()} world {dist.get_world_size()} gaussians {ps[0].shape[0]} "
+          f"chunked runs {checked + 2} bit-identical, factored start/finish within 1e-6", flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -592,6 +592,7 @@ struct BwdCtx {
     uint32_t* valid_words;
     uint32_t* order;
     float4* pairgrad;
+    uint32_t* seg_list;   // S360_FLAG_SPLIT_LISTS: [0] = count, then the segment units that hold survivor records
 };
 
 static int bwd_ctx(const S360Params* prm, const void* workspace, size_t workspace_bytes, void* bwd_workspace,
@@ -620,6 +621,11 @@ static int bwd_ctx(const S360Params* prm, const void* workspace, size_t workspac
         c.order = c.valid_words + kp.cap;
     }
     c.pairgrad = (float4*)((char*)(c.order + c.nt * 4) + 256 - ((uintptr_t)(c.order + c.nt * 4) & 255));
+    c.seg_list = nullptr;
+    if (kp.flags & S360_FLAG_SPLIT_LISTS) {   // behind the pair records and the [P] summed dL/dRGB
+        char* e = (char*)(c.pairgrad + (size_t)kp.V * (kp.P > 0 ? kp.P : 1) * 3 + (size_t)(kp.P > 0 ? kp.P : 1));
+        c.seg_list = (uint32_t*)(e + 256 - ((uintptr_t)e & 255));
+    }
     return S360_OK;
 }
 
@@ -636,7 +642,20 @@ static int backward_composite(const BwdCtx& c, const S360View* views, const void
     {
         ProfScope ps(PS_ORDER, st);
         hipLaunchKernelGGL(k_order_units, dim3(1 + 512), dim3(1024), 0, st, surv_count, c.order, c.nt * 4, c.valid_words, header, kp.cap,
-                           (kp.flags & S360_FLAG_ATOMIC_GRADS) ? c.pairgrad : (float4*)nullptr, (const uint8_t*)(ws + L.vis_mask), kp.P, kp.V);
+                           (kp.flags & S360_FLAG_ATOMIC_GRADS) ? c.pairgrad : (float4*)nullptr, (const uint8_t*)(ws + L.vis_mask), kp.P, kp.V,
+                           (const uint32_t*)(ws + L.seg_cnt), (const uint32_t*)(ws + L.chunk_start) + c.nt, c.seg_list);
+    }
+    SegBwd sb{};
+    if (c.seg_list) {
+        sb.seg_flag = (const uint32_t*)(ws + L.seg_flag);
+        sb.chunk_start = (const uint32_t*)(ws + L.chunk_start);
+        sb.seg_c = (const float4*)(ws + L.seg_c);
+        sb.seg_t = (const float*)(ws + L.seg_t);
+        sb.seg_cnt = (const uint32_t*)(ws + L.seg_cnt);
+        sb.seg_info = (const uint2*)(ws + L.seg_info);
+        sb.seg_list = c.seg_list;
+        sb.n_seg_blocks = (uint32_t)min((size_t)1024, seg_slots(kp.cap) * 4);
+        sb.dbg_base = (uint32_t)c.nt * 4u;
     }
     {
         ProfScope ps(PS_RENDER_BWD, st);
@@ -646,9 +665,9 @@ static int backward_composite(const BwdCtx& c, const S360View* views, const void
                              dL_ddepth, c.part, (uint8_t*)c.valid_words, c.order, depth_mode,
                              (kp.flags & S360_FLAG_ATOMIC_GRADS) ? (float*)c.pairgrad : (float*)nullptr,
 #ifdef S360_DBG_TIMING
-                             (uint32_t*)(ws + L.keys_alt));  // the forward's merge buffer is free by now
+                             (uint32_t*)(ws + L.keys_alt), sb);  // the forward's merge buffer is free by now
 #else
-                             (uint32_t*)nullptr);
+                             (uint32_t*)nullptr, sb);
 #endif
     }
     S360_CHECK_LAUNCH();
@@ -823,22 +842,29 @@ namespace s360 {
 // pixels), out[2] += survivor records (all).  bench.py turns these into the work-based VALU figure next to the issue-rate one.
 __global__ __launch_bounds__(64) void k_count_pairs(KParams kp, const uint32_t* __restrict__ tile_start, const float4* __restrict__ surv,
                                                    const uint32_t* __restrict__ surv_count, const uint32_t* __restrict__ n_contrib,
-                                                   unsigned long long* __restrict__ out) {
+                                                   unsigned long long* __restrict__ out, const uint32_t* __restrict__ seg_flag,
+                                                   const uint32_t* __restrict__ chunk_start, const uint32_t* __restrict__ seg_cnt) {
     __shared__ uint32_t s_last[64];
     const uint32_t unit = blockIdx.x;
-    const uint32_t n_surv = surv_count[unit];
     const int t = (int)(unit >> 2), wave = (int)(unit & 3u), lane = threadIdx.x;
     const int v = t / kp.T, rem = t - v * kp.T;
     const int ty = rem / kp.gx, tx = rem - ty * kp.gx;
     const int qx = tx * 16 + sub_ox(wave), qy = ty * 16 + sub_oy(wave);
     const uint32_t start = min(tile_start[t], kp.cap), end = min(tile_start[t + 1], kp.cap);
-    const float4* const sv = surv + 3 * ((size_t)4 * start + (size_t)wave * (end - start));
     {
         const int px = qx + (lane & 7), py = qy + (lane >> 3);
         s_last[lane] = (px < kp.W && py < kp.H) ? n_contrib[((size_t)v * kp.H + py) * kp.W + px] : 0u;
     }
     __syncthreads();
     uint32_t cnt = 0;
+    unsigned long long evaluated = 0ull;
+    // a split quadrant (S360_FLAG_SPLIT_LISTS): its head, then every segment's own records
+    const bool split = seg_flag && seg_flag[unit] == 1u;
+    const uint32_t nseg = split ? (end - start + SEG_LEN - 1) / SEG_LEN : 1u;
+  for (uint32_t ks = 0; ks < nseg; ks = ks ? ks + 1 : (split ? SEG_K0 : 1u)) {
+    const uint32_t n_surv = ks == 0 ? surv_count[unit] : seg_cnt[((size_t)SEG_PER_CHUNK * chunk_start[t] + ks) * 4 + wave];
+    const float4* const sv = surv + 3 * ((size_t)4 * start + (size_t)wave * (end - start) + (size_t)ks * SEG_LEN);
+    evaluated += (unsigned long long)n_surv * 64ull;
     for (uint32_t g0 = 0; g0 < n_surv; g0 += 64) {
         const bool ok = g0 + lane < n_surv;
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, c = a;
@@ -854,11 +880,12 @@ __global__ __launch_bounds__(64) void k_count_pairs(KParams kp, const uint32_t* 
             cnt += (pos < s_last[p] && !(power > 0.0f) && !(alpha < 1.0f / 255.0f)) ? 1u : 0u;
         }
     }
+  }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, o);
     if (lane == 0) {
         atomicAdd(&out[0], (unsigned long long)cnt);
-        atomicAdd(&out[1], (unsigned long long)n_surv * 64ull);
+        atomicAdd(&out[1], evaluated);
     }
 }
 
@@ -909,8 +936,11 @@ extern "C" int s360_count_contributions(const S360Params* prm, const void* works
     hipStream_t st = (hipStream_t)stream_;
     if (hipMemsetAsync(counts, 0, 2 * sizeof(uint64_t), st) != hipSuccess) return S360_E_LAUNCH;
     if (prm->P == 0) return S360_OK;
+    const bool split = (kp.flags & S360_FLAG_SPLIT_LISTS) != 0;
     hipLaunchKernelGGL(s360::k_count_pairs, dim3(nt * 4), dim3(64), 0, st, kp, (const uint32_t*)(ws + L.tile_start), (const float4*)(ws + L.surv),
-                       (const uint32_t*)(ws + L.surv_count), (const uint32_t*)(ws + L.n_contrib), (unsigned long long*)counts);
+                       (const uint32_t*)(ws + L.surv_count), (const uint32_t*)(ws + L.n_contrib), (unsigned long long*)counts,
+                       split ? (const uint32_t*)(ws + L.seg_flag) : (const uint32_t*)nullptr, (const uint32_t*)(ws + L.chunk_start),
+                       (const uint32_t*)(ws + L.seg_cnt));
     S360_CHECK_LAUNCH();
     return S360_OK;
 }

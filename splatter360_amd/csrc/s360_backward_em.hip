@@ -9,13 +9,13 @@ void launch_render_bwd_em(bool with_depth, int n_units, hipStream_t st, const KP
                           const uint32_t* tile_start, const float4* surv, const uint32_t* surv_count, const uint2* slot_info,
                           const float* depths, const float* final_T, const uint32_t* n_contrib, const float* dL_dimages,
                           const float* dL_dimages_scale, const float* dL_ddepth, float4* part, uint8_t* valid, const uint32_t* order, int depth_mode,
-                          float* pairgrad_atomic, uint32_t* dbg) {
+                          float* pairgrad_atomic, uint32_t* dbg, const SegBwd& sb) {
     if (with_depth)
-        hipLaunchKernelGGL(k_render_bwd_em<true>, dim3(n_units), dim3(64), 0, st, kp, views, tile_start, surv, surv_count, slot_info,
-                           depths, final_T, n_contrib, dL_dimages, dL_dimages_scale, dL_ddepth, part, valid, order, depth_mode, pairgrad_atomic, dbg);
+        hipLaunchKernelGGL(k_render_bwd_em<true>, dim3(n_units + sb.n_seg_blocks), dim3(64), 0, st, kp, views, tile_start, surv, surv_count, slot_info,
+                           depths, final_T, n_contrib, dL_dimages, dL_dimages_scale, dL_ddepth, part, valid, order, depth_mode, pairgrad_atomic, dbg, sb);
     else
-        hipLaunchKernelGGL(k_render_bwd_em<false>, dim3(n_units), dim3(64), 0, st, kp, views, tile_start, surv, surv_count, slot_info,
-                           depths, final_T, n_contrib, dL_dimages, dL_dimages_scale, dL_ddepth, part, valid, order, depth_mode, pairgrad_atomic, dbg);
+        hipLaunchKernelGGL(k_render_bwd_em<false>, dim3(n_units + sb.n_seg_blocks), dim3(64), 0, st, kp, views, tile_start, surv, surv_count, slot_info,
+                           depths, final_T, n_contrib, dL_dimages, dL_dimages_scale, dL_ddepth, part, valid, order, depth_mode, pairgrad_atomic, dbg, sb);
 }
 
 }  // namespace s360

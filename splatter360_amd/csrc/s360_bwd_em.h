@@ -94,6 +94,22 @@ __device__ __forceinline__ float depth_value_grad(float z, float nearp, float fa
     return 1.0f;
 }
 
+// S360_FLAG_SPLIT_LISTS (include/s360.h): the forward composited the rest of a long list in segments and left, per (segment slot,
+// quadrant, pixel), the transmittance behind the segment (seg_t) and the colour accumulated behind it (seg_c).  The backward replays
+// the head and every segment as INDEPENDENT units from those two: same entry-major arithmetic per unit, the per-pixel running state
+// (T behind, colour behind) starts from the forward's values instead of (final_T, 0).
+struct SegBwd {
+    const uint32_t* seg_flag;     // null: the call was rendered without the flag
+    const uint32_t* chunk_start;
+    const float4* seg_c;
+    const float* seg_t;
+    const uint32_t* seg_cnt;
+    const uint2* seg_info;
+    const uint32_t* seg_list;     // [0] = number of segment units with survivor records, then their ids (slot * 4 + quadrant)
+    uint32_t n_seg_blocks;        // the launch's first n_seg_blocks workgroups take the segment units (grid-stride over seg_list)
+    uint32_t dbg_base;            // S360_DBG_TIMING: first timing record of the segment units
+};
+
 #ifdef S360_EM_KERNEL_TU
 template <bool WITH_DEPTH>
 __global__ __launch_bounds__(64) void k_render_bwd_em(
@@ -103,10 +119,7 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
     const float* __restrict__ dL_dimages, const float* __restrict__ dL_dimages_scale, const float* __restrict__ dL_ddepth,
     float4* __restrict__ part,
     uint8_t* __restrict__ valid, const uint32_t* __restrict__ order, int depth_mode, float* __restrict__ pairgrad_atomic,
-    uint32_t* __restrict__ dbg) {
-#ifdef S360_DBG_TIMING
-    const long long t_begin = wall_clock64();
-#endif
+    uint32_t* __restrict__ dbg, SegBwd sb) {
     static_assert(SUB_W == 8, "entry-major backward assumes 8x8 quadrants");
     // per-pixel tables, one array per quantity (pixel-contiguous: a 16-byte read hands a four-pixel run to the lanes as two
     // register PAIRS — the operands of the packed v_pk_* arithmetic below)
@@ -115,15 +128,40 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
     __shared__ __attribute__((aligned(16))) float s_B[64];           // T_final * (bg . dL/dpixel)
     __shared__ __attribute__((aligned(16))) uint32_t s_last[64];     // n_contrib
 
-    const uint32_t unit = order ? order[blockIdx.x] : blockIdx.x;  // tile*4 + quadrant
-    const uint32_t n_surv = surv_count[unit];  // survivor records in front of the quadrant's last contributor
-    if (n_surv == 0) return;                   // nothing reaches any pixel of this quadrant
-    const int t = (int)(unit >> 2), wave = (int)(unit & 3u), lane = threadIdx.x;
+    const bool seg_blk = blockIdx.x < sb.n_seg_blocks;   // segment units of split quadrants first: they are the heavy ones
+    const int lane = threadIdx.x;
+  for (uint32_t sj = blockIdx.x;; sj += sb.n_seg_blocks) {     // one unit per workgroup, except the segment workgroups (grid-stride)
+#ifdef S360_DBG_TIMING
+    const long long t_begin = wall_clock64();
+#endif
+    uint32_t unit, n_surv, kseg = 0;
+    bool split_unit = false;
+    size_t sli = 0;     // split units: index of this (slot, quadrant)'s pixel 0 in seg_c / seg_t
+    if (seg_blk) {
+        if (sj >= sb.seg_list[0]) return;
+        const uint32_t su = sb.seg_list[1 + sj];          // slot * 4 + quadrant
+        const uint2 info = sb.seg_info[su >> 2];           // (tile, segment)
+        unit = 4u * info.x + (su & 3u);
+        kseg = info.y;
+        n_surv = sb.seg_cnt[su];
+        split_unit = true;
+        sli = (size_t)su * 64;
+    } else {
+        unit = order ? order[blockIdx.x - sb.n_seg_blocks] : blockIdx.x - sb.n_seg_blocks;  // tile*4 + quadrant
+        n_surv = surv_count[unit];  // survivor records in front of the quadrant's last contributor
+        if (n_surv == 0) return;    // nothing reaches any pixel of this quadrant
+        if (sb.seg_flag && sb.seg_flag[unit] == 1u) {   // the head of a split quadrant
+            split_unit = true;
+            sli = ((size_t)SEG_PER_CHUNK * sb.chunk_start[unit >> 2] * 4 + (unit & 3u)) * 64;
+        }
+    }
+    const int t = (int)(unit >> 2), wave = (int)(unit & 3u);
     const int v = t / kp.T, rem = t - v * kp.T;
     const int ty = rem / kp.gx, tx = rem - ty * kp.gx;
     const int qx = tx * 16 + sub_ox(wave), qy = ty * 16 + sub_oy(wave);
     const uint32_t start = min(tile_start[t], kp.cap), end = min(tile_start[t + 1], kp.cap);
-    const float4* const sv = surv + 3 * ((size_t)4 * start + (size_t)wave * (end - start));  // this unit's records
+    // this unit's records (a segment's start at its first list position: at most one record per entry in front of it)
+    const float4* const sv = surv + 3 * ((size_t)4 * start + (size_t)wave * (end - start) + (size_t)kseg * SEG_LEN);
     const S360View& vw = views[view_of_image(kp, v)];  // v = image index
 
     // the first group's records: in flight while the pixel tables are set up
@@ -152,10 +190,17 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
             if (WITH_DEPTH) pa.w = dL_ddepth[(size_t)v * hw + pix];  // depth background is 0: no background term
             pb.x = T_final;
             pb.z = T_final * (vw.bg[0] * pa.x + vw.bg[1] * pa.y + vw.bg[2] * pa.z);
+            if (split_unit) {   // wave-uniform: start behind this unit's backmost entry, not behind the whole list
+                const float4 cb = sb.seg_c[sli + lane];
+                pb.x = sb.seg_t[sli + lane];
+                float r0 = cb.z * pa.z + (cb.y * pa.y + cb.x * pa.x);
+                if (WITH_DEPTH) r0 = cb.w * pa.w + r0;
+                pb.y = r0;      // colour (. dL/dpixel) behind the unit
+            }
         }
         s_gr[lane] = pa.x; s_gg[lane] = pa.y; s_gb[lane] = pa.z;
         if (WITH_DEPTH) s_gd[lane] = pa.w;
-        s_T[lane] = pb.x; s_R[lane] = 0.f; s_B[lane] = pb.z;
+        s_T[lane] = pb.x; s_R[lane] = pb.y; s_B[lane] = pb.z;
         s_last[lane] = last;
     }
     f2 pxc[4];  // pixel-centre x of the row's four pixel pairs
@@ -341,12 +386,15 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
     }
 #ifdef S360_DBG_TIMING
     if (lane == 0 && dbg) {  // per-unit (start, duration) in 100-MHz ticks + replay length (scripts/bwdtiming.py)
-        dbg[4 * unit] = (uint32_t)t_begin;
-        dbg[4 * unit + 1] = (uint32_t)(wall_clock64() - t_begin);
-        dbg[4 * unit + 2] = n_surv;
-        dbg[4 * unit + 3] = (dbg_halves << 16) | min(n_surv, 65535u);
+        const size_t di = seg_blk ? (size_t)sb.dbg_base + sb.seg_list[1 + sj] : (size_t)unit;
+        dbg[4 * di] = (uint32_t)t_begin;
+        dbg[4 * di + 1] = (uint32_t)(wall_clock64() - t_begin);
+        dbg[4 * di + 2] = n_surv;
+        dbg[4 * di + 3] = (dbg_halves << 16) | min(n_surv, 65535u);
     }
 #endif
+    if (!seg_blk) return;
+  }
 }
 #endif  // S360_EM_KERNEL_TU
 
@@ -357,6 +405,6 @@ void launch_render_bwd_em(bool with_depth, int n_units, hipStream_t st, const KP
                           const uint32_t* tile_start, const float4* surv, const uint32_t* surv_count, const uint2* slot_info,
                           const float* depths, const float* final_T, const uint32_t* n_contrib, const float* dL_dimages,
                           const float* dL_dimages_scale, const float* dL_ddepth, float4* part, uint8_t* valid, const uint32_t* order, int depth_mode,
-                          float* pairgrad_atomic, uint32_t* dbg);
+                          float* pairgrad_atomic, uint32_t* dbg, const SegBwd& sb);
 
 }  // namespace s360

@@ -47,6 +47,15 @@ struct KParams {
     uint32_t flags, cap;
 };
 
+// S360_FLAG_SPLIT_LISTS (include/s360.h): an 8x8 quadrant that is still busy after the first SEG_HEAD entries of a tile list with
+// at least SEG_MIN_REST more hands the rest over in segments of SEG_LEN entries (k_render_tail), one wave each.  Segment k covers
+// list positions [SEG_LEN k, SEG_LEN (k + 1)); its slot is SEG_PER_CHUNK * chunk_start[tile] + k (chunk_start: the sort's table of
+// 4 096-key chunks of the lists beyond 2 048 keys — every list that can split has chunks).
+constexpr uint32_t SEG_LEN = 1024, SEG_HEAD = 2048, SEG_MIN_REST = 1024, SEG_PER_CHUNK = 4;
+constexpr uint32_t SEG_K0 = SEG_HEAD / SEG_LEN;   // first segment index a segment wave takes
+__host__ __device__ inline size_t seg_slots(size_t cap) { return (size_t)SEG_PER_CHUNK * (cap / 2048 + 1); }
+#define S360_HDR_SPLIT 5   /* header word: split (tile, quadrant) units of this call */
+
 // Real-SH constants (degree <= 3: public 3DGS table; degree 4: standard real-SH table).
 __device__ constexpr float kC0 = 0.28209479177387814f;
 __device__ constexpr float kC1 = 0.4886025119029199f;
@@ -617,7 +626,23 @@ __device__ __forceinline__ void mse_finish_body(const float* __restrict__ partia
 static __global__ __launch_bounds__(1024) void k_order_units(const uint32_t* __restrict__ weight, uint32_t* __restrict__ order, int n,
                                                      uint32_t* __restrict__ valid_words, const uint32_t* __restrict__ header,
                                                      uint32_t cap, float4* __restrict__ pairgrad_atomic,
-                                                     const uint8_t* __restrict__ vis_mask, int P, int V) {
+                                                     const uint8_t* __restrict__ vis_mask, int P, int V,
+                                                     const uint32_t* __restrict__ seg_cnt, const uint32_t* __restrict__ n_chunks,
+                                                     uint32_t* __restrict__ seg_list) {
+    if (blockIdx.x == 2 && seg_list) {
+        // S360_FLAG_SPLIT_LISTS: the segment units that hold survivor records, compacted (any order: every unit is self-contained) —
+        // the backward composite's first workgroups take them grid-stride
+        __shared__ uint32_t s_n;
+        if (threadIdx.x == 0) s_n = 0u;
+        __syncthreads();
+        if (header[S360_HDR_SPLIT] != 0u) {   // else the forward's k_render_tail returned at once and seg_cnt was never written
+            const uint32_t n = SEG_PER_CHUNK * n_chunks[0] * 4u;
+            for (uint32_t i = threadIdx.x; i < n; i += 1024)
+                if (seg_cnt[i]) seg_list[1u + atomicAdd(&s_n, 1u)] = i;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) seg_list[0] = s_n;
+    }
     if (blockIdx.x == 1) {   // S360_FLAG_DEFER_LOSS: the forward left its loss reduction to this launch
         const uint64_t pp = (uint64_t)header[S360_HDR_LOSS] | ((uint64_t)header[S360_HDR_LOSS + 1] << 32);
         const uint64_t po = (uint64_t)header[S360_HDR_LOSS + 2] | ((uint64_t)header[S360_HDR_LOSS + 3] << 32);

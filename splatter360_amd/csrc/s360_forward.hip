@@ -564,7 +564,7 @@ constexpr int TS_BLOCK = 1024;  // one workgroup; 16 waves: 1 536 tiles in two s
 __global__ __launch_bounds__(TS_BLOCK) void k_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_start,
                                                          uint32_t* __restrict__ tile_cursor, uint32_t* __restrict__ tile_max_contrib,
                                                          int nt, uint32_t cap, uint32_t* __restrict__ header,
-                                                         uint32_t* __restrict__ chunk_start) {
+                                                         uint32_t* __restrict__ chunk_start, unsigned long long* __restrict__ header_mirror) {
     __shared__ uint32_t lds[TS_BLOCK / 64];
     __shared__ uint32_t lds_max;
     if (threadIdx.x == 0) lds_max = 0;
@@ -604,6 +604,12 @@ __global__ __launch_bounds__(TS_BLOCK) void k_tile_scan(const uint32_t* __restri
             header[3] = nch <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(nch - 1);
         }
         header[4] = 0;                        // pairs with more than 32 instance slots (k_emit counts and lists them)
+        header[S360_HDR_SPLIT] = 0;           // split (tile, quadrant) units (k_render counts them)
+        header[6] = header[7] = 0;
+        // S360Params.header_mirror: the count and the overflow flag as ONE 64-bit store into host-visible memory — the caller's
+        // next call sizes its buffers from it without ever synchronising with the device
+        if (header_mirror) __hip_atomic_store(header_mirror, (unsigned long long)carry | ((unsigned long long)(carry > cap ? 1u : 0u) << 32),
+                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         for (int i = 8; i < 24; ++i) header[i] = 0;  // debug counters; [16, 24): deferred-loss hand-over (S360_HDR_LOSS), set by k_render
     }
 }
@@ -1157,6 +1163,22 @@ __global__ __launch_bounds__(MSE_BLOCK) void k_mse_finish(const float* __restric
     mse_finish_body(partials, n_per_view, V, loss_scale, inv_elems, out);
 }
 
+// S360_FLAG_SPLIT_LISTS state (S360Layout part_* / seg_*), by value into the composites
+struct SegBufs {
+    const uint32_t* chunk_start;  // null: splitting off
+    uint32_t* seg_flag;
+    uint32_t* seg_arrive;
+    float4* part_c;
+    float* part_t;
+    uint32_t* part_l;
+    uint32_t* part_n;
+    float4* seg_c;
+    float* seg_t;
+    uint32_t* seg_cnt;
+    uint2* seg_info;
+    uint32_t* header;
+};
+
 template <bool WITH_DEPTH>
 __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_render(KParams kp, const S360View* __restrict__ views,
                                                       const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ list,
@@ -1167,7 +1189,7 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
                                                       uint32_t* __restrict__ dbg, const float* __restrict__ depths,
                                                       float* __restrict__ depth_maps, int depth_mode, MseEp ep,
                                                       const uint32_t* __restrict__ tile_order, float4* __restrict__ surv,
-                                                      uint32_t* __restrict__ surv_count, uint32_t* __restrict__ hdr_loss) {
+                                                      uint32_t* __restrict__ surv_count, uint32_t* __restrict__ hdr_loss, SegBufs sg) {
 #ifdef S360_DBG_TIMING
     const long long t_begin = wall_clock64();
 #endif
@@ -1181,6 +1203,18 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
     // tiles are dealt longest list first (LPT: the sequential per-pixel chains of the long polar lists would
     // otherwise form the tail of the kernel): 249 -> 224 us.  (Single-wave workgroups per (tile, quadrant), as in
     // the backward, bring nothing more here: 229 us.)
+    if (hdr_loss && blockIdx.x == 0 && threadIdx.x == 0) {
+        // S360_FLAG_DEFER_LOSS: where the loss reduction goes, for the backward's first launch (k_order_units)
+        const uint64_t pp = (uint64_t)(uintptr_t)ep.partials, po = (uint64_t)(uintptr_t)ep.loss_out;
+        hdr_loss[0] = (uint32_t)pp; hdr_loss[1] = (uint32_t)(pp >> 32);
+        hdr_loss[2] = (uint32_t)po; hdr_loss[3] = (uint32_t)(po >> 32);
+        hdr_loss[4] = (uint32_t)(kp.T * 4); hdr_loss[5] = (uint32_t)kp.V;
+        hdr_loss[6] = __float_as_uint(0.5f * ep.grad_scale);
+        hdr_loss[7] = __float_as_uint(1.0f / (3.0f * (float)kp.H * (float)kp.W));
+        // until the backward has reduced them, loss / clipped MSE read as NaN — a premature read (a NaN guard, a logger, Lightning's
+        // returned loss) is then visibly wrong instead of uninitialised memory (ADVICE r04)
+        for (int i = 0; i <= kp.V; ++i) ep.loss_out[i] = __uint_as_float(0x7FC00000u);
+    }
     const int t = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;
     // (s_setprio by launch-order quartile — the longest lists take the SIMD's issue slots first, all 6 144 waves being resident at
     // once — measured no change: 141.5 vs 141.8 us; the slowest waves are ordinary tiles whose pixels never saturate.)
@@ -1222,9 +1256,16 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
         nc = recA[3 * (size_t)(p_n1) + 2];
         if (WITH_DEPTH) nz = depths[p_n1];
     }
+    // S360_FLAG_SPLIT_LISTS: where this quadrant may hand the rest of its list over to segment waves (k_render_tail)
+    const uint32_t split_at = (sg.chunk_start && end - start >= SEG_HEAD + SEG_MIN_REST) ? start + SEG_HEAD : 0xFFFFFFFFu;
+    bool went = false;
     for (uint32_t b = start; b < end; b += 64) {
         const unsigned long long act = __ballot(!done);
         if (act == 0ull) break;
+        if (b == split_at && __popcll(act) > SPARSE_PIXELS) {   // wave-uniform: still busy after SEG_HEAD entries, >= SEG_MIN_REST to go
+            went = true;
+            break;
+        }
         const float4 ea = na, eb = nb;
         // fused depth "colour" of this lane's entry: camera z in unscaled units, then the reference's mode
         float ez = 0.f;
@@ -1381,6 +1422,33 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
             scount += (uint32_t)__popcll(m);
         }
     }
+    if (went) {
+        // The exact sequential state of this quadrant after SEG_HEAD entries, per pixel, in slot k = 0 of the tile; the segment
+        // waves of k_render_tail (next launch) composite [SEG_HEAD, end) in parallel and the last of them to finish combines,
+        // replays where a pixel's stop test can trip, and writes the pixels.
+        const size_t slot = (size_t)SEG_PER_CHUNK * sg.chunk_start[t];
+        const size_t li = (slot * 4 + wave) * 64 + lane;
+        sg.part_c[li] = make_float4(C01.x, C01.y, C2D.x, C2D.y);
+        sg.part_t[li] = T;
+        sg.part_l[li] = last | (done ? 0x80000000u : 0u);
+        const uint32_t wmh = wave_max_u32(inside ? last : 0u);
+        if (lane == 0) {
+            sg.part_n[slot * 4 + wave] = scount;        // survivor records of the head
+            // ... and how many of them lie in front of the head's last contributor (what the backward replays if no segment adds one)
+            sg.part_n[(slot + 1) * 4 + wave] = wmh ? sv_cnt + (uint32_t)__popcll(sv_m & ((2ull << (wmh - 1u - sv_rel)) - 1ull)) : 0u;
+            sg.seg_flag[4 * t + wave] = 1u;
+            atomicAdd(&sg.header[S360_HDR_SPLIT], 1u);
+        }
+#ifdef S360_DBG_TIMING
+        if (lane == 0) {
+            dbg[4 * (4 * t + wave)] = (uint32_t)t_begin;
+            dbg[4 * (4 * t + wave) + 1] = (uint32_t)(wall_clock64() - t_begin);
+            dbg[4 * (4 * t + wave) + 2] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+            dbg[4 * (4 * t + wave) + 3] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);
+        }
+#endif
+        return;
+    }
     float sq = 0.f, sqc = 0.f;
     if (inside) {
         const S360View& vw = views[vcam];
@@ -1416,18 +1484,6 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
             ep.partials[2 * (4 * (size_t)t + wave) + 1] = s1;
         }
     }
-    if (hdr_loss && blockIdx.x == 0 && threadIdx.x == 0) {
-        // S360_FLAG_DEFER_LOSS: where the loss reduction goes, for the backward's first launch (k_order_units)
-        const uint64_t pp = (uint64_t)(uintptr_t)ep.partials, po = (uint64_t)(uintptr_t)ep.loss_out;
-        hdr_loss[0] = (uint32_t)pp; hdr_loss[1] = (uint32_t)(pp >> 32);
-        hdr_loss[2] = (uint32_t)po; hdr_loss[3] = (uint32_t)(po >> 32);
-        hdr_loss[4] = (uint32_t)(kp.T * 4); hdr_loss[5] = (uint32_t)kp.V;
-        hdr_loss[6] = __float_as_uint(0.5f * ep.grad_scale);
-        hdr_loss[7] = __float_as_uint(1.0f / (3.0f * (float)kp.H * (float)kp.W));
-        // until the backward has reduced them, loss / clipped MSE read as NaN — a premature read (a NaN guard, a logger, Lightning's
-        // returned loss) is then visibly wrong instead of uninitialised memory (ADVICE r04)
-        for (int i = 0; i <= kp.V; ++i) ep.loss_out[i] = __uint_as_float(0x7FC00000u);
-    }
     const uint32_t wm = wave_max_u32(inside ? last : 0u);
     if (lane == 0) {
         strip_last[4 * t + wave] = wm;  // per-quadrant replay length (list positions)
@@ -1444,6 +1500,358 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
         dbg[4 * (4 * t + wave) + 3] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);  // HW_REG_XCC_ID
     }
 #endif
+}
+
+
+// ------------------------------------------------------------------------------ split lists: segment waves + combine
+// S360_FLAG_SPLIT_LISTS, second launch of the composite.  k_render left, for every split (tile, quadrant), the exact per-pixel state
+// after SEG_HEAD entries.  Here one wave per (tile, quadrant, segment k >= SEG_K0) composites list positions [SEG_LEN k, SEG_LEN (k+1))
+// from T = 1 with the same per-(pixel, entry) arithmetic as k_render — a pixel stops locally when ITS OWN product trips the 1e-4 test,
+// which implies the true one does — appends the segment's survivor records for the backward, and delivers (C_k, T_k, last_k, stopped)
+// per pixel.  The wave that delivers last (device-coherent stores, drained, then one agent-scope counter) combines, per pixel and in
+// list order:  a pixel that cannot stop inside segment k (not stopped locally and T T_k >= 1.001e-4) takes the segment as a block,
+// C += T C_k, T *= T_k; any other pixel REPLAYS the segment from its exact incoming T with the sequential rule (so the stop decision,
+// n_contrib and final_T are those of a front-to-back walk; what differs from it is floating-point association: a block is a sum of
+// products formed from 1 instead of from T).  The combine leaves, for the backward, the transmittance behind every segment and the
+// colour accumulated behind it, writes the pixels exactly like k_render's epilogue and sizes the backward's units.
+__device__ __forceinline__ void st_dev32(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t ld_dev32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_devf(float* p, float v) { st_dev32(reinterpret_cast<uint32_t*>(p), __float_as_uint(v)); }
+__device__ __forceinline__ float ld_devf(const float* p) { return __uint_as_float(ld_dev32(reinterpret_cast<const uint32_t*>(p))); }
+
+struct WaveLds {   // one wave's slices of the compaction arrays (see k_render)
+    float *x, *y, *a, *b, *c, *o;
+    float2 *rg, *bz;
+    uint32_t* pos;
+};
+
+// k_render's chunk loop over list positions [b0, b1) of the tile that starts at `start` (b0 - start a multiple of 64), on the
+// running per-pixel state (T, C01, C2D, last, done); sv != null: survivor records appended at sv[3 (scount + rank)].
+template <bool WITH_DEPTH>
+__device__ __forceinline__ void composite_segment(const uint32_t* __restrict__ list, const float4* __restrict__ recA, const float* __restrict__ depths,
+                                                  uint32_t start, uint32_t b0, uint32_t b1, float pxf, float pyf, float x0, float ys0, int lane,
+                                                  const WaveLds& L, float inv_scale, float v_near, float v_far, int depth_mode, float& T, f2& C01,
+                                                  f2& C2D, uint32_t& last, bool& done, float4* sv, uint32_t& scount) {
+    uint32_t p_n1 = 0, p_n2 = 0;
+    if (b0 + lane < b1) p_n1 = list[b0 + lane];
+    if (b0 + 64 + lane < b1) p_n2 = list[b0 + 64 + lane];
+    float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na, nc = na;
+    float nz = 0.f;
+    if (b0 + lane < b1) {
+        na = recA[3 * (size_t)(p_n1)];
+        nb = recA[3 * (size_t)(p_n1) + 1];
+        nc = recA[3 * (size_t)(p_n1) + 2];
+        if (WITH_DEPTH) nz = depths[p_n1];
+    }
+    for (uint32_t b = b0; b < b1; b += 64) {
+        const unsigned long long act = __ballot(!done);
+        if (act == 0ull) break;
+        const float4 ea = na, eb = nb;
+        float ez = 0.f;
+        if (WITH_DEPTH) ez = depth_value(nz * inv_scale, v_near, v_far, depth_mode);
+        const float ec = nc.x, erad = nc.y, eka = nc.z, ekb = nc.w;
+        const bool ev = b + lane < b1;
+        const uint32_t epair = p_n1;
+        p_n1 = p_n2;
+        if (b + 64 + lane < b1) {
+            na = recA[3 * (size_t)(p_n1)];
+            nb = recA[3 * (size_t)(p_n1) + 1];
+            nc = recA[3 * (size_t)(p_n1) + 2];
+            if (WITH_DEPTH) nz = depths[p_n1];
+        }
+        if (b + 128 + lane < b1) p_n2 = list[b + 128 + lane];
+        const bool hit = ev && quadrant_hit(ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, eka, ekb, x0, ys0);
+        const unsigned long long m = __ballot(hit);
+        if (m == 0ull) continue;
+        const uint32_t rel = b - start;  // list position of this chunk's lane 0
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (sv && hit) {
+            float4* o = sv + 3 * (size_t)(scount + rank);
+            o[0] = ea;
+            o[1] = eb;
+            o[2] = make_float4(ec, erad, __uint_as_float(rel + (uint32_t)lane), __uint_as_float(epair));
+        }
+        scount += (uint32_t)__popcll(m);
+        if (__popcll(act) > SPARSE_PIXELS) {
+            const uint32_t cnt = (uint32_t)__popcll(m);
+            if (hit) {
+                L.x[rank] = ea.x; L.y[rank] = ea.y; L.a[rank] = ea.z; L.b[rank] = ea.w;
+                L.c[rank] = eb.x; L.o[rank] = eb.y;
+                L.rg[rank] = make_float2(eb.z, eb.w);
+                L.bz[rank] = make_float2(ec, ez);
+                L.pos[rank] = rel + (uint32_t)lane + 1u;
+            }
+            if (lane < 3) {  // null records: opacity 0
+                L.x[cnt + lane] = 0.f; L.y[cnt + lane] = 0.f; L.a[cnt + lane] = 0.f; L.b[cnt + lane] = 0.f;
+                L.c[cnt + lane] = 0.f; L.o[cnt + lane] = 0.f;
+                L.rg[cnt + lane] = make_float2(0.f, 0.f);
+                L.bz[cnt + lane] = make_float2(0.f, 0.f);
+                L.pos[cnt + lane] = 0u;
+            }
+            const f2 pxf2 = f2{pxf, pxf}, pyf2 = f2{pyf, pyf};
+            for (uint32_t i = 0; i < cnt; i += 4) {
+                const float4 vx = *reinterpret_cast<const float4*>(&L.x[i]), vy = *reinterpret_cast<const float4*>(&L.y[i]),
+                             va = *reinterpret_cast<const float4*>(&L.a[i]), vb = *reinterpret_cast<const float4*>(&L.b[i]),
+                             vc = *reinterpret_cast<const float4*>(&L.c[i]), vo = *reinterpret_cast<const float4*>(&L.o[i]);
+                const float4 rg01 = *reinterpret_cast<const float4*>(&L.rg[i]), rg23 = *reinterpret_cast<const float4*>(&L.rg[i + 2]);
+                const float4 bz01 = *reinterpret_cast<const float4*>(&L.bz[i]), bz23 = *reinterpret_cast<const float4*>(&L.bz[i + 2]);
+                const uint4 vp = *reinterpret_cast<const uint4*>(&L.pos[i]);
+                float al[4], om[4];
+                bool ok[4];
+                bool any_ok = false;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {  // entries 2j, 2j+1 as one register pair: k_render's operations in k_render's order
+                    const f2 X = j ? f2{vx.z, vx.w} : f2{vx.x, vx.y}, Y = j ? f2{vy.z, vy.w} : f2{vy.x, vy.y};
+                    const f2 A = j ? f2{va.z, va.w} : f2{va.x, va.y}, B = j ? f2{vb.z, vb.w} : f2{vb.x, vb.y};
+                    const f2 Cc = j ? f2{vc.z, vc.w} : f2{vc.x, vc.y}, O = j ? f2{vo.z, vo.w} : f2{vo.x, vo.y};
+                    const f2 dx = X - pxf2, dy = Y - pyf2;
+                    const f2 t = pk_fma(B, dy, A * dx);
+                    const f2 pw = pk_fma(t, dx, (Cc * dy) * dy);
+                    const f2 og = O * f2{__builtin_amdgcn_exp2f(pw.x), __builtin_amdgcn_exp2f(pw.y)};
+                    al[2 * j] = fminf(0.99f, og.x);
+                    al[2 * j + 1] = fminf(0.99f, og.y);
+                    const f2 o2 = f2{1.0f, 1.0f} - f2{al[2 * j], al[2 * j + 1]};
+                    om[2 * j] = o2.x;
+                    om[2 * j + 1] = o2.y;
+                    ok[2 * j] = !done && !(pw.x > 0.0f) && !(al[2 * j] < 1.0f / 255.0f);
+                    ok[2 * j + 1] = !done && !(pw.y > 0.0f) && !(al[2 * j + 1] < 1.0f / 255.0f);
+                    any_ok = any_ok || ok[2 * j] || ok[2 * j + 1];
+                }
+                if (__ballot(any_ok) == 0ull) continue;  // wave-uniform
+                const f2 rg[4] = {f2{rg01.x, rg01.y}, f2{rg01.z, rg01.w}, f2{rg23.x, rg23.y}, f2{rg23.z, rg23.w}};
+                const f2 bz[4] = {f2{bz01.x, bz01.y}, f2{bz01.z, bz01.w}, f2{bz23.x, bz23.y}, f2{bz23.z, bz23.w}};
+                const uint32_t posk[4] = {vp.x, vp.y, vp.z, vp.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool v = ok[e] && !done;
+                    const float test_T = T * om[e];
+                    const bool stop = v && test_T < 0.0001f;
+                    const bool contrib = v && !stop;
+                    done = done || stop;
+                    const float w = contrib ? al[e] * T : 0.0f;
+                    const f2 w2 = f2{w, w};
+                    C01 = C01 + rg[e] * w2;
+                    if (WITH_DEPTH) C2D = C2D + bz[e] * w2;
+                    else C2D.x = C2D.x + bz[e].x * w;
+                    T = contrib ? test_T : T;
+                    last = contrib ? posk[e] : last;
+                }
+            }
+        } else {
+            unsigned long long am = act;
+            while (am) {
+                const int pl = __builtin_ctzll(am);
+                am &= am - 1;
+                const float ppx = rl(pxf, pl), ppy = rl(pyf, pl);
+                const float dx = ea.x - ppx, dy = ea.y - ppy;
+                const float power = power2(ea.z, ea.w, eb.x, dx, dy);
+                const float alpha = fminf(0.99f, eb.y * __builtin_amdgcn_exp2f(power));
+                unsigned long long vm = __ballot(hit && !(power > 0.0f) && !(alpha < 1.0f / 255.0f));
+                const bool mine = lane == pl;
+                while (vm) {
+                    const int eb_ = __builtin_ctzll(vm);
+                    vm &= vm - 1;
+                    const float a_s = rl(alpha, eb_);
+                    const float test_T = T * (1.0f - a_s);
+                    const bool stop = mine && test_T < 0.0001f;
+                    const bool contrib = mine && !stop;
+                    const float w = contrib ? a_s * T : 0.0f;
+                    C01.x += rl(eb.z, eb_) * w;
+                    C01.y += rl(eb.w, eb_) * w;
+                    C2D.x += rl(ec, eb_) * w;
+                    if (WITH_DEPTH) C2D.y += rl(ez, eb_) * w;
+                    T = contrib ? test_T : T;
+                    last = contrib ? rel + (uint32_t)eb_ + 1u : last;
+                    done = done || stop;
+                    if (__ballot(stop) != 0ull) break;
+                }
+            }
+        }
+    }
+}
+
+template <bool WITH_DEPTH>
+__global__ __launch_bounds__(S360_BLOCK) void k_render_tail(KParams kp, const S360View* __restrict__ views, const uint32_t* __restrict__ tile_start,
+                                                            const uint32_t* __restrict__ list, const float4* __restrict__ recA,
+                                                            float* __restrict__ images, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+                                                            uint32_t* __restrict__ tile_max_contrib, uint32_t* __restrict__ strip_last,
+                                                            const float* __restrict__ depths, float* __restrict__ depth_maps, int depth_mode, MseEp ep,
+                                                            float4* __restrict__ surv, uint32_t* __restrict__ surv_count, SegBufs sg, int nt,
+                                                            uint32_t* __restrict__ dbg) {
+    __shared__ __attribute__((aligned(16))) float s_x[S360_BLOCK / 64][68], s_y[S360_BLOCK / 64][68], s_a[S360_BLOCK / 64][68],
+        s_b[S360_BLOCK / 64][68], s_c[S360_BLOCK / 64][68], s_o[S360_BLOCK / 64][68];
+    __shared__ __attribute__((aligned(16))) float2 s_rg[S360_BLOCK / 64][68], s_bz[S360_BLOCK / 64][68];
+    __shared__ __attribute__((aligned(16))) uint32_t s_pos[S360_BLOCK / 64][68];
+    if (sg.header[S360_HDR_SPLIT] == 0u) return;   // no quadrant of this call split
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const WaveLds L{s_x[wave], s_y[wave], s_a[wave], s_b[wave], s_c[wave], s_o[wave], s_rg[wave], s_bz[wave], s_pos[wave]};
+    const uint32_t nunits = SEG_PER_CHUNK * sg.chunk_start[nt];
+    for (uint32_t u = blockIdx.x; u < nunits; u += gridDim.x) {
+#ifdef S360_DBG_TIMING
+        const long long t_begin = wall_clock64();
+#endif
+        const ChunkUnit cu = chunk_unit(tile_start, sg.chunk_start, nt, kp.cap, u / SEG_PER_CHUNK);
+        const uint32_t k = cu.k * SEG_PER_CHUNK + (u % SEG_PER_CHUNK);
+        const int t = (int)cu.t;
+        const uint32_t start = cu.s, n = cu.n, end = start + n;
+        if (threadIdx.x == 0) sg.seg_info[u] = make_uint2((uint32_t)t, k);
+        const bool valid = cu.valid && k >= SEG_K0 && k * SEG_LEN < n && sg.seg_flag[4 * t + wave] == 1u;   // wave-uniform
+        if (!valid) {
+            if (lane == 0) sg.seg_cnt[(size_t)u * 4 + wave] = 0u;
+            continue;
+        }
+        const int v = t / kp.T, rem = t - v * kp.T;
+        const int ty = rem / kp.gx, tx = rem - ty * kp.gx;
+        const int lx = sub_ox(wave) + lane % SUB_W, ly = sub_oy(wave) + lane / SUB_W;
+        const int px = tx * 16 + lx, py = ty * 16 + ly;
+        const bool inside = px < kp.W && py < kp.H;
+        const float pxf = (float)px, pyf = (float)py;
+        const float x0 = (float)(tx * 16 + sub_ox(wave)), ys0 = (float)(ty * 16 + sub_oy(wave));
+        const int vcam = view_of_image(kp, v);
+        const float inv_scale = WITH_DEPTH ? 1.0f / views[vcam].scale : 0.f;
+        const float v_near = WITH_DEPTH ? views[vcam].near_plane : 0.f, v_far = WITH_DEPTH ? views[vcam].far_plane : 0.f;
+        float4* const sv_unit = surv ? surv + 3 * ((size_t)4 * start + (size_t)wave * n) : nullptr;
+        const uint32_t K = (n + SEG_LEN - 1) / SEG_LEN;   // segments of the list, the head's SEG_K0 included
+        {   // ---- this wave's segment, composited from T = 1
+            float T = 1.0f;
+            f2 C01 = f2{0.f, 0.f}, C2D = f2{0.f, 0.f};
+            uint32_t last = 0, scount = 0;
+            bool done = !inside;
+            const uint32_t b0 = start + k * SEG_LEN, b1 = min(b0 + SEG_LEN, end);
+            composite_segment<WITH_DEPTH>(list, recA, depths, start, b0, b1, pxf, pyf, x0, ys0, lane, L, inv_scale, v_near, v_far, depth_mode, T, C01,
+                                          C2D, last, done, sv_unit ? sv_unit + 3 * (size_t)(k * SEG_LEN) : nullptr, scount);
+            const size_t li = ((size_t)u * 4 + wave) * 64 + lane;
+            float* pc = reinterpret_cast<float*>(sg.part_c + li);
+            st_devf(pc, C01.x); st_devf(pc + 1, C01.y); st_devf(pc + 2, C2D.x); st_devf(pc + 3, C2D.y);
+            st_devf(sg.part_t + li, T);
+            st_dev32(sg.part_l + li, last | ((done && inside) ? 0x80000000u : 0u));
+            if (lane == 0) st_dev32(sg.part_n + (size_t)u * 4 + wave, scount);
+        }
+        // every lane drains its write-through stores, then ONE agent-scope counter says so (the pattern of k_merge_all)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint32_t arrived = 0;
+        if (lane == 0) arrived = __hip_atomic_fetch_add(&sg.seg_arrive[4 * t + wave], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
+#ifdef S360_DBG_TIMING
+        if (lane == 0) {
+            const size_t di = 4 * ((size_t)4 * nt + (size_t)u * 4 + wave);
+            dbg[di] = (uint32_t)t_begin;
+            dbg[di + 1] = (uint32_t)(wall_clock64() - t_begin);
+            dbg[di + 2] = (uint32_t)t;
+            dbg[di + 3] = (k << 8) | (uint32_t)wave;
+        }
+#endif
+        if (arrived + 1u != K - SEG_K0) continue;   // wave-uniform: another segment of this quadrant is still out
+        // ---- combine: this wave delivered last
+        const size_t slot0 = (size_t)u - k;         // slot of segment 0 of this tile (= SEG_PER_CHUNK * chunk_start[t])
+        const size_t li0 = (slot0 * 4 + wave) * 64 + lane;
+        float T;
+        f2 C01, C2D;
+        uint32_t last;
+        bool done;
+        {   // the head's state (written by k_render: the previous launch)
+            const float4 c = sg.part_c[li0];
+            const uint32_t l = sg.part_l[li0];
+            C01 = f2{c.x, c.y}; C2D = f2{c.z, c.w};
+            T = sg.part_t[li0];
+            last = l & 0x7FFFFFFFu;
+            done = (l >> 31) != 0u || !inside;
+        }
+        const float head_T = T;
+        for (uint32_t kk = SEG_K0; kk < K; ++kk) {
+            const size_t lik = ((slot0 + kk) * 4 + wave) * 64 + lane;
+            const float* pc = reinterpret_cast<const float*>(sg.part_c + lik);
+            const float c0 = ld_devf(pc), c1 = ld_devf(pc + 1), c2 = ld_devf(pc + 2), c3 = ld_devf(pc + 3);
+            const float pt = ld_devf(sg.part_t + lik);
+            const uint32_t pl = ld_dev32(sg.part_l + lik);
+            const bool pstop = (pl >> 31) != 0u;
+            const uint32_t plast = pl & 0x7FFFFFFFu;
+            // can this pixel's stop test trip inside the segment?  (0.1 % margin over the rounding of the two product orders)
+            const bool need = !done && (pstop || T * pt < 1.001e-4f);
+            f2 D01 = f2{0.f, 0.f}, D2D = f2{0.f, 0.f};
+            if (__ballot(need) != 0ull) {   // wave-uniform: sequential replay of the segment for those pixels, from their exact state
+                float rT = T;
+                f2 r01 = f2{0.f, 0.f}, r2d = f2{0.f, 0.f};
+                uint32_t rlast = 0, nosv = 0;
+                bool rdone = !need;
+                const uint32_t b0 = start + kk * SEG_LEN, b1 = min(b0 + SEG_LEN, end);
+                composite_segment<WITH_DEPTH>(list, recA, depths, start, b0, b1, pxf, pyf, x0, ys0, lane, L, inv_scale, v_near, v_far, depth_mode, rT,
+                                              r01, r2d, rlast, rdone, nullptr, nosv);
+                if (need) {
+                    D01 = r01; D2D = r2d;
+                    T = rT;
+                    last = rlast ? rlast : last;
+                    done = rdone || pstop;   // a local stop implies the true one (T <= 1); a one-ulp disagreement must not resurrect the pixel
+                }
+            } 
+            if (!done && !need) {   // the segment as a block
+                D01 = f2{T * c0, T * c1}; D2D = f2{T * c2, T * c3};
+                last = plast ? plast : last;
+                T = T * pt;
+            }
+            C01 = C01 + D01; C2D = C2D + D2D;
+            sg.seg_c[lik] = make_float4(D01.x, D01.y, D2D.x, D2D.y);   // the segment's own contribution; turned into "behind" sums below
+            sg.seg_t[lik] = T;                                         // transmittance behind the segment
+        }
+        // ---- the pixels, exactly as k_render's epilogue writes them
+        float sq = 0.f, sqc = 0.f;
+        if (inside) {
+            const S360View& vw = views[vcam];
+            const size_t hw = (size_t)kp.H * kp.W;
+            const size_t pix = (size_t)py * kp.W + px;
+            float* img = images + (size_t)v * 3 * hw;
+            const float o0 = C01.x + T * vw.bg[0], o1 = C01.y + T * vw.bg[1], o2 = C2D.x + T * vw.bg[2];
+            img[pix] = o0;
+            img[hw + pix] = o1;
+            img[2 * hw + pix] = o2;
+            if (ep.target) {
+                const float* gt = ep.target + (size_t)v * 3 * hw;
+                float* dg = ep.d_images + (size_t)v * 3 * hw;
+                const float g0 = gt[pix], g1 = gt[hw + pix], g2 = gt[2 * hw + pix];
+                const float d0 = o0 - g0, d1 = o1 - g1, d2 = o2 - g2;
+                dg[pix] = ep.grad_scale * d0;
+                dg[hw + pix] = ep.grad_scale * d1;
+                dg[2 * hw + pix] = ep.grad_scale * d2;
+                sq = d0 * d0 + d1 * d1 + d2 * d2;
+                const float q0 = fminf(fmaxf(g0, 0.f), 1.f) - fminf(fmaxf(o0, 0.f), 1.f);
+                const float q1 = fminf(fmaxf(g1, 0.f), 1.f) - fminf(fmaxf(o1, 0.f), 1.f);
+                const float q2 = fminf(fmaxf(g2, 0.f), 1.f) - fminf(fmaxf(o2, 0.f), 1.f);
+                sqc = q0 * q0 + q1 * q1 + q2 * q2;
+            }
+            final_T[(size_t)v * hw + pix] = T;
+            n_contrib[(size_t)v * hw + pix] = last;
+            if (WITH_DEPTH) depth_maps[(size_t)v * hw + pix] = C2D.y;
+        }
+        if (ep.target) {  // wave-uniform
+            const float s0 = wave_sum1_lane63(sq), s1 = wave_sum1_lane63(sqc);
+            if (lane == 63) {
+                ep.partials[2 * (4 * (size_t)t + wave)] = s0;
+                ep.partials[2 * (4 * (size_t)t + wave) + 1] = s1;
+            }
+        }
+        const uint32_t wm = wave_max_u32(inside ? last : 0u);
+        if (lane == 0) {
+            strip_last[4 * t + wave] = wm;
+            if (wm) atomicMax(&tile_max_contrib[t], wm);
+            // the backward's units of this quadrant: the head (all of its survivor records once a later segment contributes, else
+            // those in front of its own last contributor) and every segment that starts in front of the last contributor
+            if (surv_count) surv_count[4 * t + wave] = wm > SEG_HEAD ? sg.part_n[slot0 * 4 + wave] : sg.part_n[(slot0 + 1) * 4 + wave];
+            for (uint32_t kk = SEG_K0; kk < K; ++kk)
+                sg.seg_cnt[(slot0 + kk) * 4 + wave] = (surv_count && kk * SEG_LEN < wm) ? ld_dev32(sg.part_n + (slot0 + kk) * 4 + wave) : 0u;
+        }
+        // ---- colour accumulated BEHIND every segment (back to front: the small terms first) and behind the head
+        {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (uint32_t kk = K; kk-- > SEG_K0;) {
+                const size_t lik = ((slot0 + kk) * 4 + wave) * 64 + lane;
+                const float4 d = sg.seg_c[lik];
+                sg.seg_c[lik] = acc;
+                acc = make_float4(acc.x + d.x, acc.y + d.y, acc.z + d.z, acc.w + d.w);
+            }
+            sg.seg_c[li0] = acc;
+            sg.seg_t[li0] = head_T;
+        }
+    }
 }
 
 }  // namespace s360
@@ -1480,6 +1888,8 @@ extern "C" int s360_layout(const S360Params* prm, S360Layout* out) {
     out->tile_count = take(nt * 4);
     out->slot_ticket = take((size_t)prm->V * 256);  // per-image instance-slot tickets, 256 B apart; cleared with tile_count
     out->merge_done = take((nt * MAX_PASSES + 1) * 4);   // completion counters of the merge passes, one per (tile, pass), + the ticket counter of their work queue; cleared with tile_count
+    out->seg_flag = take(nt * 4 * 4);                    // S360_FLAG_SPLIT_LISTS: split mark / arrival counter per (tile, quadrant); cleared with tile_count
+    out->seg_arrive = take(nt * 4 * 4);
     out->tile_start = take((nt + 1) * 4);
     out->tile_cursor = take(nt * 4);
     out->chunk_start = take((nt + 1) * 4);
@@ -1497,6 +1907,18 @@ extern "C" int s360_layout(const S360Params* prm, S360Layout* out) {
     out->sh_jac = take((size_t)(prm->P > 0 ? prm->P : 1) * 36);
     out->surv = take(fwd_only ? 16 : cap * 4 * 48);
     out->surv_count = take(nt * 4 * 4);
+    {   // segment state of S360_FLAG_SPLIT_LISTS (44 B per pixel of a (segment slot, quadrant): ~11 B per instance of capacity)
+        const bool split = (prm->flags & S360_FLAG_SPLIT_LISTS) != 0;
+        const size_t ns = split ? seg_slots(cap) : 1, nl = ns * 4 * 64;
+        out->part_c = take(nl * 16);
+        out->part_t = take(nl * 4);
+        out->part_l = take(nl * 4);
+        out->part_n = take(ns * 4 * 4);
+        out->seg_c = take(nl * 16);
+        out->seg_t = take(nl * 4);
+        out->seg_cnt = take(ns * 4 * 4);
+        out->seg_info = take(ns * 8);
+    }
     out->total_bytes = o;
     // backward scratch: 4 quadrant-partial raster-gradient records (12 floats) + 4 validity bytes per instance
     // ... + tile order [V*T] + one gathered 48-byte record per (view, Gaussian) pair
@@ -1504,7 +1926,8 @@ extern "C" int s360_layout(const S360Params* prm, S360Layout* out) {
     // adds into the pair records directly — no partial slots, no validity flags
     const bool atomic = (prm->flags & S360_FLAG_ATOMIC_GRADS) != 0;
     out->backward_bytes = (atomic ? 0 : align_up(cap * 4 * (size_t)(16 * S360_PREC_F4)) + align_up(cap * 4)) + align_up(nt * 4 * 4) + 512 +
-                          align_up(np * 48) + align_up((size_t)(prm->P > 0 ? prm->P : 1) * 16) + 256;
+                          align_up(np * 48) + align_up((size_t)(prm->P > 0 ? prm->P : 1) * 16) + 256 +
+                          ((prm->flags & S360_FLAG_SPLIT_LISTS) ? align_up((seg_slots(cap) * 4 + 64) * 4) + 256 : 0);   // launch list of the split segments' units
     return S360_OK;
 }
 
@@ -1630,7 +2053,7 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
     {
         ProfScope ps(PS_TILE_SCAN, st);
         hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(TS_BLOCK), 0, st, tile_count, tile_start, tile_cursor, tile_max_contrib, nt, kp.cap, header,
-                           chunk_start);
+                           chunk_start, (unsigned long long*)prm->header_mirror);
     }
     S360_CHECK_LAUNCH();
     if (kp.P > 0) {
@@ -1686,14 +2109,29 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
         // header and the backward's first launch reduces (loss_out is complete once s360_backward* has run on this workspace)
         const bool defer = training && kp.P > 0 && ep.target && ep.loss_out && (kp.flags & S360_FLAG_DEFER_LOSS);
         uint32_t* hdr_loss = defer ? header + S360_HDR_LOSS : nullptr;
+        // S360_FLAG_SPLIT_LISTS: quadrants still busy after SEG_HEAD entries of a long list stop there (k_render) and the rest of
+        // the list is composited segment-parallel by a second launch (k_render_tail: returns at once when nothing split)
+        const bool split = kp.P > 0 && (kp.flags & S360_FLAG_SPLIT_LISTS);
+        SegBufs sg{split ? chunk_start : (const uint32_t*)nullptr, (uint32_t*)(ws + L.seg_flag), (uint32_t*)(ws + L.seg_arrive),
+                   (float4*)(ws + L.part_c), (float*)(ws + L.part_t), (uint32_t*)(ws + L.part_l), (uint32_t*)(ws + L.part_n),
+                   (float4*)(ws + L.seg_c), (float*)(ws + L.seg_t), (uint32_t*)(ws + L.seg_cnt), (uint2*)(ws + L.seg_info), header};
         if (depth_maps)
             hipLaunchKernelGGL(k_render<true>, rgrid, rblock, 0, st, kp, views, tile_start,
                                list, recA, recB, recC, images, final_T, n_contrib, tile_max_contrib, strip_last, dbg,
-                               depths, depth_maps, depth_mode, ep, kp.P > 0 ? tile_order : (const uint32_t*)nullptr, surv, surv_count, hdr_loss);
+                               depths, depth_maps, depth_mode, ep, kp.P > 0 ? tile_order : (const uint32_t*)nullptr, surv, surv_count, hdr_loss, sg);
         else
             hipLaunchKernelGGL(k_render<false>, rgrid, rblock, 0, st, kp, views, tile_start,
                                list, recA, recB, recC, images, final_T, n_contrib, tile_max_contrib, strip_last, dbg,
-                               depths, depth_maps, depth_mode, ep, kp.P > 0 ? tile_order : (const uint32_t*)nullptr, surv, surv_count, hdr_loss);
+                               depths, depth_maps, depth_mode, ep, kp.P > 0 ? tile_order : (const uint32_t*)nullptr, surv, surv_count, hdr_loss, sg);
+        if (split) {
+            const unsigned tgrid = (unsigned)min((size_t)1024, seg_slots(kp.cap));
+            if (depth_maps)
+                hipLaunchKernelGGL(k_render_tail<true>, dim3(tgrid), rblock, 0, st, kp, views, tile_start, list, recA, images, final_T, n_contrib,
+                                   tile_max_contrib, strip_last, depths, depth_maps, depth_mode, ep, surv, surv_count, sg, nt, dbg);
+            else
+                hipLaunchKernelGGL(k_render_tail<false>, dim3(tgrid), rblock, 0, st, kp, views, tile_start, list, recA, images, final_T, n_contrib,
+                                   tile_max_contrib, strip_last, depths, depth_maps, depth_mode, ep, surv, surv_count, sg, nt, dbg);
+        }
         if (ep.target && ep.loss_out && !defer)
             hipLaunchKernelGGL(k_mse_finish, dim3(1), dim3(MSE_BLOCK), 0, st, ep.partials, kp.T * 4, kp.V, 0.5f * ep.grad_scale,
                                1.0f / (3.0f * (float)kp.H * (float)kp.W), ep.loss_out);

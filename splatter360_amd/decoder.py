@@ -196,7 +196,8 @@ def render_views_fused(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far
                        max_instances: Optional[int] = None, check: str = "sync", views: Optional[Tensor] = None, glue: str = "native",
                        depth_mode: Optional[DepthRenderingMode] = None, defer_sh: bool = False,
                        mse_target: Optional[Tensor] = None, mse_weight: float = 1.0, mse_count: Optional[int] = None,
-                       exchange=None, lean: Optional[bool] = None, mse_defer: bool = False, atomic_grads: Optional[bool] = None):
+                       exchange=None, lean: Optional[bool] = None, mse_defer: bool = False, atomic_grads: Optional[bool] = None,
+                       split_lists: Optional[bool] = None):
     """V <= 8 views of ONE cloud in one fused rasteriser call: means[G,3], covariances[G,3,3],
     harmonics[G,3,d_sh] (the reference's Gaussians layout, src/model/types.py:7-12, read in place),
     opacities[G] -> [V,3,h,w].  With the six face cameras of a panorama (one camera centre) and glue="torch" (the
@@ -207,6 +208,7 @@ def render_views_fused(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far
     (views_share_camera_centre: one small synchronising read when they live on the device; with
     pre-packed `views` and no extrinsics the views are taken to be independent, False).
     lean: None = rasterizer.LEAN_LISTS (on: tile lists hold only the instances that can reach a pixel; results bit-identical).
+    split_lists: None = rasterizer.SPLIT_LONG_LISTS (on: long lists whose pixels do not saturate are composited segment-parallel).
     exchange: distributed.ExchangeConfig — multi-GPU, the gradients come back summed over the ranks (rasterize_views).
     Host synchronisation: check="sync" (default) reads the binning-overflow flag back after the forward, like
     upstream's own scan read-back, and re-renders with the exact capacity if needed; check="lazy" together with an
@@ -226,7 +228,7 @@ def render_views_fused(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far
         image_height=h, image_width=w, sh_degree=isqrt(n) - 1, shared_campos=shared_campos, want_radii=False,
         max_instances=max_instances, check=check, cov9=True, sh_channel_major=True, depth_mode=depth_mode,
         defer_sh=defer_sh, mse_target=mse_target, mse_weight=mse_weight, mse_count=mse_count, exchange=exchange, lean=lean,
-        mse_defer=mse_defer, atomic_grads=atomic_grads)
+        mse_defer=mse_defer, atomic_grads=atomic_grads, split_lists=split_lists)
     res = (out[0],) if depth_mode is None else (out[0], out[2])
     if mse_target is not None:
         res = res + (out[-1],)

@@ -138,7 +138,7 @@ class FactoredExchange:
 
 
 def start_factored_exchange(means: Tensor, covariances: Tensor, harmonics: Tensor, opacities: Tensor, deferred,
-                            group=None) -> FactoredExchange:
+                            group=None, force_collectives: bool = False) -> FactoredExchange:
     """Gradient exchange for views sharded one panorama per rank, exploiting that each rank's dL/dSH is the
     rank-1 product Y(dir_rank) (x) dL/dRGB_rank per Gaussian (the pipelined form; `exchange_chunked` below is the one that
     hides the exchange INSIDE a step):
@@ -166,7 +166,7 @@ def start_factored_exchange(means: Tensor, covariances: Tensor, harmonics: Tenso
     rgb[:, 3] = torch.where(vis, torch.full_like(rgb[:, 3].view(torch.int32), rank), torch.full_like(rgb[:, 3].view(torch.int32), -1)).view(torch.float32)
     rep = d.views[:1].contiguous()  # all views of the call share campos and scale
     works_ag, work_ar = [], None
-    if world > 1:
+    if world > 1 or (force_collectives and dist.is_available() and dist.is_initialized()):
         # the communicator runs its work in issue order: the all-gathers first (the local SH pass waits for them),
         # the all-reduce behind them, overlapping with that pass
         rgb_all = torch.empty((world * rgb.shape[0], 4), dtype=rgb.dtype, device=dev)   # dim-0 concat: gloo-compatible
@@ -176,15 +176,15 @@ def start_factored_exchange(means: Tensor, covariances: Tensor, harmonics: Tenso
         work_ar = dist.all_reduce(small, op=dist.ReduceOp.SUM, group=group, async_op=True)
     else:
         rgb_all, rep_all = rgb, rep
-    snap = d.means3D.clone() if world > 1 else d.means3D      # 12 B / Gaussian: see FactoredExchange.finish
+    snap = d.means3D.clone() if (world > 1 or works_ag) else d.means3D      # 12 B / Gaussian: see FactoredExchange.finish
     return FactoredExchange((means, covariances, harmonics, opacities), d, small, rgb_all, rep_all, works_ag, work_ar, world, snap)
 
 
 def sync_gradients_factored(means: Tensor, covariances: Tensor, harmonics: Tensor, opacities: Tensor, deferred,
-                            group=None) -> None:
+                            group=None, force_collectives: bool = False) -> None:
     """start_factored_exchange(...).finish(), then the summed gradients are stored in .grad of the four tensors: the blocking
     form (nothing can run between the two halves, so assigning .grad is safe here)."""
-    g = start_factored_exchange(means, covariances, harmonics, opacities, deferred, group).finish()
+    g = start_factored_exchange(means, covariances, harmonics, opacities, deferred, group, force_collectives).finish()
     means.grad, covariances.grad, harmonics.grad, opacities.grad = g
 
 
@@ -197,7 +197,7 @@ def chunk_bounds(p: int, n_chunks: int, align: int = 256) -> List[tuple]:
 
 
 def exchange_chunked(p: int, packed: Tensor, rgb: Tensor, rep_view: Tensor, produce, rebuild_sh, n_chunks: int = 4, group=None,
-                     group_gather=None, timings: Optional[dict] = None) -> None:
+                     group_gather=None, timings: Optional[dict] = None, force_collectives: bool = False) -> None:
     """The gradient exchange of ONE step hidden inside that step (no gradient accumulation assumed): the per-Gaussian tail of
     the backward is cut into Gaussian ranges and every range's collectives start as soon as its rows exist, so RCCL runs under
     the tail kernels of the following ranges and under the local dL/dSH rebuilds of the preceding ones.
@@ -217,10 +217,14 @@ def exchange_chunked(p: int, packed: Tensor, rgb: Tensor, rep_view: Tensor, prod
     microseconds at 1 M, N = 8) — DESIGN.md section 5 does the arithmetic.
     rebuild_sh=None (harmonics frozen on EVERY rank): the dL/dRGB factors are neither gathered nor rebuilt — only the packed
     all-reduces run.  The collectives are issued from inside the caller's backward: every rank of `group` must run this backward
-    the same number of times with the same p / n_chunks / rebuild_sh-or-None, or the ranks that did wait forever."""
+    the same number of times with the same p / n_chunks / rebuild_sh-or-None, or the ranks that did wait forever.
+    force_collectives=True (with an initialised process group): a world of ONE rank also goes through the collective branch
+    instead of the short cut — how the RCCL path (communicator streams against the ctypes-launched kernels on torch's current
+    stream, in-place all-reduces of slices whose neighbours the next produce() writes) is exercised on a one-GPU box
+    (tests/test_gpu_rccl_single_rank.py); the results are those of the short cut bit for bit."""
     world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
     bounds = chunk_bounds(p, n_chunks)
-    if world == 1:
+    if world == 1 and not (force_collectives and dist.is_available() and dist.is_initialized()):
         for lo, hi in bounds:
             produce(lo, hi)
         rep_all = rep_view.reshape(1, -1)
@@ -259,8 +263,9 @@ class ExchangeConfig:
     does not reach the render would leave the others waiting in the collectives).  Frozen harmonics (no gradient required on any
     rank) skip the dL/dRGB gathers and the dL/dSH rebuild."""
 
-    def __init__(self, group=None, n_chunks: int = 4, group_gather=None):
+    def __init__(self, group=None, n_chunks: int = 4, group_gather=None, force_collectives: bool = False):
         self.group, self.n_chunks, self.group_gather = group, int(n_chunks), group_gather
+        self.force_collectives = bool(force_collectives)      # world size 1: still issue the collectives (see exchange_chunked)
 
     def world(self) -> int:
         return dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1

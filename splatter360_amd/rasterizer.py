@@ -46,6 +46,14 @@ class GaussianRasterizationSettings(NamedTuple):
 # this switch or S360_LEAN_LISTS=0 select upstream's 3-sigma rectangles (what the integer-state parity tests compare).
 LEAN_LISTS = bool(int(os.environ.get("S360_LEAN_LISTS", "1")))
 
+# Segment-parallel compositing of long tile lists (S360_FLAG_SPLIT_LISTS, forward and backward): an 8x8 quadrant that is still busy
+# after the first 2 048 entries of a list hands the rest over in 1 024-entry segments, one wave each, combined per pixel in list
+# order (pixels whose stop test can trip inside a segment replay it sequentially).  Quadrants that do not split — all of them on
+# lists up to 3 071 entries — are bit-identical either way; inside split quadrants the floating-point association changes
+# (<= 1e-6 per pixel; integers, stop decisions and n_contrib stay those of the sequential walk).  Default on;
+# rasterize_views(split_lists=False), this switch or S360_SPLIT_LISTS=0 keep every list a single sequential chain.
+SPLIT_LONG_LISTS = bool(int(os.environ.get("S360_SPLIT_LISTS", "1")))
+
 # Opt-in (S360_FLAG_ATOMIC_GRADS): the backward composite accumulates with float32 atomics instead of the deterministic
 # partial-record gather — a quarter of the backward scratch, one launch less, gradients no longer bit-reproducible run to run.
 ATOMIC_GRADS = bool(int(os.environ.get("S360_ATOMIC_GRADS", "0")))
@@ -131,19 +139,58 @@ def _hint_key(dev, p: int, v: int, h: int, w: int, lean: bool):
     return (None if d is None else (d.type, d.index), p, v, h, w, bool(lean))
 
 
+_MIRRORS: dict = {}         # hint key -> pinned int64[1]: (num_instances | overflow << 32) of the latest finished call of that shape
+
+
+def _mirror(key) -> Tensor:
+    """The host-visible word the forward's k_tile_scan stores its instance count and overflow flag into (S360Params.header_mirror):
+    one pinned int64 per (device, shape, list mode), never freed (a kernel in flight may still write it).  -1 = nothing yet."""
+    m = _MIRRORS.get(key)
+    if m is None:
+        m = torch.full((1,), -1, dtype=torch.int64).pin_memory()
+        _MIRRORS[key] = m
+    return m
+
+
+def _poll_mirror(key, warn: bool = True) -> None:
+    """Fold what the latest FINISHED call of this shape reported into the capacity hint — a plain host read of pinned memory, no
+    device synchronisation; whatever is still in flight is simply not seen yet."""
+    m = _MIRRORS.get(key)
+    if m is None:
+        return
+    word = int(m[0])
+    if word < 0:
+        return
+    n, over = word & 0xFFFFFFFF, (word >> 32) & 1
+    _CAPACITY_HINT[key] = max(n, _CAPACITY_HINT.get(key, 0))
+    if over and warn and _OVERFLOW_WARNED.get(key) != n:
+        import warnings
+        _OVERFLOW_WARNED[key] = n
+        warnings.warn(f"splatter360_amd: a check='lazy' rasteriser call needed {n} instances, more than its binning capacity — that "
+                      "call's tile lists were truncated (memory-safe, image incomplete); the following calls are sized for it.  "
+                      "Pass max_instances= or use check='sync' where a truncated frame is not acceptable.", RuntimeWarning, stacklevel=3)
+
+
+_OVERFLOW_WARNED: dict = {}
+
+
 def default_capacity(p: int, v: int, h: int = 0, w: int = 0, *, device=None, lean: bool = False, lazy: bool = False) -> int:
     """Capacity (instances = (Gaussian, tile) pairs) of the binning buffers and, through them, of the backward scratch
     (per instance of capacity: 24 B of keys / lists / owner table, 192 B of survivor records and 4 x 64 B of quadrant-partial
-    slots in the backward scratch).  First-call guess 1.5 P V.  Once a caller has read an instance count back for this
-    (device, shape, list mode) — check="sync" reads it with the overflow flag; RasterState.num_rendered() / overflowed() do too —
-    the size is 1.25 x the LARGEST count seen (a running maximum: one sparse scene never shrinks the buffers of the next, denser
-    one).  check="sync" re-renders an overflowing call with the exact size; check="lazy" cannot, so there the hint may only
-    RAISE the capacity above the first-call guess, never lower it — pass max_instances= explicitly to run lazy calls in less."""
+    slots in the backward scratch).  First-call guess 1.5 P V.  Once an instance count is known for this (device, shape, list
+    mode) the size is 1.25 x the LARGEST count seen (a running maximum: one sparse scene never shrinks the buffers of the next,
+    denser one).  Where the count comes from: check="sync" reads it back with the overflow flag (and re-renders an overflowing
+    call with the exact size); check="lazy" never synchronises — every forward also stores (count, overflow flag) into a pinned
+    host word (S360Params.header_mirror), and the NEXT lazy call of the shape reads that word: the buffers follow the scene with
+    one call of delay.  A lazy call whose scene outgrows 1.25 x everything seen before is truncated (flagged, memory-safe, a
+    RuntimeWarning at the next call); pass max_instances= to rule that out."""
     guess = (3 * p * v) // 2 + (1 << 18)
-    hint = _CAPACITY_HINT.get(_hint_key(device, p, v, h, w, lean))
+    key = _hint_key(device, p, v, h, w, lean)
+    if lazy:
+        _poll_mirror(key)
+    hint = _CAPACITY_HINT.get(key)
     if hint is not None:
-        sized = hint + hint // 4 + (1 << 16)
-        guess = max(guess, sized) if lazy else sized
+        guess = hint + hint // 4 + (1 << 16)
     return int(min(2**32 - 1, max(1 << 16, guess)))
 
 
@@ -186,6 +233,7 @@ class RasterState:
             final_T=self._arr(l.final_T, p.V * p.H * p.W, torch.float32).view(p.V, p.H, p.W),
             n_contrib=self._arr(l.n_contrib, p.V * p.H * p.W, torch.int32).view(p.V, p.H, p.W),
             tile_max_contrib=self._arr(l.tile_max_contrib, nt, torch.int32),
+            seg_flag=self._arr(l.seg_flag, nt * 4, torch.int32),       # 1: this (tile, quadrant) split its list (S360_FLAG_SPLIT_LISTS)
         )
 
     def _tiles_touched(self) -> Tensor:
@@ -276,7 +324,7 @@ class _RasterizeViews(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, cov6, views, cfg, mse_target=None):
         (h, w, sh_degree, shared_campos, max_instances, check, want_radii, cov9, sh_channel_major, keep_slots, depth_mode,
-         defer_sh, mse_weight, mse_count, spherical, exchange, lean, mse_defer, atomic_grads) = cfg
+         defer_sh, mse_weight, mse_count, spherical, exchange, lean, mse_defer, atomic_grads, split_lists) = cfg
         if exchange is not None and (shs is None or not (shared_campos or int(views.shape[0]) == 1) or defer_sh):
             raise RuntimeError("exchange=: the chunked gradient exchange needs SH colours and views sharing one camera centre "
                                "(and replaces defer_sh)")
@@ -308,9 +356,12 @@ class _RasterizeViews(torch.autograd.Function):
                 _lib.FLAG_SH_DEG4_IGNORED if SH_DEG4_IGNORED else 0) | (_lib.FLAG_SPHERICAL if spherical else 0) | (
                 _lib.FLAG_LEAN_LISTS if lean else 0) | (
                 _lib.FLAG_DEFER_LOSS if (mse_defer and mse_target is not None and needs_bwd) else 0) | (
-                _lib.FLAG_ATOMIC_GRADS if (atomic_grads and needs_bwd) else 0)
+                _lib.FLAG_ATOMIC_GRADS if (atomic_grads and needs_bwd) else 0) | (
+                _lib.FLAG_SPLIT_LISTS if (split_lists and not (atomic_grads and needs_bwd)) else 0)
             prm.max_instances = int(max_instances) if max_instances else default_capacity(
                 p, v, int(h), int(w), device=m3.device, lean=lean, lazy=(check != "sync"))
+            # every forward reports (instance count, overflow flag) into pinned host memory: how check="lazy" callers size the next call
+            prm.header_mirror = _mirror(_hint_key(m3.device, p, v, int(h), int(w), lean)).data_ptr()
             mse = None
             if mse_target is not None:
                 tgt = _f32c(mse_target, "mse_target")
@@ -411,7 +462,8 @@ class _RasterizeViews(torch.autograd.Function):
 
                 # harmonics frozen (need[2] False — on every rank, it is the same model): no dL/dRGB gathers, no dL/dSH rebuild
                 distributed.exchange_chunked(p, packed, rgb, vw[0], produce, rebuild_sh if d_sh is not None else None,
-                                             n_chunks=ex.n_chunks, group=ex.group, group_gather=ex.group_gather)
+                                             n_chunks=ex.n_chunks, group=ex.group, group_gather=ex.group_gather,
+                                             force_collectives=getattr(ex, "force_collectives", False))
                 _lib.check(lib.s360_unpack_gradients(_ptr(packed), p, int(c6.dim() == 3), _ptr(d_m3), _ptr(d_c6), _ptr(d_op), stream),
                            "s360_unpack_gradients")
                 if d_m2 is not None:
@@ -499,7 +551,8 @@ def rasterize_views(means3D: Tensor, cov6: Tensor, opacities: Tensor, shs: Optio
                     cov9: bool = False, sh_channel_major: bool = False, keep_slots: bool = False,
                     depth_mode: Optional[str] = None, defer_sh: bool = False, mse_target: Optional[Tensor] = None,
                     mse_weight: float = 1.0, mse_count: Optional[int] = None, spherical: bool = False, exchange=None,
-                    lean: Optional[bool] = None, mse_defer: bool = False, atomic_grads: Optional[bool] = None):
+                    lean: Optional[bool] = None, mse_defer: bool = False, atomic_grads: Optional[bool] = None,
+                    split_lists: Optional[bool] = None):
     """Render V views ([V,44] packed, see pack_views) of one cloud.  cov9: cov6 is [P,3,3];
     sh_channel_major: shs is [P,3,M] (the reference's Gaussians layouts, consumed without copies).
     When no input requires grad the instance-slot tables (backward-only state) are skipped unless
@@ -522,6 +575,8 @@ def rasterize_views(means3D: Tensor, cov6: Tensor, opacities: Tensor, shs: Optio
     their values only AFTER .backward(); for training loops that read the scalar for logging after the step.
     atomic_grads (default: module switch ATOMIC_GRADS = False): S360_FLAG_ATOMIC_GRADS — float32 atomics in the backward
     composite instead of the deterministic gather (less scratch, one launch less; gradients not bit-reproducible).
+    split_lists (default: module switch SPLIT_LONG_LISTS = True): S360_FLAG_SPLIT_LISTS — long tile lists whose pixels do not
+    saturate are composited segment-parallel, forward and backward (see the switch's comment).
     lean (default: module switch LEAN_LISTS = True): bin a (Gaussian, tile) instance only where the splat can reach
     alpha >= 1/255 on that tile — same images / radii / gradients bit for bit, shorter lists; lean=False = upstream's rectangles.
     spherical=True: native equirectangular splat mode (S360_FLAG_SPHERICAL; no reference counterpart, specified by the
@@ -534,7 +589,8 @@ def rasterize_views(means3D: Tensor, cov6: Tensor, opacities: Tensor, shs: Optio
         raise ValueError(f"depth_mode must be one of {sorted(DEPTH_MODES)}")
     cfg = (image_height, image_width, sh_degree, shared_campos, max_instances, check, want_radii, cov9,
            sh_channel_major, keep_slots, depth_mode, defer_sh, mse_weight, mse_count, bool(spherical), exchange,
-           LEAN_LISTS if lean is None else bool(lean), bool(mse_defer), ATOMIC_GRADS if atomic_grads is None else bool(atomic_grads))
+           LEAN_LISTS if lean is None else bool(lean), bool(mse_defer), ATOMIC_GRADS if atomic_grads is None else bool(atomic_grads),
+           SPLIT_LONG_LISTS if split_lists is None else bool(split_lists))
     images, radii, depth, loss, clipped = _RasterizeViews.apply(means3D, means2D, shs, colors_precomp, op2, cov6, views,
                                                                 cfg, mse_target)
     images.s360_deferred = _RasterizeViews.last_holder      # see deferred_of()

@@ -28,9 +28,11 @@ def gpu():
 def parity_lists():
     """Upstream-compatible tile lists (3-sigma rectangles) for the tests that compare tiles_touched / sorted lists / n_contrib
     with the oracle; the product default is the lean lists (rasterizer.LEAN_LISTS), whose images and gradients are bit-identical
-    (tests/test_gpu_lean.py)."""
+    (tests/test_gpu_lean.py), with long unsaturated lists composited segment-parallel (rasterizer.SPLIT_LONG_LISTS: same integers,
+    float association differs inside split quadrants — tests/test_gpu_saturating_parity.py puts that mode against the oracle)."""
     from splatter360_amd import rasterizer
-    old = rasterizer.LEAN_LISTS
+    old = (rasterizer.LEAN_LISTS, rasterizer.SPLIT_LONG_LISTS)
     rasterizer.LEAN_LISTS = False
+    rasterizer.SPLIT_LONG_LISTS = False     # ... and every list one sequential chain: the oracle's rounding order
     yield
-    rasterizer.LEAN_LISTS = old
+    rasterizer.LEAN_LISTS, rasterizer.SPLIT_LONG_LISTS = old

@@ -33,8 +33,8 @@ def test_layout_is_monotone_and_aligned():
     offs = [getattr(lay, n) for n, _ in _lib.S360Layout._fields_ if n not in ("total_bytes", "backward_bytes")]
     assert offs == sorted(offs) and all(o % 16 == 0 for o in offs)
     assert (lay.rec_b, lay.rec_c) == (lay.rec_a + 16, lay.rec_a + 32)
-    assert lay.total_bytes >= offs[-1] + 6 * 16 * 4 and lay.backward_bytes >= 5000 * 4 * 48
-    assert C.sizeof(_lib.S360Params) == 32
+    assert lay.total_bytes > offs[-1] and lay.part_c >= lay.surv_count + 6 * 16 * 4 and lay.backward_bytes >= 5000 * 4 * 48
+    assert C.sizeof(_lib.S360Params) == 40
 
 
 def test_bad_arguments_are_rejected_before_any_gpu_work():

@@ -24,6 +24,17 @@ pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
 
 
+@pytest.fixture(autouse=True)
+def _sequential_lists():
+    """Bit-identity between the two list modes is a statement about the sequential composite: a quadrant that SPLITS its list
+    (rasterizer.SPLIT_LONG_LISTS) does so at a list position, and positions differ between the modes — there the two agree to
+    float rounding only (tests/test_gpu_saturating_parity.py).  Everything here runs with splitting off."""
+    old = rasterizer.SPLIT_LONG_LISTS
+    rasterizer.SPLIT_LONG_LISTS = False
+    yield
+    rasterizer.SPLIT_LONG_LISTS = old
+
+
 def _report(key, **vals):
     out = ROOT / "gpurun_out"
     try:

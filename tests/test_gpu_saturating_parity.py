@@ -1,0 +1,155 @@
+"""Oracle parity in the regimes the headline cloud does not reach (VERDICT r04 "missing" #7, "weak" #3), at the bench's own sizes:
+
+  surface-like cloud   1 048 576 Gaussians of a coherent depth field with opacity >= 0.9 (synthetic.surface_like_cloud — the bench's
+                       `workloads.surface_like` leg): pixels SATURATE (the early-termination logic `T (1 - alpha) < 1e-4`, `done`,
+                       the replay-length / survivor-count bookkeeping of the training forward) behind tile lists of 9 - 17 K entries
+                       on the polar faces, of which a pole quadrant replays > 10 K;
+  uniform cloud        1 048 576 Gaussians U[-5,5]^3 (the bench's `workloads.uniform` leg): thousands of footprints beyond 32 tiles —
+                       rectangles binned whole, pairs summed by the wave-parallel phase of k_gather_slots.
+
+Per face: integer state bit-exact on the upstream-compatible lists with list splitting off (tiles_touched, sorted list, keys,
+ranges), pixels / final_T / n_contrib with the bars of tests/test_gpu_headline_parity.py, backward against the float32 AND float64
+oracle.  Then the PRODUCT DEFAULT (lean lists, long lists composited segment-parallel) against the same oracle outputs: pixels
+<= 1e-5 (north_star), n_contrib exact up to the legitimate borderline flips, gradients with the same bar.
+PARITY UNPINNED: the oracle restates the un-vendored upstream extension (see oracle/s360_oracle.c header)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import boundary_tensors, settings_from_views
+from oracle import oracle
+from splatter360_amd import rasterizer, synthetic
+from test_gpu_headline_parity import _check_face_forward, _face_state, _grad_err, _pixel_stats, _report, _single_face_call
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def surface1m():
+    return synthetic.surface_like_cloud(512, 1024, seed=0)
+
+
+@pytest.fixture(scope="module")
+def uniform1m():
+    return synthetic.uniform_cloud(1 << 20, seed=0, extent=5.0)
+
+
+def _params(cloud, dev):
+    return [torch.tensor(cloud[k], device=dev) for k in ("means", "covariances", "harmonics", "opacities")]
+
+
+class _Mode:
+    """Module switches of the rasteriser for the duration of a block: (lean lists, segment-parallel long lists)."""
+
+    def __init__(self, lean, split):
+        self.want = (lean, split)
+
+    def __enter__(self):
+        self.old = (rasterizer.LEAN_LISTS, rasterizer.SPLIT_LONG_LISTS)
+        rasterizer.LEAN_LISTS, rasterizer.SPLIT_LONG_LISTS = self.want
+
+    def __exit__(self, *a):
+        rasterizer.LEAN_LISTS, rasterizer.SPLIT_LONG_LISTS = self.old
+
+
+def _got_grads(ps):
+    r, c = np.triu_indices(3)
+    return dict(means3D=ps[0].grad.cpu().numpy(), cov3D=ps[1].grad.cpu().numpy()[:, r, c],
+                shs=ps[2].grad.cpu().numpy().transpose(0, 2, 1), opacities=ps[3].grad.cpu().numpy())
+
+
+def _face_case(cloud, params, face, dev, tag, seed):
+    """One 256x256 face of a 1 M cloud: (a) parity lists, no splitting — everything against the oracle, integers bit-exact;
+    (b) the product default — observables against the same oracle results."""
+    rng = np.random.default_rng(seed)
+    gimg = rng.standard_normal((3, 256, 256)).astype(np.float32)
+    with _Mode(False, False):
+        out, st, ps = _single_face_call(params, face, 256, dev, grad_image=gimg)
+    S = settings_from_views(st.views, 0, 256, 256)
+    means, cov6, shs, opac = boundary_tensors(cloud, S["scale"])
+    o32 = oracle.rasterize(S, means3D=means, cov3D_precomp=cov6, opacities=opac, shs=shs)
+    f = o32.forward()
+    P = cloud["means"].shape[0]
+    img = out[0].detach().cpu().numpy()
+    _check_face_forward(_face_state(st.tensors(), 0, P, 256), img, f, tag + "_fwd", 256)
+    sat = float((f["final_T"] < 1e-4).mean())
+    g32 = o32.backward(gimg)
+    del o32
+    o64 = oracle.rasterize(S, means3D=means, cov3D_precomp=cov6, opacities=opac, shs=shs, dtype=np.float64)
+    o64.forward()
+    g64 = o64.backward(gimg)
+    del o64
+    sc = np.float64(S["scale"])
+    fold = dict(means3D=sc, cov3D=sc * sc, shs=1.0, opacities=1.0)       # oracle gradients are w.r.t. the scaled cloud
+    got = _got_grads(ps)
+    rep = dict(saturated_pixel_fraction=sat, longest_list=int(np.diff(f["ranges"].astype(np.int64), axis=1).max()),
+               max_n_contrib=int(f["n_contrib"].max()))
+    bars = {}
+    for k in got:
+        e, e32 = _grad_err(got[k], np.asarray(g64[k]) * fold[k], np.asarray(g32[k], np.float64) * fold[k])
+        rep[k], rep[k + "_oracle_f32"] = e, e32
+        bars[k] = max(1e-4, 1.1 * e32)
+        assert e <= bars[k], (tag, k, e, e32)
+    # (b) the product default: lean lists, long lists split into depth segments composited in parallel
+    with _Mode(True, True):
+        out2, st2, ps2 = _single_face_call(params, face, 256, dev, grad_image=gimg)
+    img2 = out2[0].detach().cpu().numpy()
+    px = _pixel_stats(img2, f["image"])
+    per_px = np.abs(img2.astype(np.float64) - f["image"]).mean(0)
+    amax = float(np.abs(f["image"]).max())
+    over = per_px > 1e-5 * max(1.0, amax)
+    assert int(over.sum()) <= per_px.size // 20_000 and px["max"] <= 2e-4, (tag, px, int(over.sum()))   # borderline stop / accept flips only
+    assert px["p999"] <= 1e-6 and px["mean"] <= 1e-7, (tag, px)
+    t2 = st2.tensors()
+    dT = np.abs(t2["final_T"][0].cpu().numpy().astype(np.float64) - f["final_T"])
+    assert int((dT > 2e-6).sum()) <= per_px.size // 20_000, (tag, float(dT.max()))
+    sat2 = (t2["final_T"][0].cpu().numpy() < 1e-4)
+    assert float((sat2 != (f["final_T"] < 1e-4)).mean()) <= 1e-4
+    got2 = _got_grads(ps2)
+    for k in got2:
+        e, _ = _grad_err(got2[k], np.asarray(g64[k]) * fold[k])
+        rep[k + "_default_mode"] = e
+        assert e <= 1.5 * bars[k], (tag, k, e, bars[k])
+        e_modes, _ = _grad_err(got2[k], got[k])
+        rep[k + "_default_vs_parity_mode"] = e_modes
+    rep.update({"default_mode_px_" + k: v for k, v in px.items()})
+    _report(tag + "_bwd_rel_err_vs_f64_oracle", **rep)
+    return rep
+
+
+@pytest.mark.parametrize("face", [0, 5, 2])      # both polar faces (the pole clumps) and one side face
+def test_surface_like_1m_face_vs_oracle(gpu, surface1m, face):
+    rep = _face_case(surface1m, _params(surface1m, gpu), face, gpu, f"surface_like_face{face}", 300 + face)
+    assert rep["saturated_pixel_fraction"] > 0.5            # the regime this test exists for
+    if face != 2:
+        assert rep["longest_list"] > 9000 and rep["max_n_contrib"] > 4096
+
+
+@pytest.mark.parametrize("face", [0, 3])
+def test_uniform_1m_face_vs_oracle(gpu, uniform1m, face):
+    params = _params(uniform1m, gpu)
+    rep = _face_case(uniform1m, params, face, gpu, f"uniform_face{face}", 400 + face)
+    st = rasterizer.last_state()
+    assert int(st.header()[4].item()) > 500                 # pairs with more than 32 instance slots: the wave-parallel gather
+
+
+def test_surface_like_fused_six_faces_default_mode_is_deterministic_and_close_to_unsplit(gpu, surface1m):
+    """The bench's `surface_like` leg itself (fused six-face training step, product defaults): bit-reproducible run to run, and
+    within float rounding of the same step with list splitting off (which the per-face tests above put against the oracle)."""
+    from splatter360_amd import decoder
+    params = _params(surface1m, gpu)
+    ext, K, near, far = decoder.cube_cameras(torch.eye(4, device=gpu), 0.1, 10.0)
+    bg = torch.zeros(3, device=gpu)
+    res = []
+    for split in (True, True, False):
+        with _Mode(True, split):
+            ps = [p.clone().requires_grad_(True) for p in params]
+            faces = decoder.render_views_fused(ext, K, near, far, (256, 256), bg, *ps, shared_campos=True)
+            ((faces - 0.5) ** 2).mean().backward()
+            res.append([faces.detach()] + [p.grad for p in ps])
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+    d = (res[0][0] - res[2][0]).abs()
+    assert float(d.mean()) <= 1e-7 and int((d > 1e-5).sum()) <= d.numel() // 20_000, (float(d.mean()), float(d.max()))
+    for a, b in zip(res[0][1:], res[2][1:]):
+        assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()), (float((a - b).abs().max()), float(b.abs().max()))
