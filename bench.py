@@ -365,6 +365,8 @@ def main():
     st = rasterizer.last_state()
     if st.overflowed():
         raise SystemExit("binning capacity overflowed during the timed region: result invalid")
+    if st.split_errors():
+        raise SystemExit("k_render_tail reported a watchdog error during the timed region: result invalid")
     L = st.num_rendered()
     ws_fwd, ws_bwd = int(st_timed.layout.total_bytes), int(st_timed.layout.backward_bytes)   # scratch of a timed step (check="lazy")
     n_split = int(st_timed.header()[5].item()) if a.split_lists else 0
@@ -543,7 +545,7 @@ def main():
             _lib.profile_enable(False)
             res["workloads"][name] = {"value": G / dtw / 1e6, "unit": "Msplats/s", "ms_per_step": dtw * 1e3, "steps": k2,
                                       "num_rendered": stw.num_rendered(), "overflowed": stw.overflowed(),
-                                      "split_quadrants": int(stw.header()[5].item()) if a.split_lists else 0,
+                                      "split_quadrants": int(stw.header()[5].item()) if a.split_lists else 0, "split_errors": stw.split_errors(),
                                       "workspace_bytes_forward": int(stw.layout.total_bytes), "workspace_bytes_backward": int(stw.layout.backward_bytes),
                                       "visible_pairs": int((stw.tensors()["tiles_touched"] > 0).sum().item()),
                                       "finite": bool(torch.isfinite(out["faces"]).all()), "kernels_avg_us": kw_us}

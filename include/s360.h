@@ -106,17 +106,20 @@ enum {
                                          chain per pixel block; a tile list of 10-17 K entries whose pixels do not saturate — the pole
                                          clumps of a panorama: the 1 024 Gaussians of every polar ERP row land on a few face pixels,
                                          /root/reference/src/geometry/utils360.py:93-104 — then costs one wave hundreds of microseconds
-                                         while the rest of the chip idles.  With the flag, an 8x8 quadrant that is still busy (more
-                                         than six unsaturated pixels) after the first 2 048 entries of a list with at least 1 024 more
-                                         hands the rest over in segments of 1 024 entries: one wave per segment composites it from
-                                         T = 1, a per-pixel combine applies C += T C_k, T *= T_k in list order, and a pixel whose stop
-                                         test `T (1 - alpha) < 1e-4` can trip inside a segment replays that segment sequentially from
-                                         its exact incoming state.  The backward composites the same segments in parallel from the
-                                         forward's per-segment transmittance and the colour accumulated behind each segment.  What
-                                         changes: floating-point association inside split quadrants only (<= 1e-6 per pixel measured,
-                                         north_star's bar is 1e-5); n_contrib, the stop decisions and every integer stay those of the
-                                         sequential walk.  Quadrants that do not split — every list up to 3 071 entries, and every
-                                         quadrant that saturates within its first 2 048 — are bit-identical with and without the flag. */
+                                         while the rest of the chip idles.  With the flag, an 8x8 quadrant that after the first 1 024
+                                         entries of a list of more than 2 048 still holds a pixel far from saturating (T >= 1/16) hands
+                                         the rest over in segments of 512 entries, one wave each: phase 1 forms every segment's own
+                                         transmittance T_k per pixel, phase 2 composites the segment with the sequential rule from the
+                                         pixel's true incoming transmittance T_head T_2 ... T_(k-1) (pixels that stopped earlier are
+                                         skipped), a combine adds the contributions in list order.  The backward composites the same
+                                         segments in parallel from the forward's transmittance behind each segment and the colour
+                                         accumulated behind it.  What changes: floating-point association — a pixel's transmittance
+                                         at a segment start is a product of segment products (images within 1e-6 of the sequential
+                                         composite; north_star's bar is 1e-5) — and with it a stop decision where a product lands
+                                         within rounding of 1e-4.  Every (pixel, entry) pair is evaluated with the same arithmetic and
+                                         the same stop rule in list order.  Quadrants that do not split — every list up to 2 048
+                                         entries, every quadrant that is (nearly) saturated after 1 024 — are bit-identical with and
+                                         without the flag. */
 
 typedef struct S360View {
     float viewmatrix[16];
@@ -137,8 +140,12 @@ typedef struct S360Params {
     int32_t M;              /* SH coefficients stored per Gaussian per channel (shs.shape[1]); 0 = colors_precomp */
     uint32_t flags;         /* S360_FLAG_* */
     uint32_t max_instances; /* capacity of the binning buffers ((Gaussian,tile) pairs, "num_rendered") */
+    uint32_t max_segments;  /* S360_FLAG_SPLIT_LISTS: segment slots to reserve in the workspace (44 x 256 B each); 0 = enough for every
+                               list of the binning capacity to be long (max_instances / 256 slots).  A quadrant whose segments
+                               do not fit is composited sequentially (never an error).  header_mirror reports how many a call used. */
+    uint32_t _reserved;
     void* header_mirror;    /* NULL, or a HOST-visible (pinned / mapped) 8-byte aligned address: the forward also stores
-                               (num_instances | overflow flag << 32) there as one 64-bit word — the caller can size its next
+                               (num_instances | overflow flag << 32 | sort chunks of the long lists << 33) there as one 64-bit word — the caller can size its next
                                call from the previous call's count without a device synchronisation (upstream reads the count
                                back synchronously inside every forward; this library's callers may run without that read,
                                and this is how they learn the count and the overflow flag anyway) */
@@ -149,7 +156,8 @@ typedef struct S360Params {
 typedef struct S360Layout {
     size_t total_bytes;         /* forward workspace size */
     size_t header;              /* uint32[64]: [0]=num_instances [1]=overflow flag [2]=max tile list length [3]=merge passes needed
-                                   [4]=pairs with more than 32 instance slots [5]=split (tile, quadrant) units of this call */
+                                   [4]=pairs with more than 32 instance slots [5]=split (tile, quadrant) units of this call
+                                   [6]=their segments (work items in seg_info) */
     size_t tiles_touched;       /* uint32[V*P] */
     size_t vis_mask;            /* uint8[P]  bit v set: Gaussian visible in view v (V <= 8).  tiles_touched is written for
                                    visible pairs only; the kernels test visibility on this byte, not on V words */
@@ -170,8 +178,11 @@ typedef struct S360Layout {
                                    (cleared together with tile_count) */
     size_t seg_flag;            /* uint32[V*T*4] S360_FLAG_SPLIT_LISTS: 1 = this (tile, quadrant) handed the rest of its list over to
                                    segment waves after SEG_HEAD entries (cleared together with tile_count) */
-    size_t seg_arrive;          /* uint32[V*T*4] segment waves of a split quadrant that have delivered their partial result: the last
-                                   one to arrive runs the per-pixel combine (cleared together with tile_count) */
+    size_t seg_arrive;          /* uint32[V*T*4] segment waves of a split quadrant that have delivered their phase-1 result (the
+                                   segment's own transmittance); cleared together with tile_count */
+    size_t seg_arrive2;         /* uint32[V*T*4 + 1] ... their phase-2 result (the segment composited from its true incoming
+                                   transmittance): the last one to arrive runs the per-pixel combine; + the ticket counter of the
+                                   work queue; cleared together with tile_count */
     size_t tile_start;          /* uint32[V*T+1] exclusive scan (upstream ranges: [start[t], start[t+1])) */
     size_t tile_cursor;         /* uint32[V*T] */
     size_t chunk_start;         /* uint32[V*T+1] number of 4096-key sort chunks of long lists before tile t */
@@ -197,19 +208,20 @@ typedef struct S360Layout {
                                    [4 start_t + q n_t, ... + n_t), n_t = the tile's list length.  The backward composite
                                    streams them back to front instead of walking and culling the tile list a second time */
     size_t surv_count;          /* uint32[V*T*4] survivor records of a unit that lie in front of its last contributor */
-    /* S360_FLAG_SPLIT_LISTS state.  Segment SLOT s = 4 * chunk_start[t] + k is segment k (list positions [1024 k, 1024 (k+1)))
-     * of long tile t; NSEG = 4 (max_instances / 2048 + 1) slots.  Slots k = 0 of a split quadrant hold what its head wave
-     * published (the exact sequential state after 2 048 entries); k >= 2 the segment waves' partial results. */
-    size_t part_c;              /* float4[NSEG*4*64]  per (slot, quadrant, pixel): colour (r, g, b, depth) composited from T = 1 */
-    size_t part_t;              /* float [NSEG*4*64]  ... transmittance of the segment alone */
-    size_t part_l;              /* uint32[NSEG*4*64]  ... last contributing list position + 1 (0: none) | stopped << 31 */
+    /* S360_FLAG_SPLIT_LISTS state.  Segment SLOT s = 8 * chunk_start[t] + k is segment k (list positions [512 k, 512 (k+1)))
+     * of long tile t; NSEG = S360Params.max_segments slots.  Slots k = 0 of a split quadrant hold what its head wave
+     * published (the exact sequential state after the head); k >= 2 the segment waves' results. */
+    size_t part_c;              /* float4[NSEG*4*64]  per (slot, quadrant, pixel): the segment's colour contribution (r, g, b, depth) */
+    size_t part_t;              /* float [NSEG*4*64]  ... transmittance of the segment alone (phase 1; 0: the pixel stops inside it) */
+    size_t part_e;              /* float [NSEG*4*64]  ... transmittance behind the segment (phase 2) */
+    size_t part_l;              /* uint32[NSEG*4*64]  ... last contributing list position + 1 (0: none); slot 0: | done << 31 */
     size_t part_n;              /* uint32[NSEG*4]     survivor records the segment appended (slot k = 1: the head's count when no
                                    later segment contributes) */
     size_t seg_c;               /* float4[NSEG*4*64]  after the combine: colour accumulated BEHIND the segment (what the backward
                                    starts its colour-behind sum from) */
     size_t seg_t;               /* float [NSEG*4*64]  after the combine: transmittance behind the segment's last entry */
     size_t seg_cnt;             /* uint32[NSEG*4]     survivor records of the segment the backward replays (0: none / not split) */
-    size_t seg_info;            /* uint32[NSEG][2]    (tile, segment index k) of a slot */
+    size_t seg_info;            /* uint32[NSEG*4][2]  the segment work items of the call (header[6] of them): (tile, segment k << 2 | quadrant) */
     size_t backward_bytes;      /* size of the separate backward scratch workspace */
 } S360Layout;
 

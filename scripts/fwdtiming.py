@@ -1,5 +1,6 @@
 """Per-wave timing of the forward composite (build with S360_HIPCC_EXTRA=-DS360_DBG_TIMING): which (tile, quadrant) waves of
-k_render form its critical path on a given cloud?   usage: fwdtiming.py [encoder_like|surface_like|uniform]"""
+k_render — and, with S360_FLAG_SPLIT_LISTS, which segment waves of k_render_tail — form its critical path on a given cloud?
+usage: fwdtiming.py [encoder_like|surface_like|uniform] [split 0|1]"""
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -7,6 +8,7 @@ import numpy as np, torch
 from splatter360_amd import decoder, rasterizer, synthetic
 dev = torch.device("cuda:0")
 name = sys.argv[1] if len(sys.argv) > 1 else "surface_like"
+rasterizer.SPLIT_LONG_LISTS = bool(int(sys.argv[2])) if len(sys.argv) > 2 else True
 cloud = {"encoder_like": lambda: synthetic.encoder_like_cloud(512, 1024), "surface_like": lambda: synthetic.surface_like_cloud(512, 1024),
          "uniform": lambda: synthetic.uniform_cloud(1 << 20, seed=0, extent=5.0)}[name]()
 g = [torch.tensor(cloud[k], device=dev).requires_grad_(True) for k in ("means", "covariances", "harmonics", "opacities")]
@@ -16,24 +18,37 @@ for _ in range(3):
     st = rasterizer.last_state()
 torch.cuda.synchronize()
 nu = 1536 * 4
-d = st._arr(st.layout.keys_alt, 4 * nu, torch.int32).cpu().numpy().astype(np.int64) & 0xFFFFFFFF
 t = st.tensors()
 ts = t["tile_start"].cpu().numpy().astype(np.int64)
+nchunks = int(st._arr(st.layout.chunk_start, 1537, torch.int32)[1536].item())
+nseg = 1 if rasterizer.SPLIT_LONG_LISTS else 0
+d = st._arr(st.layout.keys_alt, 4 * nu, torch.int32).cpu().numpy().astype(np.int64) & 0xFFFFFFFF
 tl = np.repeat(ts[1:] - ts[:-1], 4)
 sl = st._arr(st.layout.strip_last, nu, torch.int32).cpu().numpy()
 sc = st._arr(st.layout.surv_count, nu, torch.int32).cpu().numpy()
-fT = t["final_T"].cpu().numpy().reshape(6, 16, 2, 8, 16, 2, 8)      # v, ty, qy, y, tx, qx, x
-unsat = (fT >= 1e-4).sum(axis=(3, 6)).transpose(0, 1, 3, 2, 4).reshape(-1)   # per (v, ty, tx, qy, qx) = unit order t*4 + (2 qy + qx)
-t0, dur = d[0::4], d[1::4] / 100.0
-start = ((t0 - t0.min()) & 0xFFFFFFFF) / 100.0
+flag = t["seg_flag"].cpu().numpy()
+t0, dur = d[0:4 * nu:4], d[1:4 * nu:4] / 100.0
+origin = t0.min()
+start = ((t0 - origin) & 0xFFFFFFFF) / 100.0
 end = start + dur
-print(name, "kernel span us", end.max(), " sum of durations / 6144 slots:", dur.sum() / 6144, " mean", dur.mean(), "p99", np.percentile(dur, 99), "max", dur.max())
-o = np.argsort(-dur)[:12]
+print(name, "split", rasterizer.SPLIT_LONG_LISTS, "k_render span us", round(end.max(), 1), " sum of durations / 6144 slots:", round(dur.sum() / 6144, 1), "p99", round(np.percentile(dur, 99), 1),
+      "max", dur.max(), " split quadrants", int((flag == 1).sum()))
+o = np.argsort(-dur)[:14]
 for i in o:
     print("unit", i, "face", i // 1024, "tile", (i // 4) % 256, "q", i % 4, "start", round(start[i], 1), "dur", round(dur[i], 1), "tile_len", tl[i],
-          "replay_len", sl[i], "surv_in_front", sc[i], "unsaturated_px", unsat[i])
-print("units that walk their whole list:", int((sl >= tl - 64).sum()), "of", nu, "; units with >= 1 unsaturated pixel:", int((unsat > 0).sum()),
-      "; with > 6:", int((unsat > 6).sum()))
-print("us per walked chunk (median over units with >= 8 chunks):", np.median((dur / np.maximum(np.ceil(np.minimum(sl + 64, tl) / 64), 1))[tl >= 512]))
+          "replay_len", sl[i], "surv_in_front", sc[i], "split", int(flag[i]))
+print("units that walk their whole list:", int(((sl >= tl - 64) & (flag != 1)).sum()), "of", nu)
 tsx = np.linspace(0, end.max(), 13)
 print("running waves at t:", [(round(x), int(((start <= x) & (end > x)).sum())) for x in tsx])
+if nseg:
+    nwork = int(st.header()[6].item())
+    d = st._arr(st.layout.keys_alt, 4 * (nu + nwork), torch.int32).cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    s0, p1, p2, tag = d[4 * nu::4], d[4 * nu + 1::4] / 100.0, d[4 * nu + 2::4] / 100.0, d[4 * nu + 3::4]
+    if nwork:
+        sst = ((s0 - origin) & 0xFFFFFFFF) / 100.0          # phase-1 start relative to k_render's first wave
+        comb = (tag >> 31) & 1
+        print("k_render_tail: segment work items", nwork, "phase-1 start min/max", round(sst.min(), 1), round(sst.max(), 1), "phase-1 end max", round((sst + p1).max(), 1),
+              "| phase 1 mean/max us", round(p1.mean(), 1), round(p1.max(), 1), "| phase 2 (incl. wait) mean/max", round(p2.mean(), 1), round(p2.max(), 1),
+              "| combiners", int(comb.sum()), "phase 2 + combine mean/max", round(p2[comb == 1].mean(), 1), round(p2[comb == 1].max(), 1))
+        for i in np.argsort(-p2)[:8]:
+            print("  item tile", int((tag[i] >> 12) & 0x7FFFF), "k", int((tag[i] >> 2) & 0x3FF), "q", int(tag[i] & 3), "p1 start", round(sst[i], 1), "p1", round(p1[i], 1), "p2", round(p2[i], 1), "combiner", int(comb[i]))

@@ -36,14 +36,15 @@ ABI_VERSION = 20
 class S360Params(C.Structure):
     _fields_ = [("P", C.c_int32), ("V", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
                 ("sh_degree", C.c_int32), ("M", C.c_int32), ("flags", C.c_uint32),
-                ("max_instances", C.c_uint32), ("header_mirror", C.c_void_p)]
+                ("max_instances", C.c_uint32), ("max_segments", C.c_uint32), ("_reserved", C.c_uint32),
+                ("header_mirror", C.c_void_p)]
 
 
 class S360Layout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in (
         "total_bytes", "header", "tiles_touched", "vis_mask", "slot_base", "rec_a", "rec_b", "rec_c",
-        "clamped", "depths", "tile_count", "slot_ticket", "merge_done", "seg_flag", "seg_arrive", "tile_start", "tile_cursor", "chunk_start", "tile_order", "keys", "keys_alt", "list", "final_T", "n_contrib",
-        "tile_max_contrib", "strip_last", "slot_pair", "long_pairs", "rgbc", "sh_jac", "surv", "surv_count", "part_c", "part_t", "part_l", "part_n", "seg_c", "seg_t", "seg_cnt", "seg_info", "backward_bytes")]
+        "clamped", "depths", "tile_count", "slot_ticket", "merge_done", "seg_flag", "seg_arrive", "seg_arrive2", "tile_start", "tile_cursor", "chunk_start", "tile_order", "keys", "keys_alt", "list", "final_T", "n_contrib",
+        "tile_max_contrib", "strip_last", "slot_pair", "long_pairs", "rgbc", "sh_jac", "surv", "surv_count", "part_c", "part_t", "part_e", "part_l", "part_n", "seg_c", "seg_t", "seg_cnt", "seg_info", "backward_bytes")]
 
 
 EXPORTS = ("s360_abi_version", "s360_error_string", "s360_layout", "s360_forward", "s360_forward_depth", "s360_forward_mse", "s360_backward", "s360_backward_split", "s360_backward_composite", "s360_backward_gaussians", "s360_unpack_gradients", "s360_sh_backward", "s360_pack_views", "s360_adapter_forward", "s360_adapter_backward", "s360_sh_rotation_blocks",

@@ -593,6 +593,7 @@ struct BwdCtx {
     uint32_t* order;
     float4* pairgrad;
     uint32_t* seg_list;   // S360_FLAG_SPLIT_LISTS: [0] = count, then the segment units that hold survivor records
+    size_t n_slots;       // segment slots of the forward workspace
 };
 
 static int bwd_ctx(const S360Params* prm, const void* workspace, size_t workspace_bytes, void* bwd_workspace,
@@ -622,6 +623,7 @@ static int bwd_ctx(const S360Params* prm, const void* workspace, size_t workspac
     }
     c.pairgrad = (float4*)((char*)(c.order + c.nt * 4) + 256 - ((uintptr_t)(c.order + c.nt * 4) & 255));
     c.seg_list = nullptr;
+    c.n_slots = seg_slots_of(prm);
     if (kp.flags & S360_FLAG_SPLIT_LISTS) {   // behind the pair records and the [P] summed dL/dRGB
         char* e = (char*)(c.pairgrad + (size_t)kp.V * (kp.P > 0 ? kp.P : 1) * 3 + (size_t)(kp.P > 0 ? kp.P : 1));
         c.seg_list = (uint32_t*)(e + 256 - ((uintptr_t)e & 255));
@@ -643,7 +645,7 @@ static int backward_composite(const BwdCtx& c, const S360View* views, const void
         ProfScope ps(PS_ORDER, st);
         hipLaunchKernelGGL(k_order_units, dim3(1 + 512), dim3(1024), 0, st, surv_count, c.order, c.nt * 4, c.valid_words, header, kp.cap,
                            (kp.flags & S360_FLAG_ATOMIC_GRADS) ? c.pairgrad : (float4*)nullptr, (const uint8_t*)(ws + L.vis_mask), kp.P, kp.V,
-                           (const uint32_t*)(ws + L.seg_cnt), (const uint32_t*)(ws + L.chunk_start) + c.nt, c.seg_list);
+                           (const uint32_t*)(ws + L.seg_cnt), (const uint32_t*)(ws + L.chunk_start), c.seg_list, (const uint2*)(ws + L.seg_info));
     }
     SegBwd sb{};
     if (c.seg_list) {
@@ -654,7 +656,7 @@ static int backward_composite(const BwdCtx& c, const S360View* views, const void
         sb.seg_cnt = (const uint32_t*)(ws + L.seg_cnt);
         sb.seg_info = (const uint2*)(ws + L.seg_info);
         sb.seg_list = c.seg_list;
-        sb.n_seg_blocks = (uint32_t)min((size_t)1024, seg_slots(kp.cap) * 4);
+        sb.n_seg_blocks = (uint32_t)min((size_t)1024, c.n_slots * 4);
         sb.dbg_base = (uint32_t)c.nt * 4u;
     }
     {

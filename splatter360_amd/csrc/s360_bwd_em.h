@@ -105,7 +105,7 @@ struct SegBwd {
     const float* seg_t;
     const uint32_t* seg_cnt;
     const uint2* seg_info;
-    const uint32_t* seg_list;     // [0] = number of segment units with survivor records, then their ids (slot * 4 + quadrant)
+    const uint32_t* seg_list;     // [0] = number of segment units with survivor records, then their indices into seg_info
     uint32_t n_seg_blocks;        // the launch's first n_seg_blocks workgroups take the segment units (grid-stride over seg_list)
     uint32_t dbg_base;            // S360_DBG_TIMING: first timing record of the segment units
 };
@@ -139,13 +139,13 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
     size_t sli = 0;     // split units: index of this (slot, quadrant)'s pixel 0 in seg_c / seg_t
     if (seg_blk) {
         if (sj >= sb.seg_list[0]) return;
-        const uint32_t su = sb.seg_list[1 + sj];          // slot * 4 + quadrant
-        const uint2 info = sb.seg_info[su >> 2];           // (tile, segment)
-        unit = 4u * info.x + (su & 3u);
-        kseg = info.y;
+        const uint2 info = sb.seg_info[sb.seg_list[1 + sj]];   // the forward's work item: (tile, segment << 2 | quadrant)
+        unit = 4u * info.x + (info.y & 3u);
+        kseg = info.y >> 2;
+        const size_t su = ((size_t)SEG_PER_CHUNK * sb.chunk_start[info.x] + kseg) * 4 + (info.y & 3u);   // slot * 4 + quadrant
         n_surv = sb.seg_cnt[su];
         split_unit = true;
-        sli = (size_t)su * 64;
+        sli = su * 64;
     } else {
         unit = order ? order[blockIdx.x - sb.n_seg_blocks] : blockIdx.x - sb.n_seg_blocks;  // tile*4 + quadrant
         n_surv = surv_count[unit];  // survivor records in front of the quadrant's last contributor

@@ -51,10 +51,26 @@ struct KParams {
 // at least SEG_MIN_REST more hands the rest over in segments of SEG_LEN entries (k_render_tail), one wave each.  Segment k covers
 // list positions [SEG_LEN k, SEG_LEN (k + 1)); its slot is SEG_PER_CHUNK * chunk_start[tile] + k (chunk_start: the sort's table of
 // 4 096-key chunks of the lists beyond 2 048 keys — every list that can split has chunks).
-constexpr uint32_t SEG_LEN = 1024, SEG_HEAD = 2048, SEG_MIN_REST = 1024, SEG_PER_CHUNK = 4;
+#ifndef S360_SEG_LEN
+#define S360_SEG_LEN 512
+#endif
+#ifndef S360_SEG_HEAD
+#define S360_SEG_HEAD 1024
+#endif
+#ifndef S360_SEG_MIN_REST
+#define S360_SEG_MIN_REST 512
+#endif
+constexpr uint32_t SEG_LEN = S360_SEG_LEN, SEG_HEAD = S360_SEG_HEAD, SEG_MIN_REST = S360_SEG_MIN_REST, SEG_PER_CHUNK = 4096 / SEG_LEN;
 constexpr uint32_t SEG_K0 = SEG_HEAD / SEG_LEN;   // first segment index a segment wave takes
+static_assert(4096 % SEG_LEN == 0 && SEG_HEAD % SEG_LEN == 0 && SEG_LEN % 64 == 0 && SEG_K0 >= 2, "segments tile the sort's 4 096-key chunks; slots 0 and 1 hold the head's state");
+__device__ constexpr float SEG_T_FAR = 1.0f / 16.0f;   // "far from saturating": at least four more opacity-0.5 contributions to go
 __host__ __device__ inline size_t seg_slots(size_t cap) { return (size_t)SEG_PER_CHUNK * (cap / 2048 + 1); }
-#define S360_HDR_SPLIT 5   /* header word: split (tile, quadrant) units of this call */
+// segment slots of a call: S360Params.max_segments, or enough for every list of the binning capacity to be long
+__host__ __device__ inline size_t seg_slots_of(const S360Params* prm) {
+    return prm->max_segments ? (size_t)prm->max_segments : seg_slots(prm->max_instances ? prm->max_instances : 1);
+}
+#define S360_HDR_SPLIT 5     /* header word: split (tile, quadrant) units of this call */
+#define S360_HDR_SEGWORK 6   /* header word: (tile, quadrant, segment) work items k_render queued for k_render_tail (seg_info[]) */
 
 // Real-SH constants (degree <= 3: public 3DGS table; degree 4: standard real-SH table).
 __device__ constexpr float kC0 = 0.28209479177387814f;
@@ -627,18 +643,18 @@ static __global__ __launch_bounds__(1024) void k_order_units(const uint32_t* __r
                                                      uint32_t* __restrict__ valid_words, const uint32_t* __restrict__ header,
                                                      uint32_t cap, float4* __restrict__ pairgrad_atomic,
                                                      const uint8_t* __restrict__ vis_mask, int P, int V,
-                                                     const uint32_t* __restrict__ seg_cnt, const uint32_t* __restrict__ n_chunks,
-                                                     uint32_t* __restrict__ seg_list) {
+                                                     const uint32_t* __restrict__ seg_cnt, const uint32_t* __restrict__ chunk_start,
+                                                     uint32_t* __restrict__ seg_list, const uint2* __restrict__ seg_info) {
     if (blockIdx.x == 2 && seg_list) {
         // S360_FLAG_SPLIT_LISTS: the segment units that hold survivor records, compacted (any order: every unit is self-contained) —
         // the backward composite's first workgroups take them grid-stride
         __shared__ uint32_t s_n;
         if (threadIdx.x == 0) s_n = 0u;
         __syncthreads();
-        if (header[S360_HDR_SPLIT] != 0u) {   // else the forward's k_render_tail returned at once and seg_cnt was never written
-            const uint32_t n = SEG_PER_CHUNK * n_chunks[0] * 4u;
-            for (uint32_t i = threadIdx.x; i < n; i += 1024)
-                if (seg_cnt[i]) seg_list[1u + atomicAdd(&s_n, 1u)] = i;
+        const uint32_t n = header[S360_HDR_SEGWORK];   // the forward's work items: (tile, segment << 2 | quadrant)
+        for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+            const uint2 w = seg_info[i];
+            if (seg_cnt[((size_t)SEG_PER_CHUNK * chunk_start[w.x] + (w.y >> 2)) * 4 + (w.y & 3u)]) seg_list[1u + atomicAdd(&s_n, 1u)] = i;
         }
         __syncthreads();
         if (threadIdx.x == 0) seg_list[0] = s_n;

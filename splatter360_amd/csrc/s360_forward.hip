@@ -608,7 +608,8 @@ __global__ __launch_bounds__(TS_BLOCK) void k_tile_scan(const uint32_t* __restri
         header[6] = header[7] = 0;
         // S360Params.header_mirror: the count and the overflow flag as ONE 64-bit store into host-visible memory — the caller's
         // next call sizes its buffers from it without ever synchronising with the device
-        if (header_mirror) __hip_atomic_store(header_mirror, (unsigned long long)carry | ((unsigned long long)(carry > cap ? 1u : 0u) << 32),
+        if (header_mirror) __hip_atomic_store(header_mirror, (unsigned long long)carry | ((unsigned long long)(carry > cap ? 1u : 0u) << 32) |
+                                                             ((unsigned long long)ccarry << 33),   // + sort chunks of the long lists: sizes max_segments
                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         for (int i = 8; i < 24; ++i) header[i] = 0;  // debug counters; [16, 24): deferred-loss hand-over (S360_HDR_LOSS), set by k_render
     }
@@ -1167,9 +1168,12 @@ __global__ __launch_bounds__(MSE_BLOCK) void k_mse_finish(const float* __restric
 struct SegBufs {
     const uint32_t* chunk_start;  // null: splitting off
     uint32_t* seg_flag;
-    uint32_t* seg_arrive;
+    uint32_t* seg_arrive;         // phase-1 deliveries per (tile, quadrant)
+    uint32_t* seg_arrive2;        // phase-2 deliveries per (tile, quadrant); [V*T*4] = the ticket counter of the work queue
+    uint32_t n_slots;             // segment slots the workspace holds (quadrants whose segments do not fit are not split)
     float4* part_c;
     float* part_t;
+    float* part_e;
     uint32_t* part_l;
     uint32_t* part_n;
     float4* seg_c;
@@ -1257,14 +1261,19 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
         if (WITH_DEPTH) nz = depths[p_n1];
     }
     // S360_FLAG_SPLIT_LISTS: where this quadrant may hand the rest of its list over to segment waves (k_render_tail)
-    const uint32_t split_at = (sg.chunk_start && end - start >= SEG_HEAD + SEG_MIN_REST) ? start + SEG_HEAD : 0xFFFFFFFFu;
+    // (lists beyond SORT_SHORT keys only: those own segment slots through the sort's chunk table)
+    const uint32_t split_at = (sg.chunk_start && end - start >= SEG_HEAD + SEG_MIN_REST && end - start > SORT_SHORT) ? start + SEG_HEAD : 0xFFFFFFFFu;
     bool went = false;
     for (uint32_t b = start; b < end; b += 64) {
         const unsigned long long act = __ballot(!done);
         if (act == 0ull) break;
-        if (b == split_at && __popcll(act) > SPARSE_PIXELS) {   // wave-uniform: still busy after SEG_HEAD entries, >= SEG_MIN_REST to go
-            went = true;
-            break;
+        if (b == split_at) {   // wave-uniform.  Hand over when some pixel is still FAR from saturating (a pixel about to stop would make
+                               // the segment waves speculate for nothing: the headline cloud's polar lists) and the slots exist
+            const bool far_px = !done && T >= SEG_T_FAR;
+            if (__ballot(far_px) != 0ull && (SEG_PER_CHUNK * sg.chunk_start[t] + (end - start + SEG_LEN - 1) / SEG_LEN) <= sg.n_slots) {
+                went = true;
+                break;
+            }
         }
         const float4 ea = na, eb = nb;
         // fused depth "colour" of this lane's entry: camera z in unscaled units, then the reference's mode
@@ -1432,13 +1441,19 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
         sg.part_t[li] = T;
         sg.part_l[li] = last | (done ? 0x80000000u : 0u);
         const uint32_t wmh = wave_max_u32(inside ? last : 0u);
+        // the quadrant's segments join the work list of k_render_tail: (tile, segment << 2 | quadrant), in ascending segment order
+        const uint32_t nseg = (end - start + SEG_LEN - 1) / SEG_LEN - SEG_K0;
+        uint32_t wbase = 0;
         if (lane == 0) {
             sg.part_n[slot * 4 + wave] = scount;        // survivor records of the head
             // ... and how many of them lie in front of the head's last contributor (what the backward replays if no segment adds one)
             sg.part_n[(slot + 1) * 4 + wave] = wmh ? sv_cnt + (uint32_t)__popcll(sv_m & ((2ull << (wmh - 1u - sv_rel)) - 1ull)) : 0u;
             sg.seg_flag[4 * t + wave] = 1u;
             atomicAdd(&sg.header[S360_HDR_SPLIT], 1u);
+            wbase = atomicAdd(&sg.header[S360_HDR_SEGWORK], nseg);
         }
+        wbase = (uint32_t)__shfl((int)wbase, 0);
+        for (uint32_t i = (uint32_t)lane; i < nseg; i += 64u) sg.seg_info[wbase + i] = make_uint2((uint32_t)t, ((SEG_K0 + i) << 2) | (uint32_t)wave);
 #ifdef S360_DBG_TIMING
         if (lane == 0) {
             dbg[4 * (4 * t + wave)] = (uint32_t)t_begin;
@@ -1505,15 +1520,24 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
 
 // ------------------------------------------------------------------------------ split lists: segment waves + combine
 // S360_FLAG_SPLIT_LISTS, second launch of the composite.  k_render left, for every split (tile, quadrant), the exact per-pixel state
-// after SEG_HEAD entries.  Here one wave per (tile, quadrant, segment k >= SEG_K0) composites list positions [SEG_LEN k, SEG_LEN (k+1))
-// from T = 1 with the same per-(pixel, entry) arithmetic as k_render — a pixel stops locally when ITS OWN product trips the 1e-4 test,
-// which implies the true one does — appends the segment's survivor records for the backward, and delivers (C_k, T_k, last_k, stopped)
-// per pixel.  The wave that delivers last (device-coherent stores, drained, then one agent-scope counter) combines, per pixel and in
-// list order:  a pixel that cannot stop inside segment k (not stopped locally and T T_k >= 1.001e-4) takes the segment as a block,
-// C += T C_k, T *= T_k; any other pixel REPLAYS the segment from its exact incoming T with the sequential rule (so the stop decision,
-// n_contrib and final_T are those of a front-to-back walk; what differs from it is floating-point association: a block is a sum of
-// products formed from 1 instead of from T).  The combine leaves, for the backward, the transmittance behind every segment and the
-// colour accumulated behind it, writes the pixels exactly like k_render's epilogue and sizes the backward's units.
+// after SEG_HEAD entries.  The rest of the list, [SEG_HEAD, n), is cut into segments of SEG_LEN entries; ONE launch of persistent
+// workgroups takes (phase, segment) work units in ticket order — all phase-1 units first:
+//   phase 1  one wave per (tile, quadrant, segment k): the TRANSMITTANCE of the segment alone, T_k = prod (1 - alpha) over its
+//            accepted entries, per pixel, from T = 1 (a pixel whose own product trips the 1e-4 test is finished inside the segment
+//            whatever came before: T_k := 0) — the alpha evaluations of the composite without its colour arithmetic;
+//   phase 2  (after every phase-1 unit of the quadrant has delivered: only ever a wait for LOWER tickets, which running workgroups
+//            hold, so the schedule cannot deadlock whatever share of the grid is resident — k_merge_all's argument) the same wave
+//            composites its segment with k_render's sequential rule from the pixel's true incoming transmittance
+//            T_in(k) = T_head * T_K0 * ... * T_(k-1)  (a fixed left-to-right product); a pixel with T_in(k) < 1e-4 has stopped in an
+//            earlier segment and is skipped.  It appends the segment's survivor records (training calls) and delivers its colour
+//            contribution, transmittance behind it and last contributor;
+//   combine  the wave that delivers last adds the contributions in list order, writes the pixels exactly like k_render's epilogue,
+//            and leaves per segment what the backward starts from: transmittance behind it, colour accumulated behind it.
+// Every (pixel, entry) pair is evaluated with k_render's arithmetic and k_render's stop rule, in list order, from a transmittance
+// that differs from the sequential product only by floating-point association (T_in is a product of segment products): images
+// within 1e-6 of the unsplit composite, stop decisions identical except where a product lands within rounding of 1e-4.
+// Exchanges between workgroups of the launch use device-coherent accesses, drained (s_waitcnt vmcnt(0)) before ONE agent-scope
+// counter is bumped — the pattern of k_merge_all.
 __device__ __forceinline__ void st_dev32(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint32_t ld_dev32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_devf(float* p, float v) { st_dev32(reinterpret_cast<uint32_t*>(p), __float_as_uint(v)); }
@@ -1527,7 +1551,8 @@ struct WaveLds {   // one wave's slices of the compaction arrays (see k_render)
 
 // k_render's chunk loop over list positions [b0, b1) of the tile that starts at `start` (b0 - start a multiple of 64), on the
 // running per-pixel state (T, C01, C2D, last, done); sv != null: survivor records appended at sv[3 (scount + rank)].
-template <bool WITH_DEPTH>
+// T_ONLY: transmittance and stop logic alone (phase 1).
+template <bool WITH_DEPTH, bool T_ONLY>
 __device__ __forceinline__ void composite_segment(const uint32_t* __restrict__ list, const float4* __restrict__ recA, const float* __restrict__ depths,
                                                   uint32_t start, uint32_t b0, uint32_t b1, float pxf, float pyf, float x0, float ys0, int lane,
                                                   const WaveLds& L, float inv_scale, float v_near, float v_far, int depth_mode, float& T, f2& C01,
@@ -1541,14 +1566,14 @@ __device__ __forceinline__ void composite_segment(const uint32_t* __restrict__ l
         na = recA[3 * (size_t)(p_n1)];
         nb = recA[3 * (size_t)(p_n1) + 1];
         nc = recA[3 * (size_t)(p_n1) + 2];
-        if (WITH_DEPTH) nz = depths[p_n1];
+        if (WITH_DEPTH && !T_ONLY) nz = depths[p_n1];
     }
     for (uint32_t b = b0; b < b1; b += 64) {
         const unsigned long long act = __ballot(!done);
         if (act == 0ull) break;
         const float4 ea = na, eb = nb;
         float ez = 0.f;
-        if (WITH_DEPTH) ez = depth_value(nz * inv_scale, v_near, v_far, depth_mode);
+        if (WITH_DEPTH && !T_ONLY) ez = depth_value(nz * inv_scale, v_near, v_far, depth_mode);
         const float ec = nc.x, erad = nc.y, eka = nc.z, ekb = nc.w;
         const bool ev = b + lane < b1;
         const uint32_t epair = p_n1;
@@ -1557,7 +1582,7 @@ __device__ __forceinline__ void composite_segment(const uint32_t* __restrict__ l
             na = recA[3 * (size_t)(p_n1)];
             nb = recA[3 * (size_t)(p_n1) + 1];
             nc = recA[3 * (size_t)(p_n1) + 2];
-            if (WITH_DEPTH) nz = depths[p_n1];
+            if (WITH_DEPTH && !T_ONLY) nz = depths[p_n1];
         }
         if (b + 128 + lane < b1) p_n2 = list[b + 128 + lane];
         const bool hit = ev && quadrant_hit(ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, eka, ekb, x0, ys0);
@@ -1565,7 +1590,7 @@ __device__ __forceinline__ void composite_segment(const uint32_t* __restrict__ l
         if (m == 0ull) continue;
         const uint32_t rel = b - start;  // list position of this chunk's lane 0
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        if (sv && hit) {
+        if (!T_ONLY && sv && hit) {
             float4* o = sv + 3 * (size_t)(scount + rank);
             o[0] = ea;
             o[1] = eb;
@@ -1577,25 +1602,26 @@ __device__ __forceinline__ void composite_segment(const uint32_t* __restrict__ l
             if (hit) {
                 L.x[rank] = ea.x; L.y[rank] = ea.y; L.a[rank] = ea.z; L.b[rank] = ea.w;
                 L.c[rank] = eb.x; L.o[rank] = eb.y;
-                L.rg[rank] = make_float2(eb.z, eb.w);
-                L.bz[rank] = make_float2(ec, ez);
-                L.pos[rank] = rel + (uint32_t)lane + 1u;
+                if (!T_ONLY) {
+                    L.rg[rank] = make_float2(eb.z, eb.w);
+                    L.bz[rank] = make_float2(ec, ez);
+                    L.pos[rank] = rel + (uint32_t)lane + 1u;
+                }
             }
             if (lane < 3) {  // null records: opacity 0
                 L.x[cnt + lane] = 0.f; L.y[cnt + lane] = 0.f; L.a[cnt + lane] = 0.f; L.b[cnt + lane] = 0.f;
                 L.c[cnt + lane] = 0.f; L.o[cnt + lane] = 0.f;
-                L.rg[cnt + lane] = make_float2(0.f, 0.f);
-                L.bz[cnt + lane] = make_float2(0.f, 0.f);
-                L.pos[cnt + lane] = 0u;
+                if (!T_ONLY) {
+                    L.rg[cnt + lane] = make_float2(0.f, 0.f);
+                    L.bz[cnt + lane] = make_float2(0.f, 0.f);
+                    L.pos[cnt + lane] = 0u;
+                }
             }
             const f2 pxf2 = f2{pxf, pxf}, pyf2 = f2{pyf, pyf};
             for (uint32_t i = 0; i < cnt; i += 4) {
                 const float4 vx = *reinterpret_cast<const float4*>(&L.x[i]), vy = *reinterpret_cast<const float4*>(&L.y[i]),
                              va = *reinterpret_cast<const float4*>(&L.a[i]), vb = *reinterpret_cast<const float4*>(&L.b[i]),
                              vc = *reinterpret_cast<const float4*>(&L.c[i]), vo = *reinterpret_cast<const float4*>(&L.o[i]);
-                const float4 rg01 = *reinterpret_cast<const float4*>(&L.rg[i]), rg23 = *reinterpret_cast<const float4*>(&L.rg[i + 2]);
-                const float4 bz01 = *reinterpret_cast<const float4*>(&L.bz[i]), bz23 = *reinterpret_cast<const float4*>(&L.bz[i + 2]);
-                const uint4 vp = *reinterpret_cast<const uint4*>(&L.pos[i]);
                 float al[4], om[4];
                 bool ok[4];
                 bool any_ok = false;
@@ -1618,23 +1644,37 @@ __device__ __forceinline__ void composite_segment(const uint32_t* __restrict__ l
                     any_ok = any_ok || ok[2 * j] || ok[2 * j + 1];
                 }
                 if (__ballot(any_ok) == 0ull) continue;  // wave-uniform
-                const f2 rg[4] = {f2{rg01.x, rg01.y}, f2{rg01.z, rg01.w}, f2{rg23.x, rg23.y}, f2{rg23.z, rg23.w}};
-                const f2 bz[4] = {f2{bz01.x, bz01.y}, f2{bz01.z, bz01.w}, f2{bz23.x, bz23.y}, f2{bz23.z, bz23.w}};
-                const uint32_t posk[4] = {vp.x, vp.y, vp.z, vp.w};
+                if (T_ONLY) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool v = ok[e] && !done;
-                    const float test_T = T * om[e];
-                    const bool stop = v && test_T < 0.0001f;
-                    const bool contrib = v && !stop;
-                    done = done || stop;
-                    const float w = contrib ? al[e] * T : 0.0f;
-                    const f2 w2 = f2{w, w};
-                    C01 = C01 + rg[e] * w2;
-                    if (WITH_DEPTH) C2D = C2D + bz[e] * w2;
-                    else C2D.x = C2D.x + bz[e].x * w;
-                    T = contrib ? test_T : T;
-                    last = contrib ? posk[e] : last;
+                    for (int e = 0; e < 4; ++e) {
+                        const bool v = ok[e] && !done;
+                        const float test_T = T * om[e];
+                        const bool stop = v && test_T < 0.0001f;
+                        done = done || stop;
+                        T = (v && !stop) ? test_T : T;
+                    }
+                } else {
+                    const float4 rg01 = *reinterpret_cast<const float4*>(&L.rg[i]), rg23 = *reinterpret_cast<const float4*>(&L.rg[i + 2]);
+                    const float4 bz01 = *reinterpret_cast<const float4*>(&L.bz[i]), bz23 = *reinterpret_cast<const float4*>(&L.bz[i + 2]);
+                    const uint4 vp = *reinterpret_cast<const uint4*>(&L.pos[i]);
+                    const f2 rg[4] = {f2{rg01.x, rg01.y}, f2{rg01.z, rg01.w}, f2{rg23.x, rg23.y}, f2{rg23.z, rg23.w}};
+                    const f2 bz[4] = {f2{bz01.x, bz01.y}, f2{bz01.z, bz01.w}, f2{bz23.x, bz23.y}, f2{bz23.z, bz23.w}};
+                    const uint32_t posk[4] = {vp.x, vp.y, vp.z, vp.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool v = ok[e] && !done;
+                        const float test_T = T * om[e];
+                        const bool stop = v && test_T < 0.0001f;
+                        const bool contrib = v && !stop;
+                        done = done || stop;
+                        const float w = contrib ? al[e] * T : 0.0f;
+                        const f2 w2 = f2{w, w};
+                        C01 = C01 + rg[e] * w2;
+                        if (WITH_DEPTH) C2D = C2D + bz[e] * w2;
+                        else C2D.x = C2D.x + bz[e].x * w;
+                        T = contrib ? test_T : T;
+                        last = contrib ? posk[e] : last;
+                    }
                 }
             }
         } else {
@@ -1655,13 +1695,15 @@ __device__ __forceinline__ void composite_segment(const uint32_t* __restrict__ l
                     const float test_T = T * (1.0f - a_s);
                     const bool stop = mine && test_T < 0.0001f;
                     const bool contrib = mine && !stop;
-                    const float w = contrib ? a_s * T : 0.0f;
-                    C01.x += rl(eb.z, eb_) * w;
-                    C01.y += rl(eb.w, eb_) * w;
-                    C2D.x += rl(ec, eb_) * w;
-                    if (WITH_DEPTH) C2D.y += rl(ez, eb_) * w;
+                    if (!T_ONLY) {
+                        const float w = contrib ? a_s * T : 0.0f;
+                        C01.x += rl(eb.z, eb_) * w;
+                        C01.y += rl(eb.w, eb_) * w;
+                        C2D.x += rl(ec, eb_) * w;
+                        if (WITH_DEPTH) C2D.y += rl(ez, eb_) * w;
+                        last = contrib ? rel + (uint32_t)eb_ + 1u : last;
+                    }
                     T = contrib ? test_T : T;
-                    last = contrib ? rel + (uint32_t)eb_ + 1u : last;
                     done = done || stop;
                     if (__ballot(stop) != 0ull) break;
                 }
@@ -1670,8 +1712,14 @@ __device__ __forceinline__ void composite_segment(const uint32_t* __restrict__ l
     }
 }
 
+#ifndef S360_TAIL_GRID
+#define S360_TAIL_GRID 1024
+#endif
+#ifndef S360_TAIL_WAVES
+#define S360_TAIL_WAVES 4   // waves per SIMD of k_render_tail (128 VGPRs; 3 = unconstrained: 141 VGPRs)
+#endif
 template <bool WITH_DEPTH>
-__global__ __launch_bounds__(S360_BLOCK) void k_render_tail(KParams kp, const S360View* __restrict__ views, const uint32_t* __restrict__ tile_start,
+__global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(S360_TAIL_WAVES, S360_TAIL_WAVES))) void k_render_tail(KParams kp, const S360View* __restrict__ views, const uint32_t* __restrict__ tile_start,
                                                             const uint32_t* __restrict__ list, const float4* __restrict__ recA,
                                                             float* __restrict__ images, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
                                                             uint32_t* __restrict__ tile_max_contrib, uint32_t* __restrict__ strip_last,
@@ -1683,23 +1731,40 @@ __global__ __launch_bounds__(S360_BLOCK) void k_render_tail(KParams kp, const S3
     __shared__ __attribute__((aligned(16))) float2 s_rg[S360_BLOCK / 64][68], s_bz[S360_BLOCK / 64][68];
     __shared__ __attribute__((aligned(16))) uint32_t s_pos[S360_BLOCK / 64][68];
     if (sg.header[S360_HDR_SPLIT] == 0u) return;   // no quadrant of this call split
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const WaveLds L{s_x[wave], s_y[wave], s_a[wave], s_b[wave], s_c[wave], s_o[wave], s_rg[wave], s_bz[wave], s_pos[wave]};
-    const uint32_t nunits = SEG_PER_CHUNK * sg.chunk_start[nt];
-    for (uint32_t u = blockIdx.x; u < nunits; u += gridDim.x) {
+    const int pwave = threadIdx.x >> 6, lane = threadIdx.x & 63;   // pwave: this wave's LDS slices; its quadrant comes with the work item
+    const WaveLds L{s_x[pwave], s_y[pwave], s_a[pwave], s_b[pwave], s_c[pwave], s_o[pwave], s_rg[pwave], s_bz[pwave], s_pos[pwave]};
+    const uint32_t nwork = sg.header[S360_HDR_SEGWORK];       // (tile, quadrant, segment) items k_render queued
+    uint32_t* const queue = sg.seg_arrive2 + (size_t)nt * 4;   // the ticket counter (cleared with the arrival counters)
+    uint32_t guard = 0;
+    for (;;) {   // every WAVE takes its own tickets: [0, nwork) = phase 1 of every item, [nwork, 2 nwork) = phase 2
+        uint32_t tk = 0;
+        if (lane == 0) tk = __hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // broadcast BY VALUE to every lane (not v_readfirstlane: were the compiler to treat this loop as divergent, the lanes that
+        // are not lane 0 would carry ticket 0 for ever — seen: a build whose loop structure did exactly that hung the GPU)
+        tk = (uint32_t)__shfl((int)tk, 0);
+        if (tk >= 2u * nwork) break;
+        const uint32_t phase = tk >= nwork ? 1u : 0u, wi = tk - phase * nwork;
 #ifdef S360_DBG_TIMING
         const long long t_begin = wall_clock64();
 #endif
-        const ChunkUnit cu = chunk_unit(tile_start, sg.chunk_start, nt, kp.cap, u / SEG_PER_CHUNK);
-        const uint32_t k = cu.k * SEG_PER_CHUNK + (u % SEG_PER_CHUNK);
-        const int t = (int)cu.t;
-        const uint32_t start = cu.s, n = cu.n, end = start + n;
-        if (threadIdx.x == 0) sg.seg_info[u] = make_uint2((uint32_t)t, k);
-        const bool valid = cu.valid && k >= SEG_K0 && k * SEG_LEN < n && sg.seg_flag[4 * t + wave] == 1u;   // wave-uniform
-        if (!valid) {
-            if (lane == 0) sg.seg_cnt[(size_t)u * 4 + wave] = 0u;
+        const uint2 item = sg.seg_info[wi];
+        const int t = (int)item.x, wave = (int)(item.y & 3u);
+        const uint32_t k = item.y >> 2;
+        if ((uint32_t)t >= (uint32_t)nt || ++guard > 100000u) {   // corrupt work item / runaway loop: an error word, never a hung GPU
+            if (lane == 0 && atomicAdd(&sg.header[7], 0x10000u) == 0u) {
+                sg.header[8] = item.x; sg.header[9] = item.y; sg.header[12] = tk; sg.header[13] = nwork; sg.header[14] = guard;
+            }
+            if (guard > 100000u) break;
             continue;
         }
+        const uint32_t start = min(tile_start[t], kp.cap), end = min(tile_start[t + 1], kp.cap), n = end - start;
+        if (k < SEG_K0 || k * SEG_LEN >= n || sg.seg_flag[4 * t + wave] != 1u) {
+            if (lane == 0 && atomicAdd(&sg.header[7], 0x100u) == 0u) {
+                sg.header[8] = item.x; sg.header[9] = item.y; sg.header[10] = n; sg.header[12] = tk; sg.header[13] = nwork;
+            }
+            continue;
+        }
+        const size_t u = (size_t)SEG_PER_CHUNK * sg.chunk_start[t] + k;     // the segment's slot
         const int v = t / kp.T, rem = t - v * kp.T;
         const int ty = rem / kp.gx, tx = rem - ty * kp.gx;
         const int lx = sub_ox(wave) + lane % SUB_W, ly = sub_oy(wave) + lane / SUB_W;
@@ -1710,88 +1775,110 @@ __global__ __launch_bounds__(S360_BLOCK) void k_render_tail(KParams kp, const S3
         const int vcam = view_of_image(kp, v);
         const float inv_scale = WITH_DEPTH ? 1.0f / views[vcam].scale : 0.f;
         const float v_near = WITH_DEPTH ? views[vcam].near_plane : 0.f, v_far = WITH_DEPTH ? views[vcam].far_plane : 0.f;
-        float4* const sv_unit = surv ? surv + 3 * ((size_t)4 * start + (size_t)wave * n) : nullptr;
         const uint32_t K = (n + SEG_LEN - 1) / SEG_LEN;   // segments of the list, the head's SEG_K0 included
-        {   // ---- this wave's segment, composited from T = 1
+        const uint32_t b0 = start + k * SEG_LEN, b1 = min(b0 + SEG_LEN, end);
+        const size_t slot0 = u - k;                       // slot of segment 0 of this tile (= SEG_PER_CHUNK * chunk_start[t])
+        const size_t li0 = (slot0 * 4 + wave) * 64 + lane, li = ((size_t)u * 4 + wave) * 64 + lane;
+        if (phase == 0u) {
+            // ---- phase 1: the segment's own transmittance per pixel
             float T = 1.0f;
+            f2 c01 = f2{0.f, 0.f}, c2d = f2{0.f, 0.f};
+            uint32_t last = 0, cnt = 0;
+            bool done = !inside;
+            composite_segment<WITH_DEPTH, true>(list, recA, depths, start, b0, b1, pxf, pyf, x0, ys0, lane, L, inv_scale, v_near, v_far, depth_mode, T,
+                                                c01, c2d, last, done, nullptr, cnt);
+            st_devf(sg.part_t + li, (done && inside) ? 0.0f : T);   // stopped on its own: finished inside this segment at the latest
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(&sg.seg_arrive[4 * t + wave], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef S360_DBG_TIMING
+            if (lane == 0) {
+                const size_t di = 4 * ((size_t)4 * nt + wi);
+                dbg[di] = (uint32_t)t_begin;
+                dbg[di + 1] = (uint32_t)(wall_clock64() - t_begin);
+            }
+#endif
+            continue;
+        }
+        // ---- phase 2: wait for the quadrant's phase-1 results (lower tickets, held by running workgroups), then the segment itself
+        if (lane == 0) {
+            // bounded (~1 s): a logic error must surface as an error word in the header (header[7], checked by the tests), never as a hung GPU
+            uint32_t spins = 0;
+            while (__hip_atomic_load(&sg.seg_arrive[4 * t + wave], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < K - SEG_K0) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1u << 22)) {
+                    if (atomicAdd(&sg.header[7], 1u) == 0u) {
+                        sg.header[8] = (uint32_t)t; sg.header[9] = (k << 2) | (uint32_t)wave; sg.header[10] = K - SEG_K0;
+                        sg.header[11] = __hip_atomic_load(&sg.seg_arrive[4 * t + wave], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        sg.header[12] = tk; sg.header[13] = nwork;
+                    }
+                    break;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        float T;
+        bool head_done;
+        {   // the head's state (written by k_render: the previous launch) and the fixed left-to-right product of the segments in front
+            const uint32_t l = sg.part_l[li0];
+            head_done = (l >> 31) != 0u || !inside;
+            T = sg.part_t[li0];
+            for (uint32_t kk = SEG_K0; kk < k; ++kk) T = T * ld_devf(sg.part_t + ((slot0 + kk) * 4 + wave) * 64 + lane);
+        }
+        {
             f2 C01 = f2{0.f, 0.f}, C2D = f2{0.f, 0.f};
             uint32_t last = 0, scount = 0;
-            bool done = !inside;
-            const uint32_t b0 = start + k * SEG_LEN, b1 = min(b0 + SEG_LEN, end);
-            composite_segment<WITH_DEPTH>(list, recA, depths, start, b0, b1, pxf, pyf, x0, ys0, lane, L, inv_scale, v_near, v_far, depth_mode, T, C01,
-                                          C2D, last, done, sv_unit ? sv_unit + 3 * (size_t)(k * SEG_LEN) : nullptr, scount);
-            const size_t li = ((size_t)u * 4 + wave) * 64 + lane;
+            bool done = head_done || T < 0.0001f;    // stopped in an earlier segment (its product took T below the stop threshold)
+            float4* const sv_unit = surv ? surv + 3 * ((size_t)4 * start + (size_t)wave * n) : nullptr;
+            composite_segment<WITH_DEPTH, false>(list, recA, depths, start, b0, b1, pxf, pyf, x0, ys0, lane, L, inv_scale, v_near, v_far, depth_mode, T,
+                                                 C01, C2D, last, done, sv_unit ? sv_unit + 3 * (size_t)(k * SEG_LEN) : nullptr, scount);
             float* pc = reinterpret_cast<float*>(sg.part_c + li);
             st_devf(pc, C01.x); st_devf(pc + 1, C01.y); st_devf(pc + 2, C2D.x); st_devf(pc + 3, C2D.y);
-            st_devf(sg.part_t + li, T);
-            st_dev32(sg.part_l + li, last | ((done && inside) ? 0x80000000u : 0u));
+            st_devf(sg.part_e + li, T);         // transmittance behind the segment (unchanged where the pixel took nothing)
+            st_dev32(sg.part_l + li, last);
             if (lane == 0) st_dev32(sg.part_n + (size_t)u * 4 + wave, scount);
         }
-        // every lane drains its write-through stores, then ONE agent-scope counter says so (the pattern of k_merge_all)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         uint32_t arrived = 0;
-        if (lane == 0) arrived = __hip_atomic_fetch_add(&sg.seg_arrive[4 * t + wave], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
+        if (lane == 0) arrived = __hip_atomic_fetch_add(&sg.seg_arrive2[4 * t + wave], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        arrived = (uint32_t)__shfl((int)arrived, 0);
 #ifdef S360_DBG_TIMING
         if (lane == 0) {
-            const size_t di = 4 * ((size_t)4 * nt + (size_t)u * 4 + wave);
-            dbg[di] = (uint32_t)t_begin;
-            dbg[di + 1] = (uint32_t)(wall_clock64() - t_begin);
-            dbg[di + 2] = (uint32_t)t;
-            dbg[di + 3] = (k << 8) | (uint32_t)wave;
+            const size_t di = 4 * ((size_t)4 * nt + wi);
+            dbg[di + 2] = (uint32_t)(wall_clock64() - t_begin);
+            dbg[di + 3] = ((uint32_t)t << 12) | (k << 2) | (uint32_t)wave;
         }
 #endif
         if (arrived + 1u != K - SEG_K0) continue;   // wave-uniform: another segment of this quadrant is still out
         // ---- combine: this wave delivered last
-        const size_t slot0 = (size_t)u - k;         // slot of segment 0 of this tile (= SEG_PER_CHUNK * chunk_start[t])
-        const size_t li0 = (slot0 * 4 + wave) * 64 + lane;
-        float T;
         f2 C01, C2D;
         uint32_t last;
-        bool done;
-        {   // the head's state (written by k_render: the previous launch)
+        {
             const float4 c = sg.part_c[li0];
-            const uint32_t l = sg.part_l[li0];
             C01 = f2{c.x, c.y}; C2D = f2{c.z, c.w};
+            last = sg.part_l[li0] & 0x7FFFFFFFu;
             T = sg.part_t[li0];
-            last = l & 0x7FFFFFFFu;
-            done = (l >> 31) != 0u || !inside;
         }
         const float head_T = T;
-        for (uint32_t kk = SEG_K0; kk < K; ++kk) {
-            const size_t lik = ((slot0 + kk) * 4 + wave) * 64 + lane;
-            const float* pc = reinterpret_cast<const float*>(sg.part_c + lik);
-            const float c0 = ld_devf(pc), c1 = ld_devf(pc + 1), c2 = ld_devf(pc + 2), c3 = ld_devf(pc + 3);
-            const float pt = ld_devf(sg.part_t + lik);
-            const uint32_t pl = ld_dev32(sg.part_l + lik);
-            const bool pstop = (pl >> 31) != 0u;
-            const uint32_t plast = pl & 0x7FFFFFFFu;
-            // can this pixel's stop test trip inside the segment?  (0.1 % margin over the rounding of the two product orders)
-            const bool need = !done && (pstop || T * pt < 1.001e-4f);
-            f2 D01 = f2{0.f, 0.f}, D2D = f2{0.f, 0.f};
-            if (__ballot(need) != 0ull) {   // wave-uniform: sequential replay of the segment for those pixels, from their exact state
-                float rT = T;
-                f2 r01 = f2{0.f, 0.f}, r2d = f2{0.f, 0.f};
-                uint32_t rlast = 0, nosv = 0;
-                bool rdone = !need;
-                const uint32_t b0 = start + kk * SEG_LEN, b1 = min(b0 + SEG_LEN, end);
-                composite_segment<WITH_DEPTH>(list, recA, depths, start, b0, b1, pxf, pyf, x0, ys0, lane, L, inv_scale, v_near, v_far, depth_mode, rT,
-                                              r01, r2d, rlast, rdone, nullptr, nosv);
-                if (need) {
-                    D01 = r01; D2D = r2d;
-                    T = rT;
-                    last = rlast ? rlast : last;
-                    done = rdone || pstop;   // a local stop implies the true one (T <= 1); a one-ulp disagreement must not resurrect the pixel
+        {
+            float Tin = head_T;     // the same left-to-right product the segment waves formed: which segments this pixel was live in
+            for (uint32_t kk = SEG_K0; kk < K; ++kk) {
+                const size_t lik = ((slot0 + kk) * 4 + wave) * 64 + lane;
+                const bool live = !head_done && !(Tin < 0.0001f);
+                const float* pc = reinterpret_cast<const float*>(sg.part_c + lik);
+                const float c0 = ld_devf(pc), c1 = ld_devf(pc + 1), c2 = ld_devf(pc + 2), c3 = ld_devf(pc + 3);
+                const float te = ld_devf(sg.part_e + lik);
+                const uint32_t pl = ld_dev32(sg.part_l + lik);
+                Tin = Tin * ld_devf(sg.part_t + lik);
+                f2 D01 = f2{0.f, 0.f}, D2D = f2{0.f, 0.f};
+                if (live) {
+                    D01 = f2{c0, c1}; D2D = f2{c2, c3};
+                    T = te;
+                    last = pl ? pl : last;
                 }
-            } 
-            if (!done && !need) {   // the segment as a block
-                D01 = f2{T * c0, T * c1}; D2D = f2{T * c2, T * c3};
-                last = plast ? plast : last;
-                T = T * pt;
+                C01 = C01 + D01; C2D = C2D + D2D;
+                sg.seg_c[lik] = make_float4(D01.x, D01.y, D2D.x, D2D.y);   // the segment's own contribution; turned into "behind" sums below
+                sg.seg_t[lik] = T;                                         // transmittance behind the segment
             }
-            C01 = C01 + D01; C2D = C2D + D2D;
-            sg.seg_c[lik] = make_float4(D01.x, D01.y, D2D.x, D2D.y);   // the segment's own contribution; turned into "behind" sums below
-            sg.seg_t[lik] = T;                                         // transmittance behind the segment
         }
         // ---- the pixels, exactly as k_render's epilogue writes them
         float sq = 0.f, sqc = 0.f;
@@ -1851,6 +1938,13 @@ __global__ __launch_bounds__(S360_BLOCK) void k_render_tail(KParams kp, const S3
             sg.seg_c[li0] = acc;
             sg.seg_t[li0] = head_T;
         }
+#ifdef S360_DBG_TIMING
+        if (lane == 0) {   // the combining wave: phase-2 segment + combine, marked
+            const size_t di = 4 * ((size_t)4 * nt + wi);
+            dbg[di + 2] = (uint32_t)(wall_clock64() - t_begin);
+            dbg[di + 3] |= 0x80000000u;
+        }
+#endif
     }
 }
 
@@ -1888,8 +1982,9 @@ extern "C" int s360_layout(const S360Params* prm, S360Layout* out) {
     out->tile_count = take(nt * 4);
     out->slot_ticket = take((size_t)prm->V * 256);  // per-image instance-slot tickets, 256 B apart; cleared with tile_count
     out->merge_done = take((nt * MAX_PASSES + 1) * 4);   // completion counters of the merge passes, one per (tile, pass), + the ticket counter of their work queue; cleared with tile_count
-    out->seg_flag = take(nt * 4 * 4);                    // S360_FLAG_SPLIT_LISTS: split mark / arrival counter per (tile, quadrant); cleared with tile_count
+    out->seg_flag = take(nt * 4 * 4);                    // S360_FLAG_SPLIT_LISTS: split mark / arrival counters per (tile, quadrant); cleared with tile_count
     out->seg_arrive = take(nt * 4 * 4);
+    out->seg_arrive2 = take((nt * 4 + 1) * 4);           // ... + the ticket counter of k_render_tail's work queue
     out->tile_start = take((nt + 1) * 4);
     out->tile_cursor = take(nt * 4);
     out->chunk_start = take((nt + 1) * 4);
@@ -1909,15 +2004,16 @@ extern "C" int s360_layout(const S360Params* prm, S360Layout* out) {
     out->surv_count = take(nt * 4 * 4);
     {   // segment state of S360_FLAG_SPLIT_LISTS (44 B per pixel of a (segment slot, quadrant): ~11 B per instance of capacity)
         const bool split = (prm->flags & S360_FLAG_SPLIT_LISTS) != 0;
-        const size_t ns = split ? seg_slots(cap) : 1, nl = ns * 4 * 64;
+        const size_t ns = split ? seg_slots_of(prm) : 1, nl = ns * 4 * 64;
         out->part_c = take(nl * 16);
         out->part_t = take(nl * 4);
+        out->part_e = take(nl * 4);
         out->part_l = take(nl * 4);
         out->part_n = take(ns * 4 * 4);
         out->seg_c = take(nl * 16);
         out->seg_t = take(nl * 4);
         out->seg_cnt = take(ns * 4 * 4);
-        out->seg_info = take(ns * 8);
+        out->seg_info = take(ns * 4 * 8);
     }
     out->total_bytes = o;
     // backward scratch: 4 quadrant-partial raster-gradient records (12 floats) + 4 validity bytes per instance
@@ -1927,7 +2023,7 @@ extern "C" int s360_layout(const S360Params* prm, S360Layout* out) {
     const bool atomic = (prm->flags & S360_FLAG_ATOMIC_GRADS) != 0;
     out->backward_bytes = (atomic ? 0 : align_up(cap * 4 * (size_t)(16 * S360_PREC_F4)) + align_up(cap * 4)) + align_up(nt * 4 * 4) + 512 +
                           align_up(np * 48) + align_up((size_t)(prm->P > 0 ? prm->P : 1) * 16) + 256 +
-                          ((prm->flags & S360_FLAG_SPLIT_LISTS) ? align_up((seg_slots(cap) * 4 + 64) * 4) + 256 : 0);   // launch list of the split segments' units
+                          ((prm->flags & S360_FLAG_SPLIT_LISTS) ? align_up((seg_slots_of(prm) * 4 + 64) * 4) + 256 : 0);   // launch list of the split segments' units
     return S360_OK;
 }
 
@@ -2113,7 +2209,8 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
         // the list is composited segment-parallel by a second launch (k_render_tail: returns at once when nothing split)
         const bool split = kp.P > 0 && (kp.flags & S360_FLAG_SPLIT_LISTS);
         SegBufs sg{split ? chunk_start : (const uint32_t*)nullptr, (uint32_t*)(ws + L.seg_flag), (uint32_t*)(ws + L.seg_arrive),
-                   (float4*)(ws + L.part_c), (float*)(ws + L.part_t), (uint32_t*)(ws + L.part_l), (uint32_t*)(ws + L.part_n),
+                   (uint32_t*)(ws + L.seg_arrive2), (uint32_t)seg_slots_of(prm),
+                   (float4*)(ws + L.part_c), (float*)(ws + L.part_t), (float*)(ws + L.part_e), (uint32_t*)(ws + L.part_l), (uint32_t*)(ws + L.part_n),
                    (float4*)(ws + L.seg_c), (float*)(ws + L.seg_t), (uint32_t*)(ws + L.seg_cnt), (uint2*)(ws + L.seg_info), header};
         if (depth_maps)
             hipLaunchKernelGGL(k_render<true>, rgrid, rblock, 0, st, kp, views, tile_start,
@@ -2124,7 +2221,7 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
                                list, recA, recB, recC, images, final_T, n_contrib, tile_max_contrib, strip_last, dbg,
                                depths, depth_maps, depth_mode, ep, kp.P > 0 ? tile_order : (const uint32_t*)nullptr, surv, surv_count, hdr_loss, sg);
         if (split) {
-            const unsigned tgrid = (unsigned)min((size_t)1024, seg_slots(kp.cap));
+            const unsigned tgrid = (unsigned)min((size_t)S360_TAIL_GRID, 2 * seg_slots_of(prm));
             if (depth_maps)
                 hipLaunchKernelGGL(k_render_tail<true>, dim3(tgrid), rblock, 0, st, kp, views, tile_start, list, recA, images, final_T, n_contrib,
                                    tile_max_contrib, strip_last, depths, depth_maps, depth_mode, ep, surv, surv_count, sg, nt, dbg);

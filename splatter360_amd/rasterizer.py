@@ -161,8 +161,9 @@ def _poll_mirror(key, warn: bool = True) -> None:
     word = int(m[0])
     if word < 0:
         return
-    n, over = word & 0xFFFFFFFF, (word >> 32) & 1
+    n, over, chunks = word & 0xFFFFFFFF, (word >> 32) & 1, word >> 33
     _CAPACITY_HINT[key] = max(n, _CAPACITY_HINT.get(key, 0))
+    _CHUNK_HINT[key] = max(chunks, _CHUNK_HINT.get(key, 0))
     if over and warn and _OVERFLOW_WARNED.get(key) != n:
         import warnings
         _OVERFLOW_WARNED[key] = n
@@ -172,6 +173,16 @@ def _poll_mirror(key, warn: bool = True) -> None:
 
 
 _OVERFLOW_WARNED: dict = {}
+_CHUNK_HINT: dict = {}      # hint key -> most 4 096-key sort chunks of long tile lists any finished call of that shape reported
+SEG_PER_CHUNK = 8           # csrc/s360_device.h: segment slots per sort chunk
+
+
+def default_segments(key) -> int:
+    """S360Params.max_segments for a call of this shape: twice the most long-list chunks seen so far (+ slack), in segment slots; 0
+    (= the library's worst case, every list of the binning capacity long: ~48 B per instance of capacity) until a count is known.
+    Quadrants whose segments do not fit are simply composited sequentially."""
+    c = _CHUNK_HINT.get(key)
+    return 0 if c is None else SEG_PER_CHUNK * (2 * c + 64)
 
 
 def default_capacity(p: int, v: int, h: int = 0, w: int = 0, *, device=None, lean: bool = False, lazy: bool = False) -> int:
@@ -250,6 +261,7 @@ class RasterState:
         p = self.prm
         key = _hint_key(self.workspace.device, p.P, p.V, p.H, p.W, bool(p.flags & _lib.FLAG_LEAN_LISTS))
         _CAPACITY_HINT[key] = max(n, _CAPACITY_HINT.get(key, 0))    # running maximum: sizes later calls (default_capacity)
+        _poll_mirror(key, warn=False)                               # the call has finished: its mirror word (chunk count) is there too
         return n, over
 
     def count_contributions(self):
@@ -262,6 +274,12 @@ class RasterState:
                        "s360_count_contributions")
         a, b = out.cpu().tolist()
         return int(a), int(b)
+
+    def split_errors(self) -> int:
+        """header[7] (host read): 0 unless k_render_tail's watchdogs fired — a segment wave that waited ~1 s for its quadrant's
+        phase-1 results, or a corrupt work item.  The kernel then gives up on that item instead of hanging the GPU; the images of
+        such a call are invalid.  Never seen on a correct build; the tests and bench.py assert it stays 0."""
+        return int(self.header()[7].item())
 
     def num_rendered(self) -> int:
         """Host read of num_instances (synchronises)."""
@@ -360,8 +378,11 @@ class _RasterizeViews(torch.autograd.Function):
                 _lib.FLAG_SPLIT_LISTS if (split_lists and not (atomic_grads and needs_bwd)) else 0)
             prm.max_instances = int(max_instances) if max_instances else default_capacity(
                 p, v, int(h), int(w), device=m3.device, lean=lean, lazy=(check != "sync"))
-            # every forward reports (instance count, overflow flag) into pinned host memory: how check="lazy" callers size the next call
-            prm.header_mirror = _mirror(_hint_key(m3.device, p, v, int(h), int(w), lean)).data_ptr()
+            # every forward reports (instance count, overflow flag, long-list chunks) into pinned host memory: how check="lazy" callers
+            # size the next call
+            hkey = _hint_key(m3.device, p, v, int(h), int(w), lean)
+            prm.header_mirror = _mirror(hkey).data_ptr()
+            prm.max_segments = default_segments(hkey) if split_lists else 0
             mse = None
             if mse_target is not None:
                 tgt = _f32c(mse_target, "mse_target")

@@ -34,7 +34,7 @@ def test_layout_is_monotone_and_aligned():
     assert offs == sorted(offs) and all(o % 16 == 0 for o in offs)
     assert (lay.rec_b, lay.rec_c) == (lay.rec_a + 16, lay.rec_a + 32)
     assert lay.total_bytes > offs[-1] and lay.part_c >= lay.surv_count + 6 * 16 * 4 and lay.backward_bytes >= 5000 * 4 * 48
-    assert C.sizeof(_lib.S360Params) == 40
+    assert C.sizeof(_lib.S360Params) == 48
 
 
 def test_bad_arguments_are_rejected_before_any_gpu_work():

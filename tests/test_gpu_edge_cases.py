@@ -96,7 +96,14 @@ def test_many_multichunk_tiles_merge_is_race_free_over_repeated_runs(gpu):
     f, _ = _orc(S, means, cov6, None, opac, colors=colors)
     assert (np.diff(f["ranges"], axis=1) > 8192).sum() == 64
     hh = run_hip(S, means, cov6, None, opac, gpu, colors=colors)
-    check_forward(hh, f, n, hw, hw)
+    # lists and keys against the oracle (not check_forward's pixel bars: every pixel of this scene ends within rounding of the
+    # 1e-4 stop threshold, by construction of a 9 500-entry list of faint splats)
+    st0 = hh["state"]
+    assert hh["num_rendered"] == f["num_rendered"]
+    np.testing.assert_array_equal(st0["list"][:f["num_rendered"]].astype(np.uint32), f["values"])
+    tile_of = np.repeat(np.arange(64, dtype=np.uint64), np.diff(st0["tile_start"].astype(np.int64)))
+    np.testing.assert_array_equal((tile_of << np.uint64(32)) | (st0["keys"][:f["num_rendered"]].view(np.uint64) >> np.uint64(32)), f["keys"])
+    assert np.abs(hh["image"].astype(np.float64) - f["image"]).mean() <= 1e-6
     want = torch.tensor(f["values"].astype(np.int64), device=gpu)
     t = lambda a: torch.tensor(np.asarray(a, np.float32), device=gpu)
     st = _settings_to_torch(S, gpu)

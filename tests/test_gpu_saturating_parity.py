@@ -19,7 +19,7 @@ import torch
 from helpers import boundary_tensors, settings_from_views
 from oracle import oracle
 from splatter360_amd import rasterizer, synthetic
-from test_gpu_headline_parity import _check_face_forward, _face_state, _grad_err, _pixel_stats, _report, _single_face_call
+from test_gpu_headline_parity import _face_state, _grad_err, _pixel_stats, _report, _single_face_call
 
 pytestmark = pytest.mark.gpu
 
@@ -52,6 +52,42 @@ class _Mode:
         rasterizer.LEAN_LISTS, rasterizer.SPLIT_LONG_LISTS = self.old
 
 
+def _check_forward_saturating(fs, img, f, tag, n_tiles):
+    """test_gpu_headline_parity._check_face_forward for the saturating regime: integer state bit-exact as there; the pixel bars
+    allow for STOP FLIPS — a pixel whose `T (1 - alpha) < 1e-4` test lands on opposite sides in v_exp_f32 and libm stops one
+    entry earlier or later; with opacities of 0.9 - 0.99 the transmittance at that point is up to 1e-4 / (1 - alpha) = 1e-2, so
+    the one extra contribution is worth up to ~1e-3 (the headline cloud, opacity ~0.5, has none).  There may be a handful of such
+    pixels per face (counted, bounded), and every other pixel obeys the headline bars."""
+    np.testing.assert_array_equal(fs["tiles_touched"], f["tiles_touched"])
+    L = f["num_rendered"]
+    assert fs["list"].shape[0] == L
+    np.testing.assert_array_equal(fs["list"], f["values"])
+    tile_of = np.repeat(np.arange(n_tiles, dtype=np.uint64), np.diff(fs["tile_start"]))
+    np.testing.assert_array_equal((tile_of << np.uint64(32)) | fs["depth_bits"], f["keys"])
+    nonempty = f["ranges"][:, 1] > f["ranges"][:, 0]
+    np.testing.assert_array_equal(fs["tile_start"][:-1][nonempty], f["ranges"][nonempty, 0])
+    np.testing.assert_array_equal(fs["tile_start"][1:][nonempty], f["ranges"][nonempty, 1])
+    return _check_pixels_saturating(img, fs["n_contrib"], fs["final_T"], f, tag)
+
+
+def _check_pixels_saturating(img, n_contrib, final_T, f, tag, same_lists=True):
+    st = _pixel_stats(img, f["image"])
+    per_px = np.abs(img.astype(np.float64) - f["image"]).mean(0)
+    amax = float(np.abs(f["image"]).max())
+    over = per_px > 1e-5 * max(1.0, amax)
+    flips = n_contrib != f["n_contrib"] if same_lists else over
+    _report(tag, n_contrib_mismatch=float(flips.mean()) if same_lists else None, pixels_over_1e5=int(over.sum()), image_absmax=amax, **st)
+    # (an ACCEPT flip — alpha within an ulp of 1/255 — need not move n_contrib, the last contributor; at transmittance ~1 it is worth
+    # up to 1/255 of a colour: the same 1e-3 scale.  Hence a count, not a per-pixel attribution.)
+    assert int(over.sum()) <= 8 and st["max"] <= 2e-3, (tag, st, int(over.sum()))
+    assert st["p999"] <= 1e-6 and st["mean"] <= 1e-7, (tag, st)
+    if same_lists:
+        assert int(flips.sum()) <= 16, (tag, int(flips.sum()))
+    dT = np.abs(final_T.astype(np.float64) - f["final_T"])
+    assert int((dT > 2e-6).sum()) <= 16 and dT[~flips].max(initial=0.0) <= 2e-5, (tag, float(dT.max()), int((dT > 2e-6).sum()))
+    return st
+
+
 def _got_grads(ps):
     r, c = np.triu_indices(3)
     return dict(means3D=ps[0].grad.cpu().numpy(), cov3D=ps[1].grad.cpu().numpy()[:, r, c],
@@ -71,8 +107,10 @@ def _face_case(cloud, params, face, dev, tag, seed):
     f = o32.forward()
     P = cloud["means"].shape[0]
     img = out[0].detach().cpu().numpy()
-    _check_face_forward(_face_state(st.tensors(), 0, P, 256), img, f, tag + "_fwd", 256)
-    sat = float((f["final_T"] < 1e-4).mean())
+    _check_forward_saturating(_face_state(st.tensors(), 0, P, 256), img, f, tag + "_fwd", 256)
+    # "saturated": the stop test tripped.  final_T itself never drops below 1e-4 (the tripping entry is not applied); with these
+    # opacities a pixel that stopped has final_T < 1e-4 / (1 - 0.99) = 1e-2, and one that did not is far above it
+    sat = float((f["final_T"] < 1e-2).mean())
     g32 = o32.backward(gimg)
     del o32
     o64 = oracle.rasterize(S, means3D=means, cov3D_precomp=cov6, opacities=opac, shs=shs, dtype=np.float64)
@@ -94,17 +132,12 @@ def _face_case(cloud, params, face, dev, tag, seed):
     with _Mode(True, True):
         out2, st2, ps2 = _single_face_call(params, face, 256, dev, grad_image=gimg)
     img2 = out2[0].detach().cpu().numpy()
-    px = _pixel_stats(img2, f["image"])
-    per_px = np.abs(img2.astype(np.float64) - f["image"]).mean(0)
-    amax = float(np.abs(f["image"]).max())
-    over = per_px > 1e-5 * max(1.0, amax)
-    assert int(over.sum()) <= per_px.size // 20_000 and px["max"] <= 2e-4, (tag, px, int(over.sum()))   # borderline stop / accept flips only
-    assert px["p999"] <= 1e-6 and px["mean"] <= 1e-7, (tag, px)
     t2 = st2.tensors()
-    dT = np.abs(t2["final_T"][0].cpu().numpy().astype(np.float64) - f["final_T"])
-    assert int((dT > 2e-6).sum()) <= per_px.size // 20_000, (tag, float(dT.max()))
-    sat2 = (t2["final_T"][0].cpu().numpy() < 1e-4)
-    assert float((sat2 != (f["final_T"] < 1e-4)).mean()) <= 1e-4
+    # (lean lists: n_contrib counts positions of shorter lists, so a flip shows as the pixel difference itself)
+    px = _check_pixels_saturating(img2, t2["n_contrib"][0].cpu().numpy().astype(np.uint32), t2["final_T"][0].cpu().numpy(), f, tag + "_default_mode_fwd",
+                                  same_lists=False)
+    rep["split_quadrants"] = int(st2.header()[5].item())
+    assert st2.split_errors() == 0
     got2 = _got_grads(ps2)
     for k in got2:
         e, _ = _grad_err(got2[k], np.asarray(g64[k]) * fold[k])
@@ -122,7 +155,7 @@ def test_surface_like_1m_face_vs_oracle(gpu, surface1m, face):
     rep = _face_case(surface1m, _params(surface1m, gpu), face, gpu, f"surface_like_face{face}", 300 + face)
     assert rep["saturated_pixel_fraction"] > 0.5            # the regime this test exists for
     if face != 2:
-        assert rep["longest_list"] > 9000 and rep["max_n_contrib"] > 4096
+        assert rep["longest_list"] > 9000 and rep["max_n_contrib"] > 4096 and rep["split_quadrants"] > 10
 
 
 @pytest.mark.parametrize("face", [0, 3])
