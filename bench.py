@@ -84,8 +84,10 @@ def parse():
                     help="fwdbwd, 1 GPU: 1 (default) = after the headline measurement, time the same step on two more clouds of the same size "
                          "(SURVEY 8(d)'s uniform-random stress cloud and a surface-like cloud: coherent depth, opacity >= 0.9) and the "
                          "per-face drop-in training step of the unchanged reference (`dropin_train`); 0 = skip them")
-    ap.add_argument("--split-lists", type=int, default=1, help="1 (default): S360_FLAG_SPLIT_LISTS — long tile lists whose pixels do not saturate are "
-                    "composited segment-parallel (forward and backward); 0: every list is one sequential chain")
+    ap.add_argument("--split-lists", choices=("auto", "1", "0"), default="auto",
+                    help="S360_FLAG_SPLIT_LISTS — long tile lists whose pixels do not saturate are composited segment-parallel (forward and "
+                         "backward): auto (default, the product's default) = set for the calls that follow a forward which reported a quadrant worth "
+                         "splitting; 1 = always; 0 = never (every list one sequential chain)")
     ap.add_argument("--single-rank-rccl", type=int, default=0,
                     help="1 (with --gpus 1): create a ONE-rank process group with backend nccl (= RCCL) and run the chunked exchange through "
                          "its collective branch (distributed.ExchangeConfig(force_collectives=True)) — the all-reduces / all-gathers really "
@@ -197,7 +199,7 @@ def main():
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(a)      # does not return
     rasterizer.ATOMIC_GRADS = bool(a.atomic_grads)
-    rasterizer.SPLIT_LONG_LISTS = bool(a.split_lists)
+    rasterizer.SPLIT_LONG_LISTS = "auto" if a.split_lists == "auto" else bool(int(a.split_lists))
     rank, local_rank, world = distributed.init()
     if a.single_rank_rccl and world == 1 and not a.dry_run:
         import socket
@@ -369,7 +371,7 @@ def main():
         raise SystemExit("k_render_tail reported a watchdog error during the timed region: result invalid")
     L = st.num_rendered()
     ws_fwd, ws_bwd = int(st_timed.layout.total_bytes), int(st_timed.layout.backward_bytes)   # scratch of a timed step (check="lazy")
-    n_split = int(st_timed.header()[5].item()) if a.split_lists else 0
+    n_split = int(st_timed.header()[5].item()) if (st_timed.prm.flags & _lib.FLAG_SPLIT_LISTS) else 0
     tt = st.tensors()
     visible_pairs = int((tt["tiles_touched"] > 0).sum().item())
     assert torch.isfinite(out["faces"]).all() and torch.isfinite(out["erp"]).all()
@@ -489,7 +491,7 @@ def main():
                        ", RCCL factored grad exchange (all-reduce 40 B/G packed + all-gather dRGB 16 B/G/rank" + (", overlapped with the next micro-batch's forward" if a.overlap_exchange else "") + ")" if factored else
                        ", RCCL all-reduce of Gaussian grads"),
                    "num_rendered": L, "num_rendered_upstream_lists": L_upstream, "lean_over_upstream": L / max(L_upstream, 1),
-                   "visible_pairs": visible_pairs, "split_lists": bool(a.split_lists), "split_quadrants": n_split,
+                   "visible_pairs": visible_pairs, "split_lists": a.split_lists, "split_flag_set_in_timed_steps": bool(st_timed.prm.flags & _lib.FLAG_SPLIT_LISTS), "split_quadrants": n_split,
                    "workspace_bytes_forward": ws_fwd, "workspace_bytes_backward": ws_bwd if a.mode == "fwdbwd" else 0,
                    "max_instances": int(st_timed.prm.max_instances)},
         "roofline": roofline,
@@ -545,13 +547,74 @@ def main():
             _lib.profile_enable(False)
             res["workloads"][name] = {"value": G / dtw / 1e6, "unit": "Msplats/s", "ms_per_step": dtw * 1e3, "steps": k2,
                                       "num_rendered": stw.num_rendered(), "overflowed": stw.overflowed(),
-                                      "split_quadrants": int(stw.header()[5].item()) if a.split_lists else 0, "split_errors": stw.split_errors(),
+                                      "split_quadrants": int(stw.header()[5].item()) if (stw.prm.flags & _lib.FLAG_SPLIT_LISTS) else 0, "split_errors": stw.split_errors(),
                                       "workspace_bytes_forward": int(stw.layout.total_bytes), "workspace_bytes_backward": int(stw.layout.backward_bytes),
                                       "visible_pairs": int((stw.tensors()["tiles_touched"] > 0).sum().item()),
                                       "finite": bool(torch.isfinite(out["faces"]).all()), "kernels_avg_us": kw_us}
             cur["params"] = None
             torch.cuda.empty_cache()
         cur["params"], cur["check"] = params, "lazy"
+        # ---- the adapter tail in front of the render: the encoder's raw outputs -> Gaussians -> the same training step,
+        # as two steps (s360_adapter_forward, fused render, backward, s360_adapter_backward: the [G,3,25] harmonics / dL/dSH and the
+        # covariances make a round trip through HBM) and FUSED (s360_forward_raw / s360_backward_raw)
+        try:
+            from splatter360_amd import adapter as _adapter
+            gen = torch.Generator().manual_seed(0)
+            nvc = 2
+            rdep = torch.exp(torch.empty(nvc, pano_h * pano_w).uniform_(-0.69, 2.08, generator=gen)).to(dev)
+            rop = torch.sigmoid(torch.randn(nvc, pano_h * pano_w, generator=gen)).to(dev)
+            rraw = torch.randn(nvc, pano_h * pano_w, 82, generator=gen)
+            rraw[..., 7:] *= 0.6
+            rraw = rraw.to(dev)
+            cext = torch.eye(4).repeat(nvc, 1, 1)
+            cext[0, :3, 3] = torch.tensor([-0.4, 0.0, 0.1])
+            cext[1, :3, 3] = torch.tensor([0.4, 0.0, -0.1])
+            cext = cext.to(dev)
+            crot = _adapter.sh_rotation_blocks(cext, 25)
+            def step_two():
+                d, o, r = rdep.clone().requires_grad_(True), rop.clone().requires_grad_(True), rraw.clone().requires_grad_(True)
+                gA = _adapter.adapter_tail(cext, d, o, r, (pano_h, pano_w), 0.5, 15.0, sh_rotation=crot)
+                views = decoder.pack_camera_views(ext, K, near, far, bg)
+                faces, fm = decoder.render_views_fused(ext, K, near, far, (face_w, face_w), bg, gA.means.reshape(-1, 3), gA.covariances.reshape(-1, 3, 3),
+                                                       gA.harmonics.reshape(-1, 3, 25), gA.opacities.reshape(-1), mse_target=gt, check="lazy",
+                                                       shared_campos=True, views=views)
+                fm.loss.backward()
+                return faces
+
+            def step_raw():
+                d, o, r = rdep.clone().requires_grad_(True), rop.clone().requires_grad_(True), rraw.clone().requires_grad_(True)
+                views = decoder.pack_camera_views(ext, K, near, far, bg)
+                faces, _, _, fm = rasterizer.rasterize_raw(d.reshape(-1), o.reshape(-1), r.reshape(-1, 82), cext, views=views, image_height=face_w,
+                                                           image_width=face_w, context_shape=(pano_h, pano_w), scale_min=0.5, scale_max=15.0,
+                                                           sh_rotation=crot, mse_target=gt, check="lazy")
+                fm.loss.backward()
+                return faces
+
+            apr = {}
+            for nm, fn in (("two_step", step_two), ("fused_raw", step_raw)):
+                for _ in range(3):
+                    f_ = fn()
+                sync()
+                t1 = time.perf_counter()
+                for _ in range(k2):
+                    f_ = fn()
+                sync()
+                dta = (time.perf_counter() - t1) / k2
+                _lib.profile_enable(True)
+                for _ in range(k2):
+                    fn()
+                torch.cuda.synchronize(dev)
+                ku = {k: round(ms / n * 1e3, 1) for k, (ms, n) in _lib.profile_collect().items() if n}
+                _lib.profile_enable(False)
+                apr[nm] = {"ms_per_step": dta * 1e3, "value": G / dta / 1e6, "unit": "Msplats/s", "kernels_avg_us": ku,
+                           "finite": bool(torch.isfinite(f_).all())}
+            apr["fused_over_two_step"] = apr["two_step"]["ms_per_step"] / apr["fused_raw"]["ms_per_step"]
+            apr["what"] = ("encoder raw outputs (2 context panoramas, 82 floats + depth + opacity per pixel) -> adapter tail -> fused six-face training "
+                           "step -> gradients w.r.t. the raw outputs; includes cloning the inputs and autograd bookkeeping of both forms alike")
+            apr["bytes_not_moved_per_gaussian"] = {"forward": 340 + 340, "backward": 300 + 300 + 36}
+            res["adapter_plus_render"] = apr
+        except Exception as e:   # an extra leg, never a reason to lose the bench line
+            res["adapter_plus_render"] = {"error": repr(e)}
         # ---- the path a user of the UNCHANGED reference is on without splatter360_amd.install(): its own decoder loop — one drop-in
         # `diff_gaussian_rasterization` call per face with the reference's torch camera glue and upstream's host synchronisation
         # (decoder_splatting_cuda.py:47-59 -> cuda_splatting.py:47-127), torch L2 loss on the faces, backward

@@ -121,6 +121,9 @@ enum {
                                          entries, every quadrant that is (nearly) saturated after 1 024 — are bit-identical with and
                                          without the flag. */
 
+#define S360_FLAG_RAW_INPUTS 1024u      /* the call is s360_forward_raw / s360_backward_raw (the workspace also keeps the 7 raw geometry
+                                         words per Gaussian for the backward); required by those two, rejected by the others */
+
 typedef struct S360View {
     float viewmatrix[16];
     float projmatrix[16];
@@ -145,7 +148,10 @@ typedef struct S360Params {
                                do not fit is composited sequentially (never an error).  header_mirror reports how many a call used. */
     uint32_t _reserved;
     void* header_mirror;    /* NULL, or a HOST-visible (pinned / mapped) 8-byte aligned address: the forward also stores
-                               (num_instances | overflow flag << 32 | sort chunks of the long lists << 33) there as one 64-bit word — the caller can size its next
+                               (num_instances | overflow flag << 32 | sort chunks of the long lists << 33) there as one 64-bit word,
+                               and 1 into the NEXT 64-bit word (16 bytes in all) when some 8x8 quadrant of the call was worth
+                               splitting (or was split) under S360_FLAG_SPLIT_LISTS's criterion — callers that set that flag
+                               adaptively clear the word before a call and read it after — the caller can size its next
                                call from the previous call's count without a device synchronisation (upstream reads the count
                                back synchronously inside every forward; this library's callers may run without that read,
                                and this is how they learn the count and the overflow flag anyway) */
@@ -222,8 +228,25 @@ typedef struct S360Layout {
     size_t seg_t;               /* float [NSEG*4*64]  after the combine: transmittance behind the segment's last entry */
     size_t seg_cnt;             /* uint32[NSEG*4]     survivor records of the segment the backward replays (0: none / not split) */
     size_t seg_info;            /* uint32[NSEG*4][2]  the segment work items of the call (header[6] of them): (tile, segment k << 2 | quadrant) */
+    size_t geo7;                /* float[P,7]  S360_FLAG_RAW_INPUTS training calls: the raw scale logits + quaternion of every Gaussian */
     size_t backward_bytes;      /* size of the separate backward scratch workspace */
 } S360Layout;
+
+/*
+ * The encoder's raw per-pixel outputs, as GaussianAdapterERP.forward receives them
+ * (/root/reference/src/model/encoder/common/gaussian_adapter_erp.py:50-61): what s360_forward_raw / s360_backward_raw consume instead
+ * of the adapter's materialised means / covariances / harmonics.  All pointers DEVICE memory.
+ */
+typedef struct S360RawInputs {
+    const float* extrinsics;    /* [n_views,4,4] context-panorama camera-to-world (row-major) */
+    const float* depths;        /* [n_views*per_view] */
+    const float* raw_gaussians; /* [n_views*per_view, 82]: 3 scale logits, quaternion (x,y,z,w), 3 x 25 SH coefficients channel-major */
+    const float* sh_rotation;   /* [n_views,25,25] block-diagonal Wigner-D matrices of rotate_sh (s360_sh_rotation_blocks) or NULL = identity */
+    int32_t n_views, per_view;  /* P = n_views * per_view Gaussians, view-major */
+    int32_t H, W, per_ray;      /* context panorama size; per_view = H*W*per_ray, ray-major */
+    int32_t erp_convention;     /* as s360_adapter_forward */
+    float scale_min, scale_max, eps;
+} S360RawInputs;
 
 /* ABI version of the loaded library (== S360_ABI_VERSION). */
 int s360_abi_version(void);
@@ -395,6 +418,30 @@ int s360_pack_views(const float* extrinsics, const float* intrinsics, const floa
  *   s360_adapter_forward / backward.  e3nn itself is not available where this was written: the convention is restated from its
  *   documentation and pinned by properties only (oracle/adapter_ref.py).
  */
+/*
+ * The adapter tail FUSED into the rasteriser: replaces GaussianAdapterERP.forward
+ * (gaussian_adapter_erp.py:63-119) + the decoder's rasteriser call on its output (cuda_splatting.py:99-124) for views sharing one
+ * camera centre, at the reference's configuration (degree-4 harmonics).  The call's first kernel reads the raw records once
+ * (328 B/Gaussian), writes means_out[P,3] and cov6_out[P,6] (the adapter's values: what the geometry pass then reads, and what a
+ * caller may keep) and evaluates the view-dependent colour with the SH basis carried through sh_mask and the per-view rotation —
+ * the [P,3,25] harmonics and [P,3,3] covariances are never materialised (340 B/Gaussian written + 340 read by the two-step path).
+ * prm: P = raw->n_views * raw->per_view, M = 25, sh_degree = 4, flags must hold S360_FLAG_RAW_INPUTS | S360_FLAG_SHARED_CAMPOS and not
+ * S360_FLAG_COV9.  target == NULL: no loss epilogue (d_images / partials / loss_out ignored); depth_maps == NULL: no depth channel.
+ * s360_backward_raw: the backward of that call down to the encoder's outputs — d_depths[P], d_raw_gaussians[P,82] (dL/d(SH
+ * coefficient) formed as (mask . D^T Y) (x) dL/dRGB: the [P,3,25] dL/dSH round trip of the two-step path does not exist),
+ * d_opacities[P]; d_means3D[P,3], d_cov6[P,6], d_rgb_sum[P,4] are caller-provided intermediates (valid results themselves).
+ * differentiable_means = 0: the reference's detached means (sphere_projection.py:14-86 runs under torch.no_grad()); 1 adds the
+ * un-projection's own depth term.  means / cov6: what s360_forward_raw wrote.
+ */
+int s360_forward_raw(const S360Params* prm, const S360View* views, const S360RawInputs* raw, const float* opacities,
+                     float* means_out, float* cov6_out, float* images, float* depth_maps, int32_t depth_mode, int32_t* radii,
+                     const float* target, float grad_scale, float* d_images, float* partials, float* loss_out, void* workspace,
+                     size_t workspace_bytes, void* stream);
+int s360_backward_raw(const S360Params* prm, const S360View* views, const S360RawInputs* raw, const float* means, const float* cov6,
+                      const float* opacities, const void* workspace, size_t workspace_bytes, const float* dL_dimages,
+                      const float* dL_dimages_scale, const float* dL_ddepth, int32_t depth_mode, int32_t differentiable_means,
+                      float* d_means3D, float* d_cov6, float* d_opacities, float* d_rgb_sum, float* d_depths, float* d_raw_gaussians,
+                      void* bwd_workspace, size_t bwd_workspace_bytes, void* stream);
 int s360_sh_rotation_blocks(const float* rotations, int32_t row_major_stride, int32_t n_views, int32_t d_sh,
                             float* sh_rotation_out, void* stream);
 int s360_adapter_forward(const float* extrinsics, const float* depths, const float* raw_gaussians,

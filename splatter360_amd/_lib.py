@@ -30,6 +30,7 @@ FLAG_LEAN_LISTS = 64
 FLAG_DEFER_LOSS = 128
 FLAG_ATOMIC_GRADS = 256
 FLAG_SPLIT_LISTS = 512
+FLAG_RAW_INPUTS = 1024
 ABI_VERSION = 20
 
 
@@ -44,10 +45,17 @@ class S360Layout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in (
         "total_bytes", "header", "tiles_touched", "vis_mask", "slot_base", "rec_a", "rec_b", "rec_c",
         "clamped", "depths", "tile_count", "slot_ticket", "merge_done", "seg_flag", "seg_arrive", "seg_arrive2", "tile_start", "tile_cursor", "chunk_start", "tile_order", "keys", "keys_alt", "list", "final_T", "n_contrib",
-        "tile_max_contrib", "strip_last", "slot_pair", "long_pairs", "rgbc", "sh_jac", "surv", "surv_count", "part_c", "part_t", "part_e", "part_l", "part_n", "seg_c", "seg_t", "seg_cnt", "seg_info", "backward_bytes")]
+        "tile_max_contrib", "strip_last", "slot_pair", "long_pairs", "rgbc", "sh_jac", "surv", "surv_count", "part_c", "part_t", "part_e", "part_l", "part_n", "seg_c", "seg_t", "seg_cnt", "seg_info", "geo7", "backward_bytes")]
 
 
-EXPORTS = ("s360_abi_version", "s360_error_string", "s360_layout", "s360_forward", "s360_forward_depth", "s360_forward_mse", "s360_backward", "s360_backward_split", "s360_backward_composite", "s360_backward_gaussians", "s360_unpack_gradients", "s360_sh_backward", "s360_pack_views", "s360_adapter_forward", "s360_adapter_backward", "s360_sh_rotation_blocks",
+class S360RawInputs(C.Structure):
+    """include/s360.h S360RawInputs: the encoder's raw per-pixel outputs (device pointers)."""
+    _fields_ = [("extrinsics", C.c_void_p), ("depths", C.c_void_p), ("raw_gaussians", C.c_void_p), ("sh_rotation", C.c_void_p),
+                ("n_views", C.c_int32), ("per_view", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("per_ray", C.c_int32),
+                ("erp_convention", C.c_int32), ("scale_min", C.c_float), ("scale_max", C.c_float), ("eps", C.c_float)]
+
+
+EXPORTS = ("s360_forward_raw", "s360_backward_raw", "s360_abi_version", "s360_error_string", "s360_layout", "s360_forward", "s360_forward_depth", "s360_forward_mse", "s360_backward", "s360_backward_split", "s360_backward_composite", "s360_backward_gaussians", "s360_unpack_gradients", "s360_sh_backward", "s360_pack_views", "s360_adapter_forward", "s360_adapter_backward", "s360_sh_rotation_blocks",
            "s360_cube2erp_forward", "s360_cube2erp_backward", "s360_count_contributions", "s360_profile_slots", "s360_profile_slot_name",
            "s360_profile_enable", "s360_profile_collect")
 
@@ -156,6 +164,10 @@ def lib() -> C.CDLL:
     l.s360_unpack_gradients.argtypes = [vp, i32, i32, vp, vp, vp, vp]
     l.s360_sh_backward.restype = C.c_int
     l.s360_sh_backward.argtypes = [C.POINTER(S360Params), i32] + [vp] * 5
+    l.s360_forward_raw.restype = C.c_int
+    l.s360_forward_raw.argtypes = [C.POINTER(S360Params), vp, C.POINTER(S360RawInputs)] + [vp] * 5 + [i32, vp, vp, C.c_float] + [vp] * 4 + [sz, vp]
+    l.s360_backward_raw.restype = C.c_int
+    l.s360_backward_raw.argtypes = [C.POINTER(S360Params), vp, C.POINTER(S360RawInputs)] + [vp] * 4 + [sz] + [vp] * 3 + [i32, i32] + [vp] * 7 + [sz, vp]
     l.s360_pack_views.restype = C.c_int
     l.s360_pack_views.argtypes = [vp] * 5 + [i32, i32, i32, vp, vp]
     f32 = C.c_float

@@ -1,0 +1,78 @@
+// s360_adapter_math.h — the Gaussian-adapter tail's per-Gaussian formulas (gaussian_adapter_erp.py:50-119), shared by the stand-alone
+// adapter kernels (s360_adapter.hip) and the raw-input entry points that fold them into the rasteriser's own first / last kernels
+// (s360_forward_raw / s360_backward_raw).  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace s360 {
+
+constexpr float kPi = 3.14159265358979323846f;
+
+struct AdapterParams {
+    int V, Gv, H, W, per_ray, d_sh, cov9, conv;
+    float smin, smax, eps;
+};
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// sh_mask per degree: 1, 0.1 * 0.25^l (gaussian_adapter_erp.py:38-47), rounded to float32 like the reference's buffer
+__device__ constexpr float kShMask[5] = {1.0f, 0.025f, 0.00625f, 0.0015625f, 0.000390625f};
+
+// unit ray of ERP pixel n (row-major) in the reference's per-dataset conventions (src/geometry/utils360.py: equi_2_spherical
+// :37-104 pixel -> (theta, phi), spherical_2_cartesian :106-153 -> xyz):
+//   0 'hm3d' / 'replica'  1 'm3d'  2 'residential'  3 'CoffeeArea' / 'outdoor_colmap'
+__device__ __forceinline__ void erp_dir(int n, int H, int W, int conv, float* d) {
+    const int y = n / W, x = n - y * W;
+    if (conv == 0) {
+        const float theta = ((0.5f - ((float)x + 0.5f) / (float)W) * 2.0f) * kPi;
+        const float phi = -((((float)y + 0.5f) / (float)H - 0.5f)) * kPi;
+        const float cp = cosf(phi);
+        d[0] = cp * sinf(theta);
+        d[1] = sinf(phi);
+        d[2] = cp * cosf(theta);
+    } else if (conv == 1) {
+        const float theta = (float)x / (float)(W - 1) * 2.0f * kPi - 0.5f * kPi;
+        const float phi = (float)y / (float)(H - 1) * kPi;
+        const float sp = sinf(phi);
+        d[0] = sp * cosf(theta);
+        d[1] = cosf(phi);
+        d[2] = sp * sinf(theta);
+    } else if (conv == 2) {
+        const float theta = kPi * (2.0f * (float)x / (float)(W - 1) - 1.5f);
+        const float phi = kPi * (0.5f - (float)y / (float)(H - 1));
+        const float cp = cosf(phi);
+        d[0] = cosf(theta) * cp;
+        d[1] = sinf(phi);
+        d[2] = sinf(theta) * cp;
+    } else {
+        const float theta = (-2.0f * kPi / (float)(W - 1)) * (float)x + 2.0f * kPi;
+        const float phi = (kPi / (float)(H - 1)) * (float)y;
+        const float sp = sinf(phi);
+        d[0] = sp * cosf(theta);
+        d[1] = sp * sinf(theta);
+        d[2] = cosf(phi);
+    }
+}
+
+struct QuatGeom {
+    float q[4];     // normalised quaternion (i, j, k, r)
+    float n, m;     // |q_raw|, |q_raw| + eps
+    float a;        // two_s = 2 / (|q^|^2 + eps)
+    float R[3][3];
+};
+
+__device__ __forceinline__ void quat_geom(const float* qr, float eps, QuatGeom& g) {
+    g.n = sqrtf(qr[0] * qr[0] + qr[1] * qr[1] + qr[2] * qr[2] + qr[3] * qr[3]);
+    g.m = g.n + eps;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) g.q[k] = qr[k] / g.m;
+    const float i = g.q[0], j = g.q[1], k = g.q[2], r = g.q[3];
+    g.a = 2.0f / (i * i + j * j + k * k + r * r + 1e-8f);  // quaternion_to_matrix's own eps (gaussians.py:11)
+    const float a = g.a;
+    g.R[0][0] = 1.0f - a * (j * j + k * k); g.R[0][1] = a * (i * j - k * r); g.R[0][2] = a * (i * k + j * r);
+    g.R[1][0] = a * (i * j + k * r); g.R[1][1] = 1.0f - a * (i * i + k * k); g.R[1][2] = a * (j * k - i * r);
+    g.R[2][0] = a * (i * k - j * r); g.R[2][1] = a * (j * k + i * r); g.R[2][2] = 1.0f - a * (i * i + j * j);
+}
+
+}  // namespace s360

@@ -17,6 +17,7 @@
 #include "s360_device.h"
 #include "s360_prof.h"
 #include "s360_bwd_em.h"
+#include "s360_adapter_math.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -553,6 +554,181 @@ __global__ __launch_bounds__(64) void k_sh_bwd(KParams kp, const S360View* __res
     }
 }
 
+
+// ------------------------------------------------------------------------------ backward down to the encoder's raw outputs
+// Last kernel of s360_backward_raw: per Gaussian, from the rasteriser's own per-Gaussian gradients (dL/dcov6, the clamp-masked
+// sum of dL/dRGB over the call's views, optionally dL/dmean) straight to dL/d(raw record) and dL/ddepth — the adapter tail's
+// backward (k_adapter_bwd's expressions: scale map, quaternion normalisation, Sigma = (C R) diag(s^2) (C R)^T) with its dL/dharmonics
+// input replaced by the rank-1 form it always has here,
+//     dL/d raw_sh[c][k] = (mask . D_v^T Y(dir))[k] * dL/dRGB[c],
+// so the [P,3,25] dL/dSH buffer (written by k_sh_bwd, re-read by the adapter's backward: 600 B/Gaussian) does not exist.
+// Reads 28 B (raw geometry words kept by the forward) + 4 (depth) + 24 (dL/dcov6) + 16 (dL/dRGB) + 12 (mean) [+ 12 dL/dmean],
+// writes the 328-byte gradient record through LDS with coalesced non-temporal stores + 4 (dL/ddepth).
+struct RawBwd {
+    const float* extrinsics;
+    const float* depths;
+    const float* geo7;
+    const float* sh_rot;
+    const float* means;        // [P,3] (forward output: the view direction)
+    const float* d_means;      // [P,3] or null (means detached, the reference's behaviour)
+    const float* d_cov6;       // [P,6]
+    const float4* d_rgb;       // [n_groups][P] (.w = index of the group's camera record, int32 bits, or -1)
+    float* d_depths;           // [P]
+    float* d_raw;              // [P,82]
+    int Gv, H, W, per_ray, conv, n_groups;
+    float smin, smax, eps;
+};
+constexpr int RAWB_C = 82;
+
+__global__ __launch_bounds__(192) void k_raw_bwd(KParams kp, const S360View* __restrict__ views, RawBwd rb) {
+    __shared__ __attribute__((aligned(16))) float s_out[64 * RAWB_C];
+    __shared__ float s_D[625];
+    const int tid = threadIdx.x, d = tid >> 6, l = tid & 63;
+    const int g0 = blockIdx.x * 64, nb = min(64, kp.P - g0), g = g0 + l;
+    const int v_first = g0 / rb.Gv, v_last = (g0 + nb - 1) / rb.Gv;
+    const bool one_view = v_first == v_last;
+    if (rb.sh_rot && one_view)
+        for (int i = tid; i < 625; i += 192) s_D[i] = rb.sh_rot[(size_t)v_first * 625 + i];
+    __syncthreads();
+    if (g < kp.P) {
+        // ---- colour channel d: sum over the camera groups of (mask . D^T Y(dir_j)) * dL/dRGB_j[d]
+        const float m0 = rb.means[3 * (size_t)g], m1 = rb.means[3 * (size_t)g + 1], m2 = rb.means[3 * (size_t)g + 2];
+        const float* D = rb.sh_rot ? (one_view ? s_D : rb.sh_rot + (size_t)(g / rb.Gv) * 625) : nullptr;
+        float acc[25];
+#pragma unroll
+        for (int k = 0; k < 25; ++k) acc[k] = 0.f;
+#pragma unroll 1
+        for (int j = 0; j < rb.n_groups; ++j) {
+            const float4 dr = rb.d_rgb[(size_t)j * kp.P + g];
+            const int fv = __float_as_int(dr.w);
+            if (fv < 0) continue;   // invisible in that group's views
+            const S360View& vw = views[fv];
+            const float sc = vw.scale;
+            const float dx = m0 * sc - vw.campos[0], dy = m1 * sc - vw.campos[1], dz = m2 * sc - vw.campos[2];
+            const float inv = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
+            float Y[25];
+            sh_basis(4, dx * inv, dy * inv, dz * inv, Y);
+            const float w = d == 0 ? dr.x : (d == 1 ? dr.y : dr.z);
+#pragma unroll
+            for (int lq = 0; lq <= 4; ++lq) {   // (mask . D^T Y) * w, accumulated
+                const int o = lq * lq, nl = 2 * lq + 1;
+#pragma unroll
+                for (int b = 0; b < nl; ++b) {
+                    float t;
+                    if (D) {
+                        t = 0.f;
+#pragma unroll
+                        for (int a = 0; a < nl; ++a) t = __builtin_fmaf(D[(o + a) * 25 + o + b], Y[o + a], t);
+                    } else {
+                        t = Y[o + b];
+                    }
+                    acc[o + b] = __builtin_fmaf(t * kShMask[lq], w, acc[o + b]);
+                }
+            }
+        }
+        float* orec = s_out + l * RAWB_C + 7 + 25 * d;
+#pragma unroll
+        for (int k = 0; k < 25; ++k) orec[k] = acc[k];
+    }
+    if (d == 0 && g < kp.P) {
+        // ---- geometry: k_adapter_bwd's chain (scale map, quaternion, covariance), 6-entry covariance gradient
+        const int v = g / rb.Gv, gi = g - v * rb.Gv;
+        const float* E = rb.extrinsics + 16 * v;
+        const float* rw = rb.geo7 + 7 * (size_t)g;
+        const float depth = rb.depths[g];
+        const float px = 1.0f / (float)max(rb.W, rb.H);
+        float sig[3], base[3], sc3[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            sig[k] = sigmoidf(rw[k]);
+            base[k] = rb.smin + (rb.smax - rb.smin) * sig[k];
+            sc3[k] = (base[k] * depth) * px;
+        }
+        QuatGeom qg;
+        const float qr[4] = {rw[3], rw[4], rw[5], rw[6]};
+        quat_geom(qr, rb.eps, qg);
+        float M[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) M[a][b] = E[4 * a] * qg.R[0][b] + E[4 * a + 1] * qg.R[1][b] + E[4 * a + 2] * qg.R[2][b];
+        float G[3][3];
+        {
+            const float* gcv = rb.d_cov6 + 6 * (size_t)g;
+            G[0][0] = gcv[0]; G[0][1] = gcv[1]; G[0][2] = gcv[2]; G[1][1] = gcv[3]; G[1][2] = gcv[4]; G[2][2] = gcv[5];
+            G[1][0] = G[2][0] = G[2][1] = 0.f;
+        }
+        float Gs[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) Gs[a][b] = G[a][b] + G[b][a];
+        float dM[3][3], ds[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float t[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) t[a] = Gs[a][0] * M[0][k] + Gs[a][1] * M[1][k] + Gs[a][2] * M[2][k];
+            const float s2 = sc3[k] * sc3[k];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) dM[a][k] = t[a] * s2;
+            ds[k] = 2.0f * sc3[k] * (0.5f * (M[0][k] * t[0] + M[1][k] * t[1] + M[2][k] * t[2]));
+        }
+        float dR[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) dR[a][b] = E[a] * dM[0][b] + E[4 + a] * dM[1][b] + E[8 + a] * dM[2][b];
+        const float qi = qg.q[0], qj = qg.q[1], qk = qg.q[2], qr_ = qg.q[3], a = qg.a;
+        const float B[3][3] = {{-(qj * qj + qk * qk), qi * qj - qk * qr_, qi * qk + qj * qr_},
+                               {qi * qj + qk * qr_, -(qi * qi + qk * qk), qj * qk - qi * qr_},
+                               {qi * qk - qj * qr_, qj * qk + qi * qr_, -(qi * qi + qj * qj)}};
+        float dLda = 0.f;
+#pragma unroll
+        for (int x = 0; x < 3; ++x)
+#pragma unroll
+            for (int y = 0; y < 3; ++y) dLda += dR[x][y] * B[x][y];
+        float dq[4];
+        dq[0] = a * (dR[0][1] * qj + dR[0][2] * qk + dR[1][0] * qj - 2.0f * qi * dR[1][1] - dR[1][2] * qr_ + dR[2][0] * qk + dR[2][1] * qr_ - 2.0f * qi * dR[2][2]);
+        dq[1] = a * (-2.0f * qj * dR[0][0] + dR[0][1] * qi + dR[0][2] * qr_ + dR[1][0] * qi + dR[1][2] * qk - dR[2][0] * qr_ + dR[2][1] * qk - 2.0f * qj * dR[2][2]);
+        dq[2] = a * (-2.0f * qk * dR[0][0] - dR[0][1] * qr_ + dR[0][2] * qi + dR[1][0] * qr_ - 2.0f * qk * dR[1][1] + dR[1][2] * qj + dR[2][0] * qi + dR[2][1] * qj);
+        dq[3] = a * (-dR[0][1] * qk + dR[0][2] * qj + dR[1][0] * qk - dR[1][2] * qi - dR[2][0] * qj + dR[2][1] * qi);
+        const float da = -a * a * dLda;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dq[k] += da * qg.q[k];
+        const float dot = qr[0] * dq[0] + qr[1] * dq[1] + qr[2] * dq[2] + qr[3] * dq[3];
+        const float f = qg.n > 0.f ? dot / (qg.n * qg.m * qg.m) : 0.f;
+        float* orec = s_out + l * RAWB_C;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) orec[3 + k] = dq[k] / qg.m - qr[k] * f;
+        float dd = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            orec[k] = ds[k] * depth * px * (rb.smax - rb.smin) * sig[k] * (1.0f - sig[k]);
+            dd += ds[k] * base[k] * px;
+        }
+        if (rb.d_means) {   // opt-in: the reference's means are detached (sphere_projection.py:14-86)
+            float dir[3];
+            erp_dir(gi / rb.per_ray, rb.H, rb.W, rb.conv, dir);
+            const float* gm = rb.d_means + 3 * (size_t)g;
+#pragma unroll
+            for (int x = 0; x < 3; ++x) dd += (E[x] * gm[0] + E[4 + x] * gm[1] + E[8 + x] * gm[2]) * dir[x];
+        }
+        rb.d_depths[g] = dd;
+    }
+    __syncthreads();
+    const int nfl = nb * RAWB_C;
+    float* dst = rb.d_raw + (size_t)g0 * RAWB_C;
+    if ((((uintptr_t)dst) & 15) == 0) {
+        const int n4 = nfl >> 2;
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        for (int i = tid; i < n4; i += 192) __builtin_nontemporal_store(reinterpret_cast<const f4v*>(s_out)[i], reinterpret_cast<f4v*>(dst) + i);
+        for (int i = (n4 << 2) + tid; i < nfl; i += 192) dst[i] = s_out[i];
+    } else {
+        for (int i = tid; i < nfl; i += 192) dst[i] = s_out[i];
+    }
+}
+
 }  // namespace s360
 
 using namespace s360;
@@ -626,7 +802,7 @@ static int bwd_ctx(const S360Params* prm, const void* workspace, size_t workspac
     c.n_slots = seg_slots_of(prm);
     if (kp.flags & S360_FLAG_SPLIT_LISTS) {   // behind the pair records and the [P] summed dL/dRGB
         char* e = (char*)(c.pairgrad + (size_t)kp.V * (kp.P > 0 ? kp.P : 1) * 3 + (size_t)(kp.P > 0 ? kp.P : 1));
-        c.seg_list = (uint32_t*)(e + 256 - ((uintptr_t)e & 255));
+        c.seg_list = (uint32_t*)(e + 256 - ((uintptr_t)e & 255)) + 32;   // 32 words in front of it hold the SegBwd record
     }
     return S360_OK;
 }
@@ -641,12 +817,6 @@ static int backward_composite(const BwdCtx& c, const S360View* views, const void
     const uint32_t* header = (const uint32_t*)(ws + L.header);
     const bool with_depth = dL_ddepth != nullptr;
     const uint32_t* surv_count = (const uint32_t*)(ws + L.surv_count);  // per-unit replay length: also the work estimate
-    {
-        ProfScope ps(PS_ORDER, st);
-        hipLaunchKernelGGL(k_order_units, dim3(1 + 512), dim3(1024), 0, st, surv_count, c.order, c.nt * 4, c.valid_words, header, kp.cap,
-                           (kp.flags & S360_FLAG_ATOMIC_GRADS) ? c.pairgrad : (float4*)nullptr, (const uint8_t*)(ws + L.vis_mask), kp.P, kp.V,
-                           (const uint32_t*)(ws + L.seg_cnt), (const uint32_t*)(ws + L.chunk_start), c.seg_list, (const uint2*)(ws + L.seg_info));
-    }
     SegBwd sb{};
     if (c.seg_list) {
         sb.seg_flag = (const uint32_t*)(ws + L.seg_flag);
@@ -656,8 +826,14 @@ static int backward_composite(const BwdCtx& c, const S360View* views, const void
         sb.seg_cnt = (const uint32_t*)(ws + L.seg_cnt);
         sb.seg_info = (const uint2*)(ws + L.seg_info);
         sb.seg_list = c.seg_list;
-        sb.n_seg_blocks = (uint32_t)min((size_t)1024, c.n_slots * 4);
+        sb.n_seg_blocks = (uint32_t)min((size_t)256, c.n_slots * 4);
         sb.dbg_base = (uint32_t)c.nt * 4u;
+    }
+    {
+        ProfScope ps(PS_ORDER, st);
+        hipLaunchKernelGGL(k_order_units, dim3(1 + 512), dim3(1024), 0, st, surv_count, c.order, c.nt * 4, c.valid_words, header, kp.cap,
+                           (kp.flags & S360_FLAG_ATOMIC_GRADS) ? c.pairgrad : (float4*)nullptr, (const uint8_t*)(ws + L.vis_mask), kp.P, kp.V,
+                           (const uint32_t*)(ws + L.seg_cnt), (const uint32_t*)(ws + L.chunk_start), c.seg_list, (const uint2*)(ws + L.seg_info), sb);
     }
     {
         ProfScope ps(PS_RENDER_BWD, st);
@@ -667,9 +843,9 @@ static int backward_composite(const BwdCtx& c, const S360View* views, const void
                              dL_ddepth, c.part, (uint8_t*)c.valid_words, c.order, depth_mode,
                              (kp.flags & S360_FLAG_ATOMIC_GRADS) ? (float*)c.pairgrad : (float*)nullptr,
 #ifdef S360_DBG_TIMING
-                             (uint32_t*)(ws + L.keys_alt), sb);  // the forward's merge buffer is free by now
+                             (uint32_t*)(ws + L.keys_alt), c.seg_list ? &sb : (const SegBwd*)nullptr, sb.n_seg_blocks);  // the forward's merge buffer is free by now
 #else
-                             (uint32_t*)nullptr, sb);
+                             (uint32_t*)nullptr, c.seg_list ? &sb : (const SegBwd*)nullptr, sb.n_seg_blocks);
 #endif
     }
     S360_CHECK_LAUNCH();
@@ -943,6 +1119,43 @@ extern "C" int s360_count_contributions(const S360Params* prm, const void* works
                        (const uint32_t*)(ws + L.surv_count), (const uint32_t*)(ws + L.n_contrib), (unsigned long long*)counts,
                        split ? (const uint32_t*)(ws + L.seg_flag) : (const uint32_t*)nullptr, (const uint32_t*)(ws + L.chunk_start),
                        (const uint32_t*)(ws + L.seg_cnt));
+    S360_CHECK_LAUNCH();
+    return S360_OK;
+}
+
+extern "C" int s360_backward_raw(const S360Params* prm, const S360View* views, const S360RawInputs* raw, const float* means, const float* cov6,
+                                 const float* opacities, const void* workspace, size_t workspace_bytes, const float* dL_dimages,
+                                 const float* dL_dimages_scale, const float* dL_ddepth, int32_t depth_mode, int32_t differentiable_means,
+                                 float* d_means3D, float* d_cov6, float* d_opacities, float* d_rgb_sum, float* d_depths,
+                                 float* d_raw_gaussians, void* bwd_workspace, size_t bwd_workspace_bytes, void* stream_) {
+    if (!prm || !raw || !means || !cov6 || !d_means3D || !d_cov6 || !d_opacities || !d_rgb_sum || !d_depths || !d_raw_gaussians)
+        return S360_E_BADARG;
+    if (!(prm->flags & S360_FLAG_RAW_INPUTS) || !(prm->flags & S360_FLAG_SHARED_CAMPOS) || (prm->flags & (S360_FLAG_COV9 | S360_FLAG_SPHERICAL)))
+        return S360_E_BADARG;
+    if (prm->M != 25 || prm->sh_degree != 4) return S360_E_UNSUPPORTED;
+    if ((long long)raw->n_views * raw->per_view != (long long)prm->P) return S360_E_BADARG;
+    // the rasteriser's own backward without its dL/dSH pass (the s360_backward_split form: per-Gaussian dL/dmean, dL/dcov6, dL/dopacity
+    // and the clamp-masked sum of dL/dRGB) ...
+    const float* dummy_sh = raw->raw_gaussians;   // never read: views sharing a camera centre take the colour terms from sh_jac
+    int rc = backward_impl(prm, views, means, cov6, opacities, dummy_sh, nullptr, workspace, workspace_bytes, dL_dimages, dL_dimages_scale,
+                           dL_ddepth, depth_mode, d_means3D, nullptr, d_cov6, d_opacities, nullptr, nullptr, d_rgb_sum, bwd_workspace,
+                           bwd_workspace_bytes, stream_);
+    if (rc || prm->P == 0) return rc;
+    // ... then ONE kernel down to the encoder's outputs
+    S360Layout L;
+    rc = s360_layout(prm, &L);
+    if (rc) return rc;
+    KParams kp;
+    kp.P = prm->P; kp.V = prm->V; kp.H = prm->H; kp.W = prm->W; kp.deg = 4; kp.M = 25;
+    kp.gx = (prm->W + 15) / 16; kp.gy = (prm->H + 15) / 16; kp.T = kp.gx * kp.gy;
+    kp.flags = prm->flags; kp.cap = prm->max_instances;
+    RawBwd rb{raw->extrinsics, raw->depths, (const float*)((const char*)workspace + L.geo7), raw->sh_rotation, means,
+              differentiable_means ? d_means3D : (const float*)nullptr, d_cov6, (const float4*)d_rgb_sum, d_depths, d_raw_gaussians,
+              raw->per_view > 0 ? raw->per_view : 1, raw->H, raw->W, raw->per_ray, raw->erp_convention, 1, raw->scale_min, raw->scale_max, raw->eps};
+    {
+        ProfScope ps(PS_SH_BWD, (hipStream_t)stream_);
+        hipLaunchKernelGGL(k_raw_bwd, dim3((prm->P + 63) / 64), dim3(192), 0, (hipStream_t)stream_, kp, views, rb);
+    }
     S360_CHECK_LAUNCH();
     return S360_OK;
 }

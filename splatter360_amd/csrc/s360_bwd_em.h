@@ -98,20 +98,10 @@ __device__ __forceinline__ float depth_value_grad(float z, float nearp, float fa
 // quadrant, pixel), the transmittance behind the segment (seg_t) and the colour accumulated behind it (seg_c).  The backward replays
 // the head and every segment as INDEPENDENT units from those two: same entry-major arithmetic per unit, the per-pixel running state
 // (T behind, colour behind) starts from the forward's values instead of (final_T, 0).
-struct SegBwd {
-    const uint32_t* seg_flag;     // null: the call was rendered without the flag
-    const uint32_t* chunk_start;
-    const float4* seg_c;
-    const float* seg_t;
-    const uint32_t* seg_cnt;
-    const uint2* seg_info;
-    const uint32_t* seg_list;     // [0] = number of segment units with survivor records, then their indices into seg_info
-    uint32_t n_seg_blocks;        // the launch's first n_seg_blocks workgroups take the segment units (grid-stride over seg_list)
-    uint32_t dbg_base;            // S360_DBG_TIMING: first timing record of the segment units
-};
+typedef SegBwdPod SegBwd;
 
 #ifdef S360_EM_KERNEL_TU
-template <bool WITH_DEPTH>
+template <bool WITH_DEPTH, bool SEG>   // SEG: the call was rendered with S360_FLAG_SPLIT_LISTS (segment units exist); false: none of that code
 __global__ __launch_bounds__(64) void k_render_bwd_em(
     KParams kp, const S360View* __restrict__ views, const uint32_t* __restrict__ tile_start,
     const float4* __restrict__ surv, const uint32_t* __restrict__ surv_count, const uint2* __restrict__ slot_info,
@@ -119,7 +109,7 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
     const float* __restrict__ dL_dimages, const float* __restrict__ dL_dimages_scale, const float* __restrict__ dL_ddepth,
     float4* __restrict__ part,
     uint8_t* __restrict__ valid, const uint32_t* __restrict__ order, int depth_mode, float* __restrict__ pairgrad_atomic,
-    uint32_t* __restrict__ dbg, SegBwd sb) {
+    uint32_t* __restrict__ dbg, SegBwd sb, uint32_t n_seg_blocks) {
     static_assert(SUB_W == 8, "entry-major backward assumes 8x8 quadrants");
     // per-pixel tables, one array per quantity (pixel-contiguous: a 16-byte read hands a four-pixel run to the lanes as two
     // register PAIRS — the operands of the packed v_pk_* arithmetic below)
@@ -128,9 +118,11 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
     __shared__ __attribute__((aligned(16))) float s_B[64];           // T_final * (bg . dL/dpixel)
     __shared__ __attribute__((aligned(16))) uint32_t s_last[64];     // n_contrib
 
-    const bool seg_blk = blockIdx.x < sb.n_seg_blocks;   // segment units of split quadrants first: they are the heavy ones
+    // (SEG = false — calls rendered without S360_FLAG_SPLIT_LISTS — compiles none of the segment code: its seven pointers and the
+    // unit loop cost this kernel 12 VGPRs (SGPRs spilled into VGPR lanes), and the depth variant a wave per SIMD)
+    const bool seg_blk = SEG && blockIdx.x < n_seg_blocks;   // segment units of split quadrants first: they are the heavy ones
     const int lane = threadIdx.x;
-  for (uint32_t sj = blockIdx.x;; sj += sb.n_seg_blocks) {     // one unit per workgroup, except the segment workgroups (grid-stride)
+  for (uint32_t sj = blockIdx.x;; sj += n_seg_blocks) {     // one unit per workgroup, except the segment workgroups (grid-stride)
 #ifdef S360_DBG_TIMING
     const long long t_begin = wall_clock64();
 #endif
@@ -147,10 +139,10 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
         split_unit = true;
         sli = su * 64;
     } else {
-        unit = order ? order[blockIdx.x - sb.n_seg_blocks] : blockIdx.x - sb.n_seg_blocks;  // tile*4 + quadrant
+        unit = order ? order[blockIdx.x - n_seg_blocks] : blockIdx.x - n_seg_blocks;  // tile*4 + quadrant
         n_surv = surv_count[unit];  // survivor records in front of the quadrant's last contributor
         if (n_surv == 0) return;    // nothing reaches any pixel of this quadrant
-        if (sb.seg_flag && sb.seg_flag[unit] == 1u) {   // the head of a split quadrant
+        if (SEG && sb.seg_flag[unit] == 1u) {   // the head of a split quadrant
             split_unit = true;
             sli = ((size_t)SEG_PER_CHUNK * sb.chunk_start[unit >> 2] * 4 + (unit & 3u)) * 64;
         }
@@ -190,7 +182,7 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
             if (WITH_DEPTH) pa.w = dL_ddepth[(size_t)v * hw + pix];  // depth background is 0: no background term
             pb.x = T_final;
             pb.z = T_final * (vw.bg[0] * pa.x + vw.bg[1] * pa.y + vw.bg[2] * pa.z);
-            if (split_unit) {   // wave-uniform: start behind this unit's backmost entry, not behind the whole list
+            if (SEG && split_unit) {   // wave-uniform: start behind this unit's backmost entry, not behind the whole list
                 const float4 cb = sb.seg_c[sli + lane];
                 pb.x = sb.seg_t[sli + lane];
                 float r0 = cb.z * pa.z + (cb.y * pa.y + cb.x * pa.x);
@@ -393,7 +385,7 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
         dbg[4 * di + 3] = (dbg_halves << 16) | min(n_surv, 65535u);
     }
 #endif
-    if (!seg_blk) return;
+    if (!SEG || !seg_blk) return;
   }
 }
 #endif  // S360_EM_KERNEL_TU
@@ -405,6 +397,6 @@ void launch_render_bwd_em(bool with_depth, int n_units, hipStream_t st, const KP
                           const uint32_t* tile_start, const float4* surv, const uint32_t* surv_count, const uint2* slot_info,
                           const float* depths, const float* final_T, const uint32_t* n_contrib, const float* dL_dimages,
                           const float* dL_dimages_scale, const float* dL_ddepth, float4* part, uint8_t* valid, const uint32_t* order, int depth_mode,
-                          float* pairgrad_atomic, uint32_t* dbg, const SegBwd& sb);
+                          float* pairgrad_atomic, uint32_t* dbg, const SegBwd* sbp_host, uint32_t n_seg_blocks);
 
 }  // namespace s360

@@ -71,6 +71,7 @@ __host__ __device__ inline size_t seg_slots_of(const S360Params* prm) {
 }
 #define S360_HDR_SPLIT 5     /* header word: split (tile, quadrant) units of this call */
 #define S360_HDR_SEGWORK 6   /* header word: (tile, quadrant, segment) work items k_render queued for k_render_tail (seg_info[]) */
+#define S360_HDR_SEGBUFS 32  /* header words [32, 64): the segment-state pointers (SegBufs), written by k_tile_scan for k_render */
 
 // Real-SH constants (degree <= 3: public 3DGS table; degree 4: standard real-SH table).
 __device__ constexpr float kC0 = 0.28209479177387814f;
@@ -639,13 +640,28 @@ __device__ __forceinline__ void mse_finish_body(const float* __restrict__ partia
 // header words (uint32 index) through which a S360_FLAG_DEFER_LOSS forward tells the backward where its loss goes
 #define S360_HDR_LOSS 16   /* [16,17] partials pointer, [18,19] loss_out pointer, [20] n_per_view, [21] V, [22] loss_scale bits, [23] inv_elems bits */
 
+// S360_FLAG_SPLIT_LISTS state for the backward composite (see s360_bwd_em.h), parked in front of the segment launch list
+struct SegBwdPod {
+    const uint32_t* seg_flag;
+    const uint32_t* chunk_start;
+    const float4* seg_c;
+    const float* seg_t;
+    const uint32_t* seg_cnt;
+    const uint2* seg_info;
+    const uint32_t* seg_list;
+    uint32_t n_seg_blocks;
+    uint32_t dbg_base;
+};
+static_assert(sizeof(SegBwdPod) <= 32 * 4, "parked in the 32 words in front of seg_list");
+
 static __global__ __launch_bounds__(1024) void k_order_units(const uint32_t* __restrict__ weight, uint32_t* __restrict__ order, int n,
                                                      uint32_t* __restrict__ valid_words, const uint32_t* __restrict__ header,
                                                      uint32_t cap, float4* __restrict__ pairgrad_atomic,
                                                      const uint8_t* __restrict__ vis_mask, int P, int V,
                                                      const uint32_t* __restrict__ seg_cnt, const uint32_t* __restrict__ chunk_start,
-                                                     uint32_t* __restrict__ seg_list, const uint2* __restrict__ seg_info) {
+                                                     uint32_t* __restrict__ seg_list, const uint2* __restrict__ seg_info, SegBwdPod sbpod) {
     if (blockIdx.x == 2 && seg_list) {
+        if (threadIdx.x == 0) *reinterpret_cast<SegBwdPod*>(seg_list - 32) = sbpod;   // the backward composite reads it through one pointer
         // S360_FLAG_SPLIT_LISTS: the segment units that hold survivor records, compacted (any order: every unit is self-contained) —
         // the backward composite's first workgroups take them grid-stride
         __shared__ uint32_t s_n;

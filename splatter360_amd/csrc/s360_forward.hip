@@ -15,6 +15,7 @@
 //   k_render         1 workgroup per 16x16 tile = 4 autonomous waves of 8x8 pixels (no LDS, no barriers)
 #include "s360_device.h"
 #include "s360_prof.h"
+#include "s360_adapter_math.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -251,6 +252,197 @@ __global__ __launch_bounds__(SHE3_G * 3) void k_sh_eval3_jac(KParams kp, const S
     }
     __syncthreads();
     {
+        const int gl = tid / 3, ch = tid - 3 * gl;
+        if (g0 + gl < kp.P) {
+            const float G0 = s_G[(3 * ch) * SHE3_G + gl], G1 = s_G[(3 * ch + 1) * SHE3_G + gl], G2 = s_G[(3 * ch + 2) * SHE3_G + gl];
+            const float4 dr = s_dir[gl];
+            const float dot = dr.x * G0 + dr.y * G1 + dr.z * G2;
+            float* o = sh_jac + 3 * ((size_t)g0 * 3 + tid);
+            o[0] = (G0 - dr.x * dot) * dr.w;
+            o[1] = (G1 - dr.y * dot) * dr.w;
+            o[2] = (G2 - dr.z * dot) * dr.w;
+        }
+    }
+    if (tid < SHE3_G && g0 + tid < kp.P) {
+        const float a0 = s_rgb[3 * tid], a1 = s_rgb[3 * tid + 1], a2 = s_rgb[3 * tid + 2];
+        const uint32_t clampbits = (a0 < 0.f ? 1u : 0u) | (a1 < 0.f ? 2u : 0u) | (a2 < 0.f ? 4u : 0u);
+        rgbc[g0 + tid] = make_float4(fmaxf(a0, 0.f), fmaxf(a1, 0.f), fmaxf(a2, 0.f), __uint_as_float(clampbits));
+    }
+}
+
+// ------------------------------------------------------------------------------ raw encoder outputs -> geometry + colours
+// s360_forward_raw (the purpose of the adapter row): the first kernel of the call reads what the ENCODER emits — per
+// context pixel a depth and a raw record of 3 scale logits, a quaternion and 3 x 25 SH coefficients
+// (/root/reference/src/model/encoder/common/gaussian_adapter_erp.py:50-119) — instead of the [G,3,25] harmonics / [G,3,3] covariances /
+// means the stand-alone adapter would materialise for it to read back (340 B/Gaussian written + 340 read).  One launch:
+//   * the workgroup's 64 raw records (64 x 328 contiguous bytes) are staged into LDS with coalesced non-temporal 16-byte loads;
+//   * wave 0: scales, normalised quaternion, Sigma = (C R) diag(s^2) (C R)^T, mean = C (ray * depth) + t with the adapter's own
+//     expressions (s360_adapter_math.h: golden-pinned against the reference module) -> means[G,3], cov6[G,6] (36 B: what the
+//     geometry pass reads) and the 7 raw geometry words compacted for the backward (28 B);
+//   * all three waves (wave d = colour channel d and derivative component d, as in k_sh_eval3_jac): the SH basis at the view
+//     direction is carried through the adapter's coefficient transform instead of the coefficients — harmonics = D_v (mask . raw)
+//     per degree (gaussian_adapter_erp.py:86,113; rotate_sh, src/misc/sh_rotation.py:10-30), so
+//         rgb = Y . harmonics = (mask . D_v^T Y) . raw,
+//     165 multiply-adds per basis vector against 75 x 25 per Gaussian for rotating the coefficients — and the same for the basis
+//     derivative behind sh_jac.  D_v (the context view's 25 x 25 block-diagonal matrix) sits in LDS.
+// Colours differ from the two-step path (adapter kernel, then k_sh_eval3_jac) by float association only (<= 2e-6).
+struct RawIn {
+    const float* extrinsics;   // [n_views,4,4] context-panorama camera-to-world
+    const float* depths;       // [P]
+    const float* raw;          // [P, 82]
+    const float* sh_rot;       // [n_views,25,25] or null (identity)
+    float* means_out;          // [P,3]
+    float* cov6_out;           // [P,6]
+    float* geo7;               // [P,7] (workspace): the raw geometry words, for the backward
+    int Gv, H, W, per_ray, conv;
+    float smin, smax, eps;
+};
+constexpr int RAW_C = 82;   // 7 + 3 * 25 floats per raw record
+
+// Y'[k] = mask_l * sum_a D[o+a][o+k] Y[o+a]  (D^T applied per degree block; D == null: the masked basis itself)
+__device__ __forceinline__ void raw_rotate_basis(const float* __restrict__ D, const float* Y, float* Yp) {
+#pragma unroll
+    for (int l = 0; l <= 4; ++l) {
+        const int o = l * l, nl = 2 * l + 1;
+#pragma unroll
+        for (int b = 0; b < nl; ++b) {
+            float acc;
+            if (D) {
+                acc = 0.f;
+#pragma unroll
+                for (int a = 0; a < nl; ++a) acc = __builtin_fmaf(D[(o + a) * 25 + o + b], Y[o + a], acc);
+            } else {
+                acc = Y[o + b];
+            }
+            Yp[o + b] = acc * kShMask[l];
+        }
+    }
+}
+
+template <int DC>
+__device__ __forceinline__ void raw_jac_component(float x, float y, float z, const float* __restrict__ D, const float* __restrict__ coef, float* G) {
+    float b0[25], b1[25], b2[25], bp[25];
+    sh_basis_grad(4, x, y, z, b0, b1, b2);
+    raw_rotate_basis(D, DC == 0 ? b0 : (DC == 1 ? b1 : b2), bp);
+    G[0] = G[1] = G[2] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 25; ++k) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) G[ch] = __builtin_fmaf(bp[k], coef[25 * ch + k], G[ch]);
+    }
+}
+
+template <bool JAC>
+__global__ __launch_bounds__(SHE3_G * 3) void k_raw_eval(KParams kp, const S360View* __restrict__ views, RawIn rin, float4* __restrict__ rgbc,
+                                                        float* __restrict__ sh_jac, uint32_t* __restrict__ zero_ptr, int zero_words) {
+    __shared__ __attribute__((aligned(16))) float s_raw[7 * SHE3_G * 3 * 4];   // 64 records x 82 floats = 5 248 floats (+ pad to 7 rounds of 192 float4)
+    __shared__ float s_D[625];
+    __shared__ float4 s_mean[SHE3_G];     // (scaled mean - campos direction inputs): mean xyz
+    __shared__ float s_rgb[SHE3_G * 3];
+    __shared__ float s_G[9 * SHE3_G];
+    __shared__ float4 s_dir[SHE3_G];
+    if ((int)(blockIdx.x * (SHE3_G * 3) + threadIdx.x) < zero_words) zero_ptr[blockIdx.x * (SHE3_G * 3) + threadIdx.x] = 0u;
+    const int tid = threadIdx.x;
+    const int g0 = blockIdx.x * SHE3_G;
+    const int nb = min(SHE3_G, kp.P - g0);
+    {
+        const float* src = rin.raw + (size_t)g0 * RAW_C;
+        const int nfl = nb * RAW_C;
+        if ((((uintptr_t)src) & 15) == 0 && nb == SHE3_G) {
+            float4* d4 = reinterpret_cast<float4*>(s_raw);
+            float4 q[7];
+            typedef float f4v __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int r = 0; r < 7; ++r) {
+                const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(src) + min(tid + r * (SHE3_G * 3), SHE3_G * RAW_C / 4 - 1));
+                q[r] = make_float4(t.x, t.y, t.z, t.w);
+            }
+#pragma unroll
+            for (int r = 0; r < 7; ++r) d4[tid + r * (SHE3_G * 3)] = q[r];
+        } else {
+            for (int i = tid; i < nfl; i += SHE3_G * 3) s_raw[i] = src[i];
+        }
+    }
+    // the context view of this workgroup's Gaussians (one view unless the block straddles a view boundary: then per-lane global reads)
+    const int v_first = g0 / rin.Gv, v_last = (g0 + nb - 1) / rin.Gv;
+    const bool one_view = v_first == v_last;
+    if (rin.sh_rot && one_view)
+        for (int i = tid; i < 625; i += SHE3_G * 3) s_D[i] = rin.sh_rot[(size_t)v_first * 625 + i];
+    __syncthreads();
+    const int d = tid >> 6, l = tid & 63;
+    const int g = g0 + l;
+    if (d == 0 && g < kp.P) {
+        // ---- geometry: the adapter tail's own expressions (k_adapter_fwd)
+        const int v = g / rin.Gv, gi = g - v * rin.Gv;
+        const float* E = rin.extrinsics + 16 * v;
+        const float* rw = s_raw + l * RAW_C;
+        const float depth = rin.depths[g];
+        const float px = 1.0f / (float)max(rin.W, rin.H);
+        float sc3[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sc3[k] = ((rin.smin + (rin.smax - rin.smin) * sigmoidf(rw[k])) * depth) * px;
+        QuatGeom qg;
+        const float qr[4] = {rw[3], rw[4], rw[5], rw[6]};
+        quat_geom(qr, rin.eps, qg);
+        float M[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) M[a][b] = E[4 * a] * qg.R[0][b] + E[4 * a + 1] * qg.R[1][b] + E[4 * a + 2] * qg.R[2][b];
+        const float s2[3] = {sc3[0] * sc3[0], sc3[1] * sc3[1], sc3[2] * sc3[2]};
+        float S[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = a; b < 3; ++b) S[a][b] = S[b][a] = M[a][0] * s2[0] * M[b][0] + M[a][1] * s2[1] * M[b][1] + M[a][2] * s2[2] * M[b][2];
+        float* oc = rin.cov6_out + 6 * (size_t)g;
+        oc[0] = S[0][0]; oc[1] = S[0][1]; oc[2] = S[0][2]; oc[3] = S[1][1]; oc[4] = S[1][2]; oc[5] = S[2][2];
+        float dr[3];
+        erp_dir(gi / rin.per_ray, rin.H, rin.W, rin.conv, dr);
+        const float p[3] = {dr[0] * depth, dr[1] * depth, dr[2] * depth};
+        float mn[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) mn[a] = (E[4 * a] * p[0] + E[4 * a + 1] * p[1] + E[4 * a + 2] * p[2]) + E[4 * a + 3];
+        rin.means_out[3 * (size_t)g] = mn[0]; rin.means_out[3 * (size_t)g + 1] = mn[1]; rin.means_out[3 * (size_t)g + 2] = mn[2];
+        s_mean[l] = make_float4(mn[0], mn[1], mn[2], 0.f);
+        if (rin.geo7) {
+            float* o7 = rin.geo7 + 7 * (size_t)g;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) o7[k] = rw[k];
+        }
+    }
+    __syncthreads();
+    const S360View& vw = views[0];
+    const float sc = vw.scale;
+    float x = 0.f, y = 0.f, z = 1.f, inv = 0.f;
+    if (g < kp.P) {
+        const float4 mn = s_mean[l];
+        const float dx = mn.x * sc - vw.campos[0], dy = mn.y * sc - vw.campos[1], dz = mn.z * sc - vw.campos[2];
+        inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+        x = dx * inv; y = dy * inv; z = dz * inv;
+    }
+    if (g < kp.P) {
+        const float* D = rin.sh_rot ? (one_view ? s_D : rin.sh_rot + (size_t)(g / rin.Gv) * 625) : nullptr;
+        const float* coef = s_raw + l * RAW_C + 7;    // [3][25] channel-major raw coefficients
+        float Y[25], Yp[25];
+        sh_basis(4, x, y, z, Y);
+        raw_rotate_basis(D, Y, Yp);
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 25; ++k) acc += Yp[k] * coef[25 * d + k];
+        s_rgb[3 * l + d] = acc + 0.5f;
+        if (JAC) {
+            float G[3];
+            if (d == 0) raw_jac_component<0>(x, y, z, D, coef, G);     // wave-uniform: each wave compiles ONE derivative component
+            else if (d == 1) raw_jac_component<1>(x, y, z, D, coef, G);
+            else raw_jac_component<2>(x, y, z, D, coef, G);
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) s_G[(3 * ch + d) * SHE3_G + l] = G[ch];
+            if (d == 0) s_dir[l] = make_float4(x, y, z, sc * inv);
+        }
+    }
+    __syncthreads();
+    if (JAC) {
         const int gl = tid / 3, ch = tid - 3 * gl;
         if (g0 + gl < kp.P) {
             const float G0 = s_G[(3 * ch) * SHE3_G + gl], G1 = s_G[(3 * ch + 1) * SHE3_G + gl], G2 = s_G[(3 * ch + 2) * SHE3_G + gl];
@@ -560,11 +752,32 @@ constexpr uint32_t SORT_CHUNK = 8 * SORT_THREADS;
 static_assert(SORT_SHORT % SORT_THREADS == 0 && SORT_SHORT <= SORT_CHUNK, "short lists: SORT_SHORT / SORT_THREADS keys per thread");
 constexpr uint32_t MAX_PASSES = 4;
 
+// S360_FLAG_SPLIT_LISTS state (S360Layout part_* / seg_*), by value into the composites
+struct SegBufs {
+    const uint32_t* chunk_start;  // null: splitting off
+    uint32_t* seg_flag;
+    uint32_t* seg_arrive;         // phase-1 deliveries per (tile, quadrant)
+    uint32_t* seg_arrive2;        // phase-2 deliveries per (tile, quadrant); [V*T*4] = the ticket counter of the work queue
+    uint32_t n_slots;             // segment slots the workspace holds (quadrants whose segments do not fit are not split)
+    float4* part_c;
+    float* part_t;
+    float* part_e;
+    uint32_t* part_l;
+    uint32_t* part_n;
+    float4* seg_c;
+    float* seg_t;
+    uint32_t* seg_cnt;
+    uint2* seg_info;
+    uint32_t* header;
+};
+static_assert(sizeof(SegBufs) <= (64 - S360_HDR_SEGBUFS) * 4, "SegBufs is parked in the workspace header");
+
 constexpr int TS_BLOCK = 1024;  // one workgroup; 16 waves: 1 536 tiles in two sweeps (a 256-thread block needed six: 10 us of barriers)
 __global__ __launch_bounds__(TS_BLOCK) void k_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_start,
                                                          uint32_t* __restrict__ tile_cursor, uint32_t* __restrict__ tile_max_contrib,
                                                          int nt, uint32_t cap, uint32_t* __restrict__ header,
-                                                         uint32_t* __restrict__ chunk_start, unsigned long long* __restrict__ header_mirror) {
+                                                         uint32_t* __restrict__ chunk_start, unsigned long long* __restrict__ header_mirror,
+                                                         SegBufs sg_in) {
     __shared__ uint32_t lds[TS_BLOCK / 64];
     __shared__ uint32_t lds_max;
     if (threadIdx.x == 0) lds_max = 0;
@@ -604,6 +817,10 @@ __global__ __launch_bounds__(TS_BLOCK) void k_tile_scan(const uint32_t* __restri
             header[3] = nch <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(nch - 1);
         }
         header[4] = 0;                        // pairs with more than 32 instance slots (k_emit counts and lists them)
+        // S360_FLAG_SPLIT_LISTS: the segment-state pointers, parked in the header for k_render — which takes ONE pointer to them and
+        // reads them only on its rare hand-over path (as thirteen by-value kernel arguments they cost k_render, at its 80-VGPR cap,
+        // ten more SGPRs spilled into VGPR lanes and a scratch dword: +15 us on the headline)
+        *reinterpret_cast<SegBufs*>(header + S360_HDR_SEGBUFS) = sg_in;
         header[S360_HDR_SPLIT] = 0;           // split (tile, quadrant) units (k_render counts them)
         header[6] = header[7] = 0;
         // S360Params.header_mirror: the count and the overflow flag as ONE 64-bit store into host-visible memory — the caller's
@@ -1164,26 +1381,12 @@ __global__ __launch_bounds__(MSE_BLOCK) void k_mse_finish(const float* __restric
     mse_finish_body(partials, n_per_view, V, loss_scale, inv_elems, out);
 }
 
-// S360_FLAG_SPLIT_LISTS state (S360Layout part_* / seg_*), by value into the composites
-struct SegBufs {
-    const uint32_t* chunk_start;  // null: splitting off
-    uint32_t* seg_flag;
-    uint32_t* seg_arrive;         // phase-1 deliveries per (tile, quadrant)
-    uint32_t* seg_arrive2;        // phase-2 deliveries per (tile, quadrant); [V*T*4] = the ticket counter of the work queue
-    uint32_t n_slots;             // segment slots the workspace holds (quadrants whose segments do not fit are not split)
-    float4* part_c;
-    float* part_t;
-    float* part_e;
-    uint32_t* part_l;
-    uint32_t* part_n;
-    float4* seg_c;
-    float* seg_t;
-    uint32_t* seg_cnt;
-    uint2* seg_info;
-    uint32_t* header;
-};
 
-template <bool WITH_DEPTH>
+// SPLIT (S360_FLAG_SPLIT_LISTS): the hand-over to segment waves is compiled in; false: the kernel only REPORTS quadrants that would
+// have handed over (one store into the caller's host-visible mirror), so that a caller which splits adaptively — the Python layer:
+// the flag is set for the calls that follow a report — pays nothing for the feature on clouds that never split (the hand-over code
+// costs this kernel, at its 80-VGPR cap, a scratch dword and ~10 us on the headline; the second launch another 3 us).
+template <bool WITH_DEPTH, bool SPLIT>
 __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_render(KParams kp, const S360View* __restrict__ views,
                                                       const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ list,
                                                       const float4* __restrict__ recA, const float4* __restrict__ recB,
@@ -1193,7 +1396,9 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
                                                       uint32_t* __restrict__ dbg, const float* __restrict__ depths,
                                                       float* __restrict__ depth_maps, int depth_mode, MseEp ep,
                                                       const uint32_t* __restrict__ tile_order, float4* __restrict__ surv,
-                                                      uint32_t* __restrict__ surv_count, uint32_t* __restrict__ hdr_loss, SegBufs sg) {
+                                                      uint32_t* __restrict__ surv_count, uint32_t* __restrict__ hdr_loss,
+                                                      const SegBufs* __restrict__ sgp, const uint32_t* __restrict__ chunk_start,
+                                                      unsigned long long* __restrict__ cand_mirror) {
 #ifdef S360_DBG_TIMING
     const long long t_begin = wall_clock64();
 #endif
@@ -1262,7 +1467,7 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
     }
     // S360_FLAG_SPLIT_LISTS: where this quadrant may hand the rest of its list over to segment waves (k_render_tail)
     // (lists beyond SORT_SHORT keys only: those own segment slots through the sort's chunk table)
-    const uint32_t split_at = (sg.chunk_start && end - start >= SEG_HEAD + SEG_MIN_REST && end - start > SORT_SHORT) ? start + SEG_HEAD : 0xFFFFFFFFu;
+    const uint32_t split_at = ((SPLIT || cand_mirror) && end - start >= SEG_HEAD + SEG_MIN_REST && end - start > SORT_SHORT) ? start + SEG_HEAD : 0xFFFFFFFFu;
     bool went = false;
     for (uint32_t b = start; b < end; b += 64) {
         const unsigned long long act = __ballot(!done);
@@ -1270,9 +1475,13 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
         if (b == split_at) {   // wave-uniform.  Hand over when some pixel is still FAR from saturating (a pixel about to stop would make
                                // the segment waves speculate for nothing: the headline cloud's polar lists) and the slots exist
             const bool far_px = !done && T >= SEG_T_FAR;
-            if (__ballot(far_px) != 0ull && (SEG_PER_CHUNK * sg.chunk_start[t] + (end - start + SEG_LEN - 1) / SEG_LEN) <= sg.n_slots) {
-                went = true;
-                break;
+            if (__ballot(far_px) != 0ull) {
+                // tell the host (next call): this cloud has quadrants worth splitting
+                if (cand_mirror && lane == 0) __hip_atomic_store(cand_mirror, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (SPLIT && (SEG_PER_CHUNK * chunk_start[t] + (end - start + SEG_LEN - 1) / SEG_LEN) <= sgp->n_slots) {
+                    went = true;
+                    break;
+                }
             }
         }
         const float4 ea = na, eb = nb;
@@ -1431,11 +1640,12 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
             scount += (uint32_t)__popcll(m);
         }
     }
-    if (went) {
+    if (SPLIT && went) {
         // The exact sequential state of this quadrant after SEG_HEAD entries, per pixel, in slot k = 0 of the tile; the segment
         // waves of k_render_tail (next launch) composite [SEG_HEAD, end) in parallel and the last of them to finish combines,
         // replays where a pixel's stop test can trip, and writes the pixels.
-        const size_t slot = (size_t)SEG_PER_CHUNK * sg.chunk_start[t];
+        const SegBufs sg = *sgp;     // (loaded here only)
+        const size_t slot = (size_t)SEG_PER_CHUNK * chunk_start[t];
         const size_t li = (slot * 4 + wave) * 64 + lane;
         sg.part_c[li] = make_float4(C01.x, C01.y, C2D.x, C2D.y);
         sg.part_t[li] = T;
@@ -2015,6 +2225,8 @@ extern "C" int s360_layout(const S360Params* prm, S360Layout* out) {
         out->seg_cnt = take(ns * 4 * 4);
         out->seg_info = take(ns * 4 * 8);
     }
+    // s360_forward_raw: the 7 raw geometry words per Gaussian (scale logits, quaternion), compacted for s360_backward_raw
+    out->geo7 = take((prm->flags & S360_FLAG_RAW_INPUTS) && !fwd_only ? (size_t)(prm->P > 0 ? prm->P : 1) * 28 : 16);
     out->total_bytes = o;
     // backward scratch: 4 quadrant-partial raster-gradient records (12 floats) + 4 validity bytes per instance
     // ... + tile order [V*T] + one gathered 48-byte record per (view, Gaussian) pair
@@ -2023,7 +2235,7 @@ extern "C" int s360_layout(const S360Params* prm, S360Layout* out) {
     const bool atomic = (prm->flags & S360_FLAG_ATOMIC_GRADS) != 0;
     out->backward_bytes = (atomic ? 0 : align_up(cap * 4 * (size_t)(16 * S360_PREC_F4)) + align_up(cap * 4)) + align_up(nt * 4 * 4) + 512 +
                           align_up(np * 48) + align_up((size_t)(prm->P > 0 ? prm->P : 1) * 16) + 256 +
-                          ((prm->flags & S360_FLAG_SPLIT_LISTS) ? align_up((seg_slots_of(prm) * 4 + 64) * 4) + 256 : 0);   // launch list of the split segments' units
+                          ((prm->flags & S360_FLAG_SPLIT_LISTS) ? align_up((seg_slots_of(prm) * 4 + 64 + 32) * 4) + 256 : 0);   // launch list of the split segments' units
     return S360_OK;
 }
 
@@ -2044,9 +2256,10 @@ extern "C" int s360_layout(const S360Params* prm, S360Layout* out) {
 static int forward_impl(const S360Params* prm, const S360View* views, const float* means3D, const float* cov6,
                         const float* opacities, const float* shs, const float* colors_precomp, float* images,
                         float* depth_maps, int depth_mode, int32_t* radii, void* workspace, size_t workspace_bytes,
-                        void* stream_, MseEp ep = MseEp{nullptr, nullptr, nullptr, 0.f, nullptr}) {
+                        void* stream_, MseEp ep = MseEp{nullptr, nullptr, nullptr, 0.f, nullptr}, const RawIn* rawin = nullptr) {
     if (!prm || !views || !images || !workspace) return S360_E_BADARG;
     if (prm->P > 0 && (shs == nullptr) == (colors_precomp == nullptr)) return S360_E_BADARG;
+    if (((prm->flags & S360_FLAG_RAW_INPUTS) != 0) != (rawin != nullptr)) return S360_E_BADARG;   // the flag sizes the workspace for this entry point
     if (prm->P > 0 && (!means3D || !cov6 || !opacities)) return S360_E_BADARG;
     if (shs && (prm->M < 1 || prm->sh_degree < 0 || prm->sh_degree > 4 ||
                 (prm->sh_degree + 1) * (prm->sh_degree + 1) > prm->M))
@@ -2093,7 +2306,7 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
 
     // one clear for the tile histogram and the (adjacent) instance-slot tickets: done by the call's first kernel when that is
     // the SH colour kernel (no memset node: 4 us), else by a memset
-    const bool eager_sh = kp.P > 0 && shs && (kp.flags & S360_FLAG_SHARED_CAMPOS) && (!(kp.flags & S360_FLAG_FORWARD_ONLY) || kp.V >= 2);
+    const bool eager_sh = kp.P > 0 && shs && (kp.flags & S360_FLAG_SHARED_CAMPOS) && (!(kp.flags & S360_FLAG_FORWARD_ONLY) || kp.V >= 2 || rawin);
     const size_t zero_words_sz = (L.tile_start - L.tile_count) / 4;
     const bool fold_clear = eager_sh && zero_words_sz <= (size_t)kp.P;
     uint32_t* zero_ptr = fold_clear ? tile_count : (uint32_t*)nullptr;
@@ -2116,7 +2329,13 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
             const bool jac = !(kp.flags & S360_FLAG_FORWARD_ONLY);
             const bool chm = (kp.flags & S360_FLAG_SH_CHANNEL_MAJOR) != 0;
 #define S360_SHE(A, B) hipLaunchKernelGGL((k_sh_eval<A, B>), dim3(nblk), dim3(S360_BLOCK), 0, st, kp, views, means3D, shs, rgbc, sh_jac, zero_ptr, zero_words)
-            if (chm && kp.M == 25 && kp.deg == 4) {  // the reference's harmonics: one lane per (Gaussian, channel)
+            if (rawin) {   // s360_forward_raw: geometry + colours straight from the encoder's raw records
+                RawIn rin = *rawin;
+                rin.geo7 = jac ? (float*)(ws + L.geo7) : nullptr;
+                const int nb3 = (kp.P + SHE3_G - 1) / SHE3_G;
+                if (jac) hipLaunchKernelGGL(k_raw_eval<true>, dim3(nb3), dim3(SHE3_G * 3), 0, st, kp, views, rin, rgbc, sh_jac, zero_ptr, zero_words);
+                else hipLaunchKernelGGL(k_raw_eval<false>, dim3(nb3), dim3(SHE3_G * 3), 0, st, kp, views, rin, rgbc, sh_jac, zero_ptr, zero_words);
+            } else if (chm && kp.M == 25 && kp.deg == 4) {  // the reference's harmonics: one lane per (Gaussian, channel)
                 const int nb3 = (kp.P + SHE3_G - 1) / SHE3_G;
                 if (jac) hipLaunchKernelGGL(k_sh_eval3_jac, dim3(nb3), dim3(SHE3_G * 3), 0, st, kp, views, means3D, shs, rgbc, sh_jac, zero_ptr, zero_words);
                 else hipLaunchKernelGGL(k_sh_eval3, dim3(nb3), dim3(SHE3_G * 3), 0, st, kp, views, means3D, shs, rgbc, zero_ptr, zero_words);
@@ -2148,8 +2367,13 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
     }
     {
         ProfScope ps(PS_TILE_SCAN, st);
+        const bool split0 = kp.P > 0 && (kp.flags & S360_FLAG_SPLIT_LISTS);
+        SegBufs sg0{split0 ? chunk_start : (const uint32_t*)nullptr, (uint32_t*)(ws + L.seg_flag), (uint32_t*)(ws + L.seg_arrive),
+                    (uint32_t*)(ws + L.seg_arrive2), (uint32_t)seg_slots_of(prm),
+                    (float4*)(ws + L.part_c), (float*)(ws + L.part_t), (float*)(ws + L.part_e), (uint32_t*)(ws + L.part_l), (uint32_t*)(ws + L.part_n),
+                    (float4*)(ws + L.seg_c), (float*)(ws + L.seg_t), (uint32_t*)(ws + L.seg_cnt), (uint2*)(ws + L.seg_info), header};
         hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(TS_BLOCK), 0, st, tile_count, tile_start, tile_cursor, tile_max_contrib, nt, kp.cap, header,
-                           chunk_start, (unsigned long long*)prm->header_mirror);
+                           chunk_start, (unsigned long long*)prm->header_mirror, sg0);
     }
     S360_CHECK_LAUNCH();
     if (kp.P > 0) {
@@ -2212,14 +2436,15 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
                    (uint32_t*)(ws + L.seg_arrive2), (uint32_t)seg_slots_of(prm),
                    (float4*)(ws + L.part_c), (float*)(ws + L.part_t), (float*)(ws + L.part_e), (uint32_t*)(ws + L.part_l), (uint32_t*)(ws + L.part_n),
                    (float4*)(ws + L.seg_c), (float*)(ws + L.seg_t), (uint32_t*)(ws + L.seg_cnt), (uint2*)(ws + L.seg_info), header};
-        if (depth_maps)
-            hipLaunchKernelGGL(k_render<true>, rgrid, rblock, 0, st, kp, views, tile_start,
-                               list, recA, recB, recC, images, final_T, n_contrib, tile_max_contrib, strip_last, dbg,
-                               depths, depth_maps, depth_mode, ep, kp.P > 0 ? tile_order : (const uint32_t*)nullptr, surv, surv_count, hdr_loss, sg);
-        else
-            hipLaunchKernelGGL(k_render<false>, rgrid, rblock, 0, st, kp, views, tile_start,
-                               list, recA, recB, recC, images, final_T, n_contrib, tile_max_contrib, strip_last, dbg,
-                               depths, depth_maps, depth_mode, ep, kp.P > 0 ? tile_order : (const uint32_t*)nullptr, surv, surv_count, hdr_loss, sg);
+        unsigned long long* cand = prm->header_mirror ? (unsigned long long*)prm->header_mirror + 1 : nullptr;   // word 1 of the mirror
+        const SegBufs* sgp = split ? (const SegBufs*)(header + S360_HDR_SEGBUFS) : (const SegBufs*)nullptr;
+#define S360_LAUNCH_RENDER(WD, SP)                                                                                                         \
+    hipLaunchKernelGGL((k_render<WD, SP>), rgrid, rblock, 0, st, kp, views, tile_start, list, recA, recB, recC, images, final_T, n_contrib,      \
+                       tile_max_contrib, strip_last, dbg, depths, depth_maps, depth_mode, ep, kp.P > 0 ? tile_order : (const uint32_t*)nullptr, \
+                       surv, surv_count, hdr_loss, sgp, chunk_start, cand)
+        if (depth_maps) { if (split) S360_LAUNCH_RENDER(true, true); else S360_LAUNCH_RENDER(true, false); }
+        else { if (split) S360_LAUNCH_RENDER(false, true); else S360_LAUNCH_RENDER(false, false); }
+#undef S360_LAUNCH_RENDER
         if (split) {
             const unsigned tgrid = (unsigned)min((size_t)S360_TAIL_GRID, 2 * seg_slots_of(prm));
             if (depth_maps)
@@ -2262,4 +2487,27 @@ extern "C" int s360_forward_mse(const S360Params* prm, const S360View* views, co
     if (depth_maps && (depth_mode < 0 || depth_mode > 3)) return S360_E_BADARG;
     return forward_impl(prm, views, means3D, cov6, opacities, shs, colors_precomp, images, depth_maps, depth_mode, radii,
                         workspace, workspace_bytes, stream_, s360::MseEp{target, d_images, partials, grad_scale, loss_out});
+}
+
+extern "C" int s360_forward_raw(const S360Params* prm, const S360View* views, const S360RawInputs* raw, const float* opacities,
+                                float* means_out, float* cov6_out, float* images, float* depth_maps, int32_t depth_mode, int32_t* radii,
+                                const float* target, float grad_scale, float* d_images, float* partials, float* loss_out, void* workspace,
+                                size_t workspace_bytes, void* stream_) {
+    if (!prm || !raw || !means_out || !cov6_out) return S360_E_BADARG;
+    if (!(prm->flags & S360_FLAG_RAW_INPUTS) || !(prm->flags & S360_FLAG_SHARED_CAMPOS) || (prm->flags & (S360_FLAG_COV9 | S360_FLAG_SPHERICAL)))
+        return S360_E_BADARG;   // one camera centre per call; the geometry pass reads the 6-entry covariances this call writes
+    if (prm->M != 25 || prm->sh_degree != 4) return S360_E_UNSUPPORTED;   // the reference's configuration (costvolume.yaml:16)
+    if (prm->P > 0 && (!raw->extrinsics || !raw->depths || !raw->raw_gaussians)) return S360_E_BADARG;
+    if (raw->n_views < 0 || raw->per_view < 0 || raw->H < 1 || raw->W < 1 || raw->per_ray < 1 ||
+        (long long)raw->n_views * raw->per_view != (long long)prm->P || (long long)raw->H * raw->W * raw->per_ray != (long long)raw->per_view)
+        return S360_E_BADARG;
+    if (raw->erp_convention < 0 || raw->erp_convention > 3 || (raw->erp_convention != 0 && (raw->H < 2 || raw->W < 2))) return S360_E_BADARG;
+    if (depth_maps && (depth_mode < 0 || depth_mode > 3)) return S360_E_BADARG;
+    if (target && (!d_images || !partials)) return S360_E_BADARG;
+    s360::RawIn rin{raw->extrinsics, raw->depths, raw->raw_gaussians, raw->sh_rotation, means_out, cov6_out, nullptr,
+                    raw->per_view > 0 ? raw->per_view : 1, raw->H, raw->W, raw->per_ray, raw->erp_convention, raw->scale_min, raw->scale_max, raw->eps};
+    const float* dummy_sh = reinterpret_cast<const float*>(raw->raw_gaussians ? raw->raw_gaussians : (const float*)workspace);   // never read: the colours come from k_raw_eval
+    return forward_impl(prm, views, means_out, cov6_out, opacities, dummy_sh, nullptr, images, depth_maps, depth_mode, radii, workspace,
+                        workspace_bytes, stream_, target ? s360::MseEp{target, d_images, partials, grad_scale, loss_out}
+                                                         : s360::MseEp{nullptr, nullptr, nullptr, 0.f, nullptr}, &rin);
 }

@@ -50,9 +50,15 @@ LEAN_LISTS = bool(int(os.environ.get("S360_LEAN_LISTS", "1")))
 # after the first 2 048 entries of a list hands the rest over in 1 024-entry segments, one wave each, combined per pixel in list
 # order (pixels whose stop test can trip inside a segment replay it sequentially).  Quadrants that do not split — all of them on
 # lists up to 3 071 entries — are bit-identical either way; inside split quadrants the floating-point association changes
-# (<= 1e-6 per pixel; integers, stop decisions and n_contrib stay those of the sequential walk).  Default on;
+# (<= 1e-6 per pixel; integers, stop decisions and n_contrib stay those of the sequential walk).
 # rasterize_views(split_lists=False), this switch or S360_SPLIT_LISTS=0 keep every list a single sequential chain.
-SPLIT_LONG_LISTS = bool(int(os.environ.get("S360_SPLIT_LISTS", "1")))
+# ADAPTIVE by default ("auto"): the forward always reports, into the caller's pinned mirror, whether some quadrant was worth splitting;
+# the flag is set for the calls that follow such a report (and dropped after 16 calls without one).  A cloud that never splits — the
+# headline's: its polar lists saturate within a few hundred entries — then runs the very kernels of a build without the feature
+# (the hand-over code costs the forward composite ~10 us and its second launch 3 us; the segment units cost the backward composite
+# 12 VGPRs).  The first call on a cloud that needs it runs sequentially (slow, correct) and the next ones split.  True / False force it.
+_sl = os.environ.get("S360_SPLIT_LISTS", "auto")
+SPLIT_LONG_LISTS = "auto" if _sl == "auto" else bool(int(_sl))
 
 # Opt-in (S360_FLAG_ATOMIC_GRADS): the backward composite accumulates with float32 atomics instead of the deterministic
 # partial-record gather — a quarter of the backward scratch, one launch less, gradients no longer bit-reproducible run to run.
@@ -147,7 +153,7 @@ def _mirror(key) -> Tensor:
     one pinned int64 per (device, shape, list mode), never freed (a kernel in flight may still write it).  -1 = nothing yet."""
     m = _MIRRORS.get(key)
     if m is None:
-        m = torch.full((1,), -1, dtype=torch.int64).pin_memory()
+        m = torch.tensor([-1, 0], dtype=torch.int64).pin_memory()    # [1]: "some quadrant was worth splitting" (k_render)
         _MIRRORS[key] = m
     return m
 
@@ -175,6 +181,23 @@ def _poll_mirror(key, warn: bool = True) -> None:
 _OVERFLOW_WARNED: dict = {}
 _CHUNK_HINT: dict = {}      # hint key -> most 4 096-key sort chunks of long tile lists any finished call of that shape reported
 SEG_PER_CHUNK = 8           # csrc/s360_device.h: segment slots per sort chunk
+
+
+_SPLIT_AGE: dict = {}       # hint key -> calls since the forward last reported a quadrant worth splitting
+
+
+def split_decision(key, mode) -> bool:
+    """S360_FLAG_SPLIT_LISTS for the next call of this shape: `mode` itself when it is True / False, else adaptive — on while a
+    call of the last 16 reported (through word 1 of the pinned mirror, a plain host read) a quadrant worth splitting."""
+    if mode is True or mode is False:
+        return mode
+    m = _MIRRORS.get(key)
+    if m is not None and int(m[1]) != 0:
+        m[1] = 0                      # (a report landing right after this clear is seen by the next call: never lost for long)
+        _SPLIT_AGE[key] = 0
+    else:
+        _SPLIT_AGE[key] = _SPLIT_AGE.get(key, 1 << 30) + 1
+    return _SPLIT_AGE[key] <= 16
 
 
 def default_segments(key) -> int:
@@ -368,6 +391,9 @@ class _RasterizeViews(torch.autograd.Function):
             if sh is not None and p == 0:
                 prm.M = max(prm.M, (int(sh_degree) + 1) ** 2)
             needs_bwd = any(ctx.needs_input_grad[:6])  # (grad mode is off inside Function.forward; this reflects apply-time)
+            hkey = _hint_key(m3.device, p, v, int(h), int(w), lean)
+            _mirror(hkey)
+            split_lists = split_decision(hkey, split_lists) and not spherical
             prm.flags = (_lib.FLAG_SHARED_CAMPOS if (shared_campos or v == 1) else 0) | (
                 _lib.FLAG_COV9 if cov9 else 0) | (_lib.FLAG_SH_CHANNEL_MAJOR if sh_channel_major else 0) | (
                 0 if (needs_bwd or keep_slots) else _lib.FLAG_FORWARD_ONLY) | (
@@ -380,7 +406,6 @@ class _RasterizeViews(torch.autograd.Function):
                 p, v, int(h), int(w), device=m3.device, lean=lean, lazy=(check != "sync"))
             # every forward reports (instance count, overflow flag, long-list chunks) into pinned host memory: how check="lazy" callers
             # size the next call
-            hkey = _hint_key(m3.device, p, v, int(h), int(w), lean)
             prm.header_mirror = _mirror(hkey).data_ptr()
             prm.max_segments = default_segments(hkey) if split_lists else 0
             mse = None
@@ -513,6 +538,129 @@ class _RasterizeViews(torch.autograd.Function):
         return d_m3, d_m2, d_sh, d_col, d_op.view(-1, 1), d_c6, None, None, None
 
 
+class _RasterizeRaw(torch.autograd.Function):
+    """The adapter tail fused into the rasteriser (s360_forward_raw / s360_backward_raw): from the encoder's raw
+    outputs (depths, opacities, raw_gaussians of the context panoramas) to the rendered views of ONE target camera centre, without
+    the [G,3,25] harmonics / [G,3,3] covariances the two-step path (adapter.adapter_tail, then rasterize_views) writes and reads
+    back, and without the [G,3,25] dL/dSH round trip in the backward.  Differentiable w.r.t. depths, opacities, raw_gaussians."""
+
+    @staticmethod
+    def forward(ctx, depths, opacities, raw, ctx_extrinsics, sh_rot, views, cfg, mse_target=None):
+        (h, w, ch, cw, per_ray, smin, smax, eps, conv, diff_means, max_instances, check, depth_mode, mse_weight, mse_count, lean, mse_defer,
+         split_lists) = cfg
+        if not depths.is_cuda:
+            raise RuntimeError("depths must live on the GPU (hip device); the rasteriser has no CPU path")
+        dev = depths.device
+        with torch.cuda.device(dev):
+            dep = _f32c(depths, "depths").reshape(-1)
+            op = _f32c(opacities, "opacities").reshape(-1)
+            rw = _f32c(raw, "raw_gaussians")
+            ext = _f32c(ctx_extrinsics, "extrinsics").reshape(-1, 4, 4)
+            rot = None if sh_rot is None else _f32c(sh_rot, "sh_rotation")
+            vw = _f32c(views, "views")
+            nv = int(ext.shape[0])
+            p, v = int(dep.shape[0]), int(vw.shape[0])
+            if rw.shape[-1] != 82 or rw.numel() != p * 82 or p % max(nv, 1) or (p // max(nv, 1)) != ch * cw * per_ray:
+                raise RuntimeError("rasterize_raw: raw_gaussians must be [views * h * w * per_ray, 82] (degree-4 harmonics) matching depths / extrinsics")
+            if v > _lib.S360_MAX_VIEWS:
+                raise RuntimeError(f"at most {_lib.S360_MAX_VIEWS} views per call")
+            needs_bwd = any(ctx.needs_input_grad[:3])
+            hkey = _hint_key(dev, p, v, int(h), int(w), lean)
+            _mirror(hkey)
+            split_lists = split_decision(hkey, split_lists)
+            prm = _lib.S360Params()
+            prm.P, prm.V, prm.H, prm.W, prm.sh_degree, prm.M = p, v, int(h), int(w), 4, 25
+            prm.flags = _lib.FLAG_SHARED_CAMPOS | _lib.FLAG_RAW_INPUTS | (0 if needs_bwd else _lib.FLAG_FORWARD_ONLY) | (
+                _lib.FLAG_LEAN_LISTS if lean else 0) | (_lib.FLAG_SPLIT_LISTS if split_lists else 0) | (
+                _lib.FLAG_DEFER_LOSS if (mse_defer and mse_target is not None and needs_bwd) else 0)
+            prm.max_instances = int(max_instances) if max_instances else default_capacity(p, v, int(h), int(w), device=dev, lean=lean,
+                                                                                          lazy=(check != "sync"))
+            prm.header_mirror = _mirror(hkey).data_ptr()
+            prm.max_segments = default_segments(hkey) if split_lists else 0
+            rin = _lib.S360RawInputs(ext.data_ptr(), dep.data_ptr(), rw.data_ptr(), None if rot is None else rot.data_ptr(), nv, p // max(nv, 1),
+                                     int(ch), int(cw), int(per_ray), int(conv), float(smin), float(smax), float(eps))
+            means = torch.empty((p, 3), dtype=torch.float32, device=dev)
+            cov6 = torch.empty((p, 6), dtype=torch.float32, device=dev)
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+            def call():
+                lay = _lib.layout(prm)
+                ws = torch.empty(lay.total_bytes, dtype=torch.uint8, device=dev)
+                images = torch.empty((v, 3, prm.H, prm.W), dtype=torch.float32, device=dev)
+                depth = torch.empty((v, prm.H, prm.W), dtype=torch.float32, device=dev) if depth_mode is not None else None
+                st = RasterState(prm, lay, ws)
+                tgt = d_images = partials = loss_out = None
+                gs = 0.0
+                if mse_target is not None:
+                    tgt = _f32c(mse_target, "mse_target")
+                    n_mean = int(mse_count) if mse_count else v * 3 * int(h) * int(w)
+                    gs = 2.0 * float(mse_weight) / n_mean
+                    d_images = torch.empty_like(images)
+                    partials = torch.empty((v * ((prm.H + 15) // 16) * ((prm.W + 15) // 16) * 4, 2), dtype=torch.float32, device=dev)
+                    loss_out = torch.empty((1 + v,), dtype=torch.float32, device=dev)
+                    st.d_images, st.mse_partials, st.mse_out = d_images, partials, loss_out
+                rc = _lib.lib().s360_forward_raw(C.byref(prm), _ptr(vw), C.byref(rin), _ptr(op), _ptr(means), _ptr(cov6), _ptr(images), _ptr(depth),
+                                                 DEPTH_MODES.get(depth_mode, 0), None, _ptr(tgt), C.c_float(gs), _ptr(d_images), _ptr(partials),
+                                                 _ptr(loss_out), _ptr(ws), lay.total_bytes, stream)
+                _lib.check(rc, "s360_forward_raw")
+                return images, depth, st
+
+            images, depth, state = call()
+            if check == "sync" and state.overflowed():
+                prm.max_instances = state.num_rendered()
+                images, depth, state = call()
+        ctx.set_materialize_grads(False)
+        ctx.state, ctx.rin_cfg, ctx.depth_mode, ctx.diff_means = state, (nv, ch, cw, per_ray, conv, smin, smax, eps), depth_mode, bool(diff_means)
+        _RasterizeViews.last_state = state
+        loss = state.mse_out[0] if mse_target is not None else torch.empty(0, dtype=torch.float32, device=dev)
+        clipped = state.mse_out[1:] if mse_target is not None else loss
+        if depth is None:
+            depth = torch.empty(0, dtype=torch.float32, device=dev)
+            ctx.mark_non_differentiable(depth, clipped, means, cov6)
+        else:
+            ctx.mark_non_differentiable(clipped, means, cov6)
+        ctx.save_for_backward(dep, op, rw, ext, rot, vw, means, cov6)
+        return images, depth, loss, clipped, means, cov6
+
+    @staticmethod
+    def backward(ctx, grad_images, grad_depth, grad_loss, _gc, _gm, _gv):
+        dep, op, rw, ext, rot, vw, means, cov6 = ctx.saved_tensors
+        state: RasterState = ctx.state
+        prm, lay = state.prm, state.layout
+        nv, ch, cw, per_ray, conv, smin, smax, eps = ctx.rin_cfg
+        dev = dep.device
+        p = prm.P
+        with torch.cuda.device(dev):
+            g = None if grad_images is None else grad_images.detach().float()
+            g_scale = None
+            if grad_loss is not None and getattr(state, "d_images", None) is not None:
+                if g is None:
+                    g, g_scale = state.d_images, grad_loss.detach().float().reshape(1).contiguous()
+                else:
+                    g = g + state.d_images * grad_loss.detach().float()
+            if g is None:
+                g = torch.zeros((prm.V, 3, prm.H, prm.W), dtype=torch.float32, device=dev)
+            g = g.contiguous()
+            gd, dm = None, 0
+            if grad_depth is not None and ctx.depth_mode is not None:
+                gd, dm = grad_depth.detach().float().contiguous(), DEPTH_MODES[ctx.depth_mode]
+            rin = _lib.S360RawInputs(ext.data_ptr(), dep.data_ptr(), rw.data_ptr(), None if rot is None else rot.data_ptr(), nv, p // max(nv, 1),
+                                     int(ch), int(cw), int(per_ray), int(conv), float(smin), float(smax), float(eps))
+            d_m3 = torch.empty((p, 3), dtype=torch.float32, device=dev)
+            d_c6 = torch.empty((p, 6), dtype=torch.float32, device=dev)
+            d_op = torch.empty((p,), dtype=torch.float32, device=dev)
+            d_rgb = torch.empty((p, 4), dtype=torch.float32, device=dev)
+            d_dep = torch.empty((p,), dtype=torch.float32, device=dev)
+            d_raw = torch.empty((p, 82), dtype=torch.float32, device=dev)
+            bws = torch.empty(lay.backward_bytes, dtype=torch.uint8, device=dev)
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            rc = _lib.lib().s360_backward_raw(C.byref(prm), _ptr(vw), C.byref(rin), _ptr(means), _ptr(cov6), _ptr(op), _ptr(state.workspace),
+                                              lay.total_bytes, _ptr(g), _ptr(g_scale), _ptr(gd), dm, int(ctx.diff_means), _ptr(d_m3), _ptr(d_c6),
+                                              _ptr(d_op), _ptr(d_rgb), _ptr(d_dep), _ptr(d_raw), _ptr(bws), lay.backward_bytes, stream)
+            _lib.check(rc, "s360_backward_raw")
+        return d_dep, d_op, d_raw, None, None, None, None, None
+
+
 _RasterizeViews.last_state = None
 _RasterizeViews.last_deferred = None
 _RasterizeViews.last_holder = None
@@ -611,11 +759,35 @@ def rasterize_views(means3D: Tensor, cov6: Tensor, opacities: Tensor, shs: Optio
     cfg = (image_height, image_width, sh_degree, shared_campos, max_instances, check, want_radii, cov9,
            sh_channel_major, keep_slots, depth_mode, defer_sh, mse_weight, mse_count, bool(spherical), exchange,
            LEAN_LISTS if lean is None else bool(lean), bool(mse_defer), ATOMIC_GRADS if atomic_grads is None else bool(atomic_grads),
-           SPLIT_LONG_LISTS if split_lists is None else bool(split_lists))
+           SPLIT_LONG_LISTS if split_lists is None else (split_lists if split_lists == "auto" else bool(split_lists)))
     images, radii, depth, loss, clipped = _RasterizeViews.apply(means3D, means2D, shs, colors_precomp, op2, cov6, views,
                                                                 cfg, mse_target)
     images.s360_deferred = _RasterizeViews.last_holder      # see deferred_of()
     out = (images, radii) if depth_mode is None else (images, radii, depth)
+    return out if mse_target is None else out + (FusedMse(loss, clipped),)
+
+
+def rasterize_raw(depths: Tensor, opacities: Tensor, raw_gaussians: Tensor, context_extrinsics: Tensor, *, views: Tensor, image_height: int,
+                  image_width: int, context_shape: tuple, scale_min: float, scale_max: float, sh_rotation: Optional[Tensor] = None,
+                  per_ray: int = 1, eps: float = 1e-8, erp_convention: int = 0, differentiable_means: bool = False,
+                  max_instances: Optional[int] = None, check: str = "sync", depth_mode: Optional[str] = None,
+                  mse_target: Optional[Tensor] = None, mse_weight: float = 1.0, mse_count: Optional[int] = None, lean: Optional[bool] = None,
+                  mse_defer: bool = False, split_lists: Optional[bool] = None):
+    """Render V views sharing one camera centre ([V,44] packed) straight from the encoder's raw outputs: depths / opacities [n*h*w*per_ray]
+    (view-major, ray-major), raw_gaussians [same, 82] (3 scale logits, quaternion xyzw, 3 x 25 SH coefficients), context_extrinsics
+    [n,4,4], sh_rotation [n,25,25] (adapter.sh_rotation_blocks) or None.  = adapter.adapter_tail(...) followed by rasterize_views(...)
+    on its result, in fewer bytes: see _RasterizeRaw.  Returns (images[V,3,H,W], means[P,3], cov6[P,6]) (+ depth maps, + FusedMse as
+    in rasterize_views).  Gradients flow to depths, opacities and raw_gaussians; the means are detached like the reference's unless
+    differentiable_means."""
+    if depth_mode is not None and depth_mode not in DEPTH_MODES:
+        raise ValueError(f"depth_mode must be one of {sorted(DEPTH_MODES)}")
+    ch, cw = context_shape
+    cfg = (image_height, image_width, int(ch), int(cw), int(per_ray), float(scale_min), float(scale_max), float(eps), int(erp_convention),
+           bool(differentiable_means), max_instances, check, depth_mode, mse_weight, mse_count, LEAN_LISTS if lean is None else bool(lean),
+           bool(mse_defer), SPLIT_LONG_LISTS if split_lists is None else (split_lists if split_lists == "auto" else bool(split_lists)))
+    images, depth, loss, clipped, means, cov6 = _RasterizeRaw.apply(depths, opacities, raw_gaussians, context_extrinsics, sh_rotation, views, cfg,
+                                                                    mse_target)
+    out = (images, means, cov6) if depth_mode is None else (images, means, cov6, depth)
     return out if mse_target is None else out + (FusedMse(loss, clipped),)
 
 
