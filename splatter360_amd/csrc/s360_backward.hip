@@ -582,18 +582,20 @@ constexpr int RAWB_C = 82;
 
 __global__ __launch_bounds__(192) void k_raw_bwd(KParams kp, const S360View* __restrict__ views, RawBwd rb) {
     __shared__ __attribute__((aligned(16))) float s_out[64 * RAWB_C];
-    __shared__ float s_D[625];
+    __shared__ float s_D[2 * 628];   // the rotation matrices of the (at most two) context views of this workgroup's Gaussians
     const int tid = threadIdx.x, d = tid >> 6, l = tid & 63;
     const int g0 = blockIdx.x * 64, nb = min(64, kp.P - g0), g = g0 + l;
     const int v_first = g0 / rb.Gv, v_last = (g0 + nb - 1) / rb.Gv;
-    const bool one_view = v_first == v_last;
-    if (rb.sh_rot && one_view)
+    if (rb.sh_rot) {
         for (int i = tid; i < 625; i += 192) s_D[i] = rb.sh_rot[(size_t)v_first * 625 + i];
+        if (v_last != v_first)
+            for (int i = tid; i < 625; i += 192) s_D[628 + i] = rb.sh_rot[(size_t)v_last * 625 + i];
+    }
     __syncthreads();
     if (g < kp.P) {
         // ---- colour channel d: sum over the camera groups of (mask . D^T Y(dir_j)) * dL/dRGB_j[d]
         const float m0 = rb.means[3 * (size_t)g], m1 = rb.means[3 * (size_t)g + 1], m2 = rb.means[3 * (size_t)g + 2];
-        const float* D = rb.sh_rot ? (one_view ? s_D : rb.sh_rot + (size_t)(g / rb.Gv) * 625) : nullptr;
+        const float* D = rb.sh_rot ? s_D + 628 * (g / rb.Gv - v_first) : nullptr;   // LDS always (never a flat pointer)
         float acc[25];
 #pragma unroll
         for (int k = 0; k < 25; ++k) acc[k] = 0.f;

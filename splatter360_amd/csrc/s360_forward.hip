@@ -336,7 +336,7 @@ template <bool JAC>
 __global__ __launch_bounds__(SHE3_G * 3) void k_raw_eval(KParams kp, const S360View* __restrict__ views, RawIn rin, float4* __restrict__ rgbc,
                                                         float* __restrict__ sh_jac, uint32_t* __restrict__ zero_ptr, int zero_words) {
     __shared__ __attribute__((aligned(16))) float s_raw[7 * SHE3_G * 3 * 4];   // 64 records x 82 floats = 5 248 floats (+ pad to 7 rounds of 192 float4)
-    __shared__ float s_D[625];
+    __shared__ float s_D[2 * 628];        // the rotation matrices of the (at most two) context views of this workgroup's Gaussians
     __shared__ float4 s_mean[SHE3_G];     // (scaled mean - campos direction inputs): mean xyz
     __shared__ float s_rgb[SHE3_G * 3];
     __shared__ float s_G[9 * SHE3_G];
@@ -366,8 +366,11 @@ __global__ __launch_bounds__(SHE3_G * 3) void k_raw_eval(KParams kp, const S360V
     // the context view of this workgroup's Gaussians (one view unless the block straddles a view boundary: then per-lane global reads)
     const int v_first = g0 / rin.Gv, v_last = (g0 + nb - 1) / rin.Gv;
     const bool one_view = v_first == v_last;
-    if (rin.sh_rot && one_view)
+    if (rin.sh_rot) {
         for (int i = tid; i < 625; i += SHE3_G * 3) s_D[i] = rin.sh_rot[(size_t)v_first * 625 + i];
+        if (!one_view)
+            for (int i = tid; i < 625; i += SHE3_G * 3) s_D[628 + i] = rin.sh_rot[(size_t)v_last * 625 + i];
+    }
     __syncthreads();
     const int d = tid >> 6, l = tid & 63;
     const int g = g0 + l;
@@ -421,8 +424,12 @@ __global__ __launch_bounds__(SHE3_G * 3) void k_raw_eval(KParams kp, const S360V
         inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
         x = dx * inv; y = dy * inv; z = dz * inv;
     }
+    // (the rotation matrix is read from LDS as broadcasts; a workgroup straddling a view boundary — only when a view's Gaussian
+    // count is not a multiple of 64 — takes its views one after the other)
     if (g < kp.P) {
-        const float* D = rin.sh_rot ? (one_view ? s_D : rin.sh_rot + (size_t)(g / rin.Gv) * 625) : nullptr;
+        // LDS, always (a pointer that may be LDS or global compiles to flat loads: 305 us for this kernel instead of ~100); a workgroup
+        // that straddles a view boundary holds both views' matrices and every lane takes its own
+        const float* D = rin.sh_rot ? s_D + 628 * (g / rin.Gv - v_first) : nullptr;
         const float* coef = s_raw + l * RAW_C + 7;    // [3][25] channel-major raw coefficients
         float Y[25], Yp[25];
         sh_basis(4, x, y, z, Y);
@@ -2502,6 +2509,7 @@ extern "C" int s360_forward_raw(const S360Params* prm, const S360View* views, co
         (long long)raw->n_views * raw->per_view != (long long)prm->P || (long long)raw->H * raw->W * raw->per_ray != (long long)raw->per_view)
         return S360_E_BADARG;
     if (raw->erp_convention < 0 || raw->erp_convention > 3 || (raw->erp_convention != 0 && (raw->H < 2 || raw->W < 2))) return S360_E_BADARG;
+    if (raw->n_views > 1 && raw->per_view < 64) return S360_E_UNSUPPORTED;   // a 64-Gaussian workgroup spans at most two context views
     if (depth_maps && (depth_mode < 0 || depth_mode > 3)) return S360_E_BADARG;
     if (target && (!d_images || !partials)) return S360_E_BADARG;
     s360::RawIn rin{raw->extrinsics, raw->depths, raw->raw_gaussians, raw->sh_rotation, means_out, cov6_out, nullptr,
