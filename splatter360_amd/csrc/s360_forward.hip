@@ -1389,6 +1389,181 @@ __global__ __launch_bounds__(MSE_BLOCK) void k_mse_finish(const float* __restric
 }
 
 
+// ---- shared by k_render's phase-1 workers and k_render_tail (S360_FLAG_SPLIT_LISTS; see k_render_tail below)
+__device__ __forceinline__ void st_dev32(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t ld_dev32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_devf(float* p, float v) { st_dev32(reinterpret_cast<uint32_t*>(p), __float_as_uint(v)); }
+__device__ __forceinline__ float ld_devf(const float* p) { return __uint_as_float(ld_dev32(reinterpret_cast<const uint32_t*>(p))); }
+
+struct WaveLds {   // one wave's slices of the compaction arrays (see k_render)
+    float *x, *y, *a, *b, *c, *o;
+    float2 *rg, *bz;
+    uint32_t* pos;
+};
+
+// k_render's chunk loop over list positions [b0, b1) of the tile that starts at `start` (b0 - start a multiple of 64), on the
+// running per-pixel state (T, C01, C2D, last, done); sv != null: survivor records appended at sv[3 (scount + rank)].
+// T_ONLY: transmittance and stop logic alone (phase 1).
+template <bool WITH_DEPTH, bool T_ONLY>
+__device__ __forceinline__ void composite_segment(const uint32_t* __restrict__ list, const float4* __restrict__ recA, const float* __restrict__ depths,
+                                                  uint32_t start, uint32_t b0, uint32_t b1, float pxf, float pyf, float x0, float ys0, int lane,
+                                                  const WaveLds& L, float inv_scale, float v_near, float v_far, int depth_mode, float& T, f2& C01,
+                                                  f2& C2D, uint32_t& last, bool& done, float4* sv, uint32_t& scount) {
+    uint32_t p_n1 = 0, p_n2 = 0;
+    if (b0 + lane < b1) p_n1 = list[b0 + lane];
+    if (b0 + 64 + lane < b1) p_n2 = list[b0 + 64 + lane];
+    float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na, nc = na;
+    float nz = 0.f;
+    if (b0 + lane < b1) {
+        na = recA[3 * (size_t)(p_n1)];
+        nb = recA[3 * (size_t)(p_n1) + 1];
+        nc = recA[3 * (size_t)(p_n1) + 2];
+        if (WITH_DEPTH && !T_ONLY) nz = depths[p_n1];
+    }
+    for (uint32_t b = b0; b < b1; b += 64) {
+        const unsigned long long act = __ballot(!done);
+        if (act == 0ull) break;
+        const float4 ea = na, eb = nb;
+        float ez = 0.f;
+        if (WITH_DEPTH && !T_ONLY) ez = depth_value(nz * inv_scale, v_near, v_far, depth_mode);
+        const float ec = nc.x, erad = nc.y, eka = nc.z, ekb = nc.w;
+        const bool ev = b + lane < b1;
+        const uint32_t epair = p_n1;
+        p_n1 = p_n2;
+        if (b + 64 + lane < b1) {
+            na = recA[3 * (size_t)(p_n1)];
+            nb = recA[3 * (size_t)(p_n1) + 1];
+            nc = recA[3 * (size_t)(p_n1) + 2];
+            if (WITH_DEPTH && !T_ONLY) nz = depths[p_n1];
+        }
+        if (b + 128 + lane < b1) p_n2 = list[b + 128 + lane];
+        const bool hit = ev && quadrant_hit(ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, eka, ekb, x0, ys0);
+        const unsigned long long m = __ballot(hit);
+        if (m == 0ull) continue;
+        const uint32_t rel = b - start;  // list position of this chunk's lane 0
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (!T_ONLY && sv && hit) {
+            float4* o = sv + 3 * (size_t)(scount + rank);
+            o[0] = ea;
+            o[1] = eb;
+            o[2] = make_float4(ec, erad, __uint_as_float(rel + (uint32_t)lane), __uint_as_float(epair));
+        }
+        scount += (uint32_t)__popcll(m);
+        if (__popcll(act) > SPARSE_PIXELS) {
+            const uint32_t cnt = (uint32_t)__popcll(m);
+            if (hit) {
+                L.x[rank] = ea.x; L.y[rank] = ea.y; L.a[rank] = ea.z; L.b[rank] = ea.w;
+                L.c[rank] = eb.x; L.o[rank] = eb.y;
+                if (!T_ONLY) {
+                    L.rg[rank] = make_float2(eb.z, eb.w);
+                    L.bz[rank] = make_float2(ec, ez);
+                    L.pos[rank] = rel + (uint32_t)lane + 1u;
+                }
+            }
+            if (lane < 3) {  // null records: opacity 0
+                L.x[cnt + lane] = 0.f; L.y[cnt + lane] = 0.f; L.a[cnt + lane] = 0.f; L.b[cnt + lane] = 0.f;
+                L.c[cnt + lane] = 0.f; L.o[cnt + lane] = 0.f;
+                if (!T_ONLY) {
+                    L.rg[cnt + lane] = make_float2(0.f, 0.f);
+                    L.bz[cnt + lane] = make_float2(0.f, 0.f);
+                    L.pos[cnt + lane] = 0u;
+                }
+            }
+            const f2 pxf2 = f2{pxf, pxf}, pyf2 = f2{pyf, pyf};
+            for (uint32_t i = 0; i < cnt; i += 4) {
+                const float4 vx = *reinterpret_cast<const float4*>(&L.x[i]), vy = *reinterpret_cast<const float4*>(&L.y[i]),
+                             va = *reinterpret_cast<const float4*>(&L.a[i]), vb = *reinterpret_cast<const float4*>(&L.b[i]),
+                             vc = *reinterpret_cast<const float4*>(&L.c[i]), vo = *reinterpret_cast<const float4*>(&L.o[i]);
+                float al[4], om[4];
+                bool ok[4];
+                bool any_ok = false;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {  // entries 2j, 2j+1 as one register pair: k_render's operations in k_render's order
+                    const f2 X = j ? f2{vx.z, vx.w} : f2{vx.x, vx.y}, Y = j ? f2{vy.z, vy.w} : f2{vy.x, vy.y};
+                    const f2 A = j ? f2{va.z, va.w} : f2{va.x, va.y}, B = j ? f2{vb.z, vb.w} : f2{vb.x, vb.y};
+                    const f2 Cc = j ? f2{vc.z, vc.w} : f2{vc.x, vc.y}, O = j ? f2{vo.z, vo.w} : f2{vo.x, vo.y};
+                    const f2 dx = X - pxf2, dy = Y - pyf2;
+                    const f2 t = pk_fma(B, dy, A * dx);
+                    const f2 pw = pk_fma(t, dx, (Cc * dy) * dy);
+                    const f2 og = O * f2{__builtin_amdgcn_exp2f(pw.x), __builtin_amdgcn_exp2f(pw.y)};
+                    al[2 * j] = fminf(0.99f, og.x);
+                    al[2 * j + 1] = fminf(0.99f, og.y);
+                    const f2 o2 = f2{1.0f, 1.0f} - f2{al[2 * j], al[2 * j + 1]};
+                    om[2 * j] = o2.x;
+                    om[2 * j + 1] = o2.y;
+                    ok[2 * j] = !done && !(pw.x > 0.0f) && !(al[2 * j] < 1.0f / 255.0f);
+                    ok[2 * j + 1] = !done && !(pw.y > 0.0f) && !(al[2 * j + 1] < 1.0f / 255.0f);
+                    any_ok = any_ok || ok[2 * j] || ok[2 * j + 1];
+                }
+                if (__ballot(any_ok) == 0ull) continue;  // wave-uniform
+                if (T_ONLY) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool v = ok[e] && !done;
+                        const float test_T = T * om[e];
+                        const bool stop = v && test_T < 0.0001f;
+                        done = done || stop;
+                        T = (v && !stop) ? test_T : T;
+                    }
+                } else {
+                    const float4 rg01 = *reinterpret_cast<const float4*>(&L.rg[i]), rg23 = *reinterpret_cast<const float4*>(&L.rg[i + 2]);
+                    const float4 bz01 = *reinterpret_cast<const float4*>(&L.bz[i]), bz23 = *reinterpret_cast<const float4*>(&L.bz[i + 2]);
+                    const uint4 vp = *reinterpret_cast<const uint4*>(&L.pos[i]);
+                    const f2 rg[4] = {f2{rg01.x, rg01.y}, f2{rg01.z, rg01.w}, f2{rg23.x, rg23.y}, f2{rg23.z, rg23.w}};
+                    const f2 bz[4] = {f2{bz01.x, bz01.y}, f2{bz01.z, bz01.w}, f2{bz23.x, bz23.y}, f2{bz23.z, bz23.w}};
+                    const uint32_t posk[4] = {vp.x, vp.y, vp.z, vp.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool v = ok[e] && !done;
+                        const float test_T = T * om[e];
+                        const bool stop = v && test_T < 0.0001f;
+                        const bool contrib = v && !stop;
+                        done = done || stop;
+                        const float w = contrib ? al[e] * T : 0.0f;
+                        const f2 w2 = f2{w, w};
+                        C01 = C01 + rg[e] * w2;
+                        if (WITH_DEPTH) C2D = C2D + bz[e] * w2;
+                        else C2D.x = C2D.x + bz[e].x * w;
+                        T = contrib ? test_T : T;
+                        last = contrib ? posk[e] : last;
+                    }
+                }
+            }
+        } else {
+            unsigned long long am = act;
+            while (am) {
+                const int pl = __builtin_ctzll(am);
+                am &= am - 1;
+                const float ppx = rl(pxf, pl), ppy = rl(pyf, pl);
+                const float dx = ea.x - ppx, dy = ea.y - ppy;
+                const float power = power2(ea.z, ea.w, eb.x, dx, dy);
+                const float alpha = fminf(0.99f, eb.y * __builtin_amdgcn_exp2f(power));
+                unsigned long long vm = __ballot(hit && !(power > 0.0f) && !(alpha < 1.0f / 255.0f));
+                const bool mine = lane == pl;
+                while (vm) {
+                    const int eb_ = __builtin_ctzll(vm);
+                    vm &= vm - 1;
+                    const float a_s = rl(alpha, eb_);
+                    const float test_T = T * (1.0f - a_s);
+                    const bool stop = mine && test_T < 0.0001f;
+                    const bool contrib = mine && !stop;
+                    if (!T_ONLY) {
+                        const float w = contrib ? a_s * T : 0.0f;
+                        C01.x += rl(eb.z, eb_) * w;
+                        C01.y += rl(eb.w, eb_) * w;
+                        C2D.x += rl(ec, eb_) * w;
+                        if (WITH_DEPTH) C2D.y += rl(ez, eb_) * w;
+                        last = contrib ? rel + (uint32_t)eb_ + 1u : last;
+                    }
+                    T = contrib ? test_T : T;
+                    done = done || stop;
+                    if (__ballot(stop) != 0ull) break;
+                }
+            }
+        }
+    }
+}
+
 // SPLIT (S360_FLAG_SPLIT_LISTS): the hand-over to segment waves is compiled in; false: the kernel only REPORTS quadrants that would
 // have handed over (one store into the caller's host-visible mirror), so that a caller which splits adaptively — the Python layer:
 // the flag is set for the calls that follow a report — pays nothing for the feature on clouds that never split (the hand-over code
@@ -1405,7 +1580,7 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
                                                       const uint32_t* __restrict__ tile_order, float4* __restrict__ surv,
                                                       uint32_t* __restrict__ surv_count, uint32_t* __restrict__ hdr_loss,
                                                       const SegBufs* __restrict__ sgp, const uint32_t* __restrict__ chunk_start,
-                                                      unsigned long long* __restrict__ cand_mirror) {
+                                                      unsigned long long* __restrict__ cand_mirror, int nt) {
 #ifdef S360_DBG_TIMING
     const long long t_begin = wall_clock64();
 #endif
@@ -1430,6 +1605,39 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
         // until the backward has reduced them, loss / clipped MSE read as NaN — a premature read (a NaN guard, a logger, Lightning's
         // returned loss) is then visibly wrong instead of uninitialised memory
         for (int i = 0; i <= kp.V; ++i) ep.loss_out[i] = __uint_as_float(0x7FC00000u);
+    }
+    if (SPLIT && blockIdx.x >= (uint32_t)nt) {
+        // ---- phase-1 workers of the split lists (the workgroups behind the nt tile workgroups: they start as the first tiles retire
+        // and work under the tail of this kernel, which a split cloud's 1 024-entry heads draw out to ~140 us at falling occupancy).
+        // For every list that MAY split (whether a quadrant does is decided by its head, still running) and every segment k >= SEG_K0:
+        // the segment's own transmittance per pixel, T_k = prod (1 - alpha) over its accepted entries from T = 1 — the alpha
+        // evaluations of the composite without its colour arithmetic; a pixel whose own product trips the 1e-4 test is finished
+        // inside the segment whatever came before: T_k := 0.  k_render_tail (next launch) forms every pixel's true incoming
+        // transmittance from these.  Speculative for the quadrants that end up not splitting: bounded (T-only, and only lists
+        // beyond SEG_HEAD + SEG_MIN_REST), and this variant of the kernel only runs on clouds that split (adaptive flag).
+        const SegBufs sg = *sgp;
+        const int pwave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        const WaveLds L{s_x[pwave], s_y[pwave], s_a[pwave], s_b[pwave], s_c[pwave], s_o[pwave], s_rg[pwave], s_bz[pwave], s_pos[pwave]};
+        const uint32_t nunits = min((uint32_t)(SEG_PER_CHUNK * chunk_start[nt]), sg.n_slots);
+        for (uint32_t u = blockIdx.x - (uint32_t)nt; u < nunits; u += gridDim.x - (uint32_t)nt) {
+            const ChunkUnit cu = chunk_unit(tile_start, chunk_start, nt, kp.cap, u / SEG_PER_CHUNK);
+            const uint32_t k = cu.k * SEG_PER_CHUNK + (u % SEG_PER_CHUNK);
+            if (!cu.valid || k < SEG_K0 || k * SEG_LEN >= cu.n || cu.n < SEG_HEAD + SEG_MIN_REST) continue;   // block-uniform
+            const int t1 = (int)cu.t, v1 = t1 / kp.T, rem1 = t1 - v1 * kp.T;
+            const int ty1 = rem1 / kp.gx, tx1 = rem1 - ty1 * kp.gx;
+            const int px1 = tx1 * 16 + sub_ox(pwave) + lane % SUB_W, py1 = ty1 * 16 + sub_oy(pwave) + lane / SUB_W;
+            const bool inside1 = px1 < kp.W && py1 < kp.H;
+            float T1 = 1.0f;
+            f2 c01 = f2{0.f, 0.f}, c2d = f2{0.f, 0.f};
+            uint32_t last1 = 0, cnt1 = 0;
+            bool done1 = !inside1;
+            const uint32_t b0 = cu.s + k * SEG_LEN, b1 = min(b0 + SEG_LEN, cu.s + cu.n);
+            composite_segment<WITH_DEPTH, true>(list, recA, depths, cu.s, b0, b1, (float)px1, (float)py1, (float)(tx1 * 16 + sub_ox(pwave)),
+                                                (float)(ty1 * 16 + sub_oy(pwave)), lane, L, 0.f, 0.f, 0.f, depth_mode, T1, c01, c2d, last1, done1,
+                                                nullptr, cnt1);
+            sg.part_t[((size_t)u * 4 + pwave) * 64 + lane] = (done1 && inside1) ? 0.0f : T1;
+        }
+        return;
     }
     const int t = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;
     // (s_setprio by launch-order quartile — the longest lists take the SIMD's issue slots first, all 6 144 waves being resident at
@@ -1737,198 +1945,23 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
 
 // ------------------------------------------------------------------------------ split lists: segment waves + combine
 // S360_FLAG_SPLIT_LISTS, second launch of the composite.  k_render left, for every split (tile, quadrant), the exact per-pixel state
-// after SEG_HEAD entries.  The rest of the list, [SEG_HEAD, n), is cut into segments of SEG_LEN entries; ONE launch of persistent
-// workgroups takes (phase, segment) work units in ticket order — all phase-1 units first:
-//   phase 1  one wave per (tile, quadrant, segment k): the TRANSMITTANCE of the segment alone, T_k = prod (1 - alpha) over its
-//            accepted entries, per pixel, from T = 1 (a pixel whose own product trips the 1e-4 test is finished inside the segment
-//            whatever came before: T_k := 0) — the alpha evaluations of the composite without its colour arithmetic;
-//   phase 2  (after every phase-1 unit of the quadrant has delivered: only ever a wait for LOWER tickets, which running workgroups
-//            hold, so the schedule cannot deadlock whatever share of the grid is resident — k_merge_all's argument) the same wave
-//            composites its segment with k_render's sequential rule from the pixel's true incoming transmittance
+// after SEG_HEAD entries and, from its phase-1 workers, the own transmittance T_k of every SEG_LEN-entry segment k of the rest of the
+// list (per pixel, from T = 1; 0 where the pixel stops inside the segment).  Here every wave takes (tile, quadrant, segment) work
+// items from the dense list k_render queued:
+//   phase 2  the wave composites its segment with k_render's sequential rule from the pixel's true incoming transmittance
 //            T_in(k) = T_head * T_K0 * ... * T_(k-1)  (a fixed left-to-right product); a pixel with T_in(k) < 1e-4 has stopped in an
 //            earlier segment and is skipped.  It appends the segment's survivor records (training calls) and delivers its colour
-//            contribution, transmittance behind it and last contributor;
-//   combine  the wave that delivers last adds the contributions in list order, writes the pixels exactly like k_render's epilogue,
-//            and leaves per segment what the backward starts from: transmittance behind it, colour accumulated behind it.
+//            contribution, the transmittance behind it and its last contributor;
+//   combine  the wave that delivers last for a quadrant adds the contributions in list order, writes the pixels exactly like
+//            k_render's epilogue, and leaves per segment what the backward starts from: transmittance behind it, colour accumulated
+//            behind it.
 // Every (pixel, entry) pair is evaluated with k_render's arithmetic and k_render's stop rule, in list order, from a transmittance
 // that differs from the sequential product only by floating-point association (T_in is a product of segment products): images
 // within 1e-6 of the unsplit composite, stop decisions identical except where a product lands within rounding of 1e-4.
-// Exchanges between workgroups of the launch use device-coherent accesses, drained (s_waitcnt vmcnt(0)) before ONE agent-scope
-// counter is bumped — the pattern of k_merge_all.
-__device__ __forceinline__ void st_dev32(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ uint32_t ld_dev32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_devf(float* p, float v) { st_dev32(reinterpret_cast<uint32_t*>(p), __float_as_uint(v)); }
-__device__ __forceinline__ float ld_devf(const float* p) { return __uint_as_float(ld_dev32(reinterpret_cast<const uint32_t*>(p))); }
-
-struct WaveLds {   // one wave's slices of the compaction arrays (see k_render)
-    float *x, *y, *a, *b, *c, *o;
-    float2 *rg, *bz;
-    uint32_t* pos;
-};
-
-// k_render's chunk loop over list positions [b0, b1) of the tile that starts at `start` (b0 - start a multiple of 64), on the
-// running per-pixel state (T, C01, C2D, last, done); sv != null: survivor records appended at sv[3 (scount + rank)].
-// T_ONLY: transmittance and stop logic alone (phase 1).
-template <bool WITH_DEPTH, bool T_ONLY>
-__device__ __forceinline__ void composite_segment(const uint32_t* __restrict__ list, const float4* __restrict__ recA, const float* __restrict__ depths,
-                                                  uint32_t start, uint32_t b0, uint32_t b1, float pxf, float pyf, float x0, float ys0, int lane,
-                                                  const WaveLds& L, float inv_scale, float v_near, float v_far, int depth_mode, float& T, f2& C01,
-                                                  f2& C2D, uint32_t& last, bool& done, float4* sv, uint32_t& scount) {
-    uint32_t p_n1 = 0, p_n2 = 0;
-    if (b0 + lane < b1) p_n1 = list[b0 + lane];
-    if (b0 + 64 + lane < b1) p_n2 = list[b0 + 64 + lane];
-    float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na, nc = na;
-    float nz = 0.f;
-    if (b0 + lane < b1) {
-        na = recA[3 * (size_t)(p_n1)];
-        nb = recA[3 * (size_t)(p_n1) + 1];
-        nc = recA[3 * (size_t)(p_n1) + 2];
-        if (WITH_DEPTH && !T_ONLY) nz = depths[p_n1];
-    }
-    for (uint32_t b = b0; b < b1; b += 64) {
-        const unsigned long long act = __ballot(!done);
-        if (act == 0ull) break;
-        const float4 ea = na, eb = nb;
-        float ez = 0.f;
-        if (WITH_DEPTH && !T_ONLY) ez = depth_value(nz * inv_scale, v_near, v_far, depth_mode);
-        const float ec = nc.x, erad = nc.y, eka = nc.z, ekb = nc.w;
-        const bool ev = b + lane < b1;
-        const uint32_t epair = p_n1;
-        p_n1 = p_n2;
-        if (b + 64 + lane < b1) {
-            na = recA[3 * (size_t)(p_n1)];
-            nb = recA[3 * (size_t)(p_n1) + 1];
-            nc = recA[3 * (size_t)(p_n1) + 2];
-            if (WITH_DEPTH && !T_ONLY) nz = depths[p_n1];
-        }
-        if (b + 128 + lane < b1) p_n2 = list[b + 128 + lane];
-        const bool hit = ev && quadrant_hit(ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, eka, ekb, x0, ys0);
-        const unsigned long long m = __ballot(hit);
-        if (m == 0ull) continue;
-        const uint32_t rel = b - start;  // list position of this chunk's lane 0
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        if (!T_ONLY && sv && hit) {
-            float4* o = sv + 3 * (size_t)(scount + rank);
-            o[0] = ea;
-            o[1] = eb;
-            o[2] = make_float4(ec, erad, __uint_as_float(rel + (uint32_t)lane), __uint_as_float(epair));
-        }
-        scount += (uint32_t)__popcll(m);
-        if (__popcll(act) > SPARSE_PIXELS) {
-            const uint32_t cnt = (uint32_t)__popcll(m);
-            if (hit) {
-                L.x[rank] = ea.x; L.y[rank] = ea.y; L.a[rank] = ea.z; L.b[rank] = ea.w;
-                L.c[rank] = eb.x; L.o[rank] = eb.y;
-                if (!T_ONLY) {
-                    L.rg[rank] = make_float2(eb.z, eb.w);
-                    L.bz[rank] = make_float2(ec, ez);
-                    L.pos[rank] = rel + (uint32_t)lane + 1u;
-                }
-            }
-            if (lane < 3) {  // null records: opacity 0
-                L.x[cnt + lane] = 0.f; L.y[cnt + lane] = 0.f; L.a[cnt + lane] = 0.f; L.b[cnt + lane] = 0.f;
-                L.c[cnt + lane] = 0.f; L.o[cnt + lane] = 0.f;
-                if (!T_ONLY) {
-                    L.rg[cnt + lane] = make_float2(0.f, 0.f);
-                    L.bz[cnt + lane] = make_float2(0.f, 0.f);
-                    L.pos[cnt + lane] = 0u;
-                }
-            }
-            const f2 pxf2 = f2{pxf, pxf}, pyf2 = f2{pyf, pyf};
-            for (uint32_t i = 0; i < cnt; i += 4) {
-                const float4 vx = *reinterpret_cast<const float4*>(&L.x[i]), vy = *reinterpret_cast<const float4*>(&L.y[i]),
-                             va = *reinterpret_cast<const float4*>(&L.a[i]), vb = *reinterpret_cast<const float4*>(&L.b[i]),
-                             vc = *reinterpret_cast<const float4*>(&L.c[i]), vo = *reinterpret_cast<const float4*>(&L.o[i]);
-                float al[4], om[4];
-                bool ok[4];
-                bool any_ok = false;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {  // entries 2j, 2j+1 as one register pair: k_render's operations in k_render's order
-                    const f2 X = j ? f2{vx.z, vx.w} : f2{vx.x, vx.y}, Y = j ? f2{vy.z, vy.w} : f2{vy.x, vy.y};
-                    const f2 A = j ? f2{va.z, va.w} : f2{va.x, va.y}, B = j ? f2{vb.z, vb.w} : f2{vb.x, vb.y};
-                    const f2 Cc = j ? f2{vc.z, vc.w} : f2{vc.x, vc.y}, O = j ? f2{vo.z, vo.w} : f2{vo.x, vo.y};
-                    const f2 dx = X - pxf2, dy = Y - pyf2;
-                    const f2 t = pk_fma(B, dy, A * dx);
-                    const f2 pw = pk_fma(t, dx, (Cc * dy) * dy);
-                    const f2 og = O * f2{__builtin_amdgcn_exp2f(pw.x), __builtin_amdgcn_exp2f(pw.y)};
-                    al[2 * j] = fminf(0.99f, og.x);
-                    al[2 * j + 1] = fminf(0.99f, og.y);
-                    const f2 o2 = f2{1.0f, 1.0f} - f2{al[2 * j], al[2 * j + 1]};
-                    om[2 * j] = o2.x;
-                    om[2 * j + 1] = o2.y;
-                    ok[2 * j] = !done && !(pw.x > 0.0f) && !(al[2 * j] < 1.0f / 255.0f);
-                    ok[2 * j + 1] = !done && !(pw.y > 0.0f) && !(al[2 * j + 1] < 1.0f / 255.0f);
-                    any_ok = any_ok || ok[2 * j] || ok[2 * j + 1];
-                }
-                if (__ballot(any_ok) == 0ull) continue;  // wave-uniform
-                if (T_ONLY) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const bool v = ok[e] && !done;
-                        const float test_T = T * om[e];
-                        const bool stop = v && test_T < 0.0001f;
-                        done = done || stop;
-                        T = (v && !stop) ? test_T : T;
-                    }
-                } else {
-                    const float4 rg01 = *reinterpret_cast<const float4*>(&L.rg[i]), rg23 = *reinterpret_cast<const float4*>(&L.rg[i + 2]);
-                    const float4 bz01 = *reinterpret_cast<const float4*>(&L.bz[i]), bz23 = *reinterpret_cast<const float4*>(&L.bz[i + 2]);
-                    const uint4 vp = *reinterpret_cast<const uint4*>(&L.pos[i]);
-                    const f2 rg[4] = {f2{rg01.x, rg01.y}, f2{rg01.z, rg01.w}, f2{rg23.x, rg23.y}, f2{rg23.z, rg23.w}};
-                    const f2 bz[4] = {f2{bz01.x, bz01.y}, f2{bz01.z, bz01.w}, f2{bz23.x, bz23.y}, f2{bz23.z, bz23.w}};
-                    const uint32_t posk[4] = {vp.x, vp.y, vp.z, vp.w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const bool v = ok[e] && !done;
-                        const float test_T = T * om[e];
-                        const bool stop = v && test_T < 0.0001f;
-                        const bool contrib = v && !stop;
-                        done = done || stop;
-                        const float w = contrib ? al[e] * T : 0.0f;
-                        const f2 w2 = f2{w, w};
-                        C01 = C01 + rg[e] * w2;
-                        if (WITH_DEPTH) C2D = C2D + bz[e] * w2;
-                        else C2D.x = C2D.x + bz[e].x * w;
-                        T = contrib ? test_T : T;
-                        last = contrib ? posk[e] : last;
-                    }
-                }
-            }
-        } else {
-            unsigned long long am = act;
-            while (am) {
-                const int pl = __builtin_ctzll(am);
-                am &= am - 1;
-                const float ppx = rl(pxf, pl), ppy = rl(pyf, pl);
-                const float dx = ea.x - ppx, dy = ea.y - ppy;
-                const float power = power2(ea.z, ea.w, eb.x, dx, dy);
-                const float alpha = fminf(0.99f, eb.y * __builtin_amdgcn_exp2f(power));
-                unsigned long long vm = __ballot(hit && !(power > 0.0f) && !(alpha < 1.0f / 255.0f));
-                const bool mine = lane == pl;
-                while (vm) {
-                    const int eb_ = __builtin_ctzll(vm);
-                    vm &= vm - 1;
-                    const float a_s = rl(alpha, eb_);
-                    const float test_T = T * (1.0f - a_s);
-                    const bool stop = mine && test_T < 0.0001f;
-                    const bool contrib = mine && !stop;
-                    if (!T_ONLY) {
-                        const float w = contrib ? a_s * T : 0.0f;
-                        C01.x += rl(eb.z, eb_) * w;
-                        C01.y += rl(eb.w, eb_) * w;
-                        C2D.x += rl(ec, eb_) * w;
-                        if (WITH_DEPTH) C2D.y += rl(ez, eb_) * w;
-                        last = contrib ? rel + (uint32_t)eb_ + 1u : last;
-                    }
-                    T = contrib ? test_T : T;
-                    done = done || stop;
-                    if (__ballot(stop) != 0ull) break;
-                }
-            }
-        }
-    }
-}
-
+// No wave ever waits for another: the phase-1 results come from the previous launch, and the combine is done by whoever arrives last
+// (device-coherent stores, drained with s_waitcnt vmcnt(0), then ONE agent-scope counter — the pattern of k_merge_all).  Tickets and
+// arrival counts are broadcast BY VALUE (__shfl), never v_readfirstlane: a build whose compiler treated the ticket loop as divergent
+// left the lanes that are not lane 0 with ticket 0 for ever and hung the GPU.
 #ifndef S360_TAIL_GRID
 #define S360_TAIL_GRID 1024
 #endif
@@ -1953,14 +1986,14 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(S360
     const uint32_t nwork = sg.header[S360_HDR_SEGWORK];       // (tile, quadrant, segment) items k_render queued
     uint32_t* const queue = sg.seg_arrive2 + (size_t)nt * 4;   // the ticket counter (cleared with the arrival counters)
     uint32_t guard = 0;
-    for (;;) {   // every WAVE takes its own tickets: [0, nwork) = phase 1 of every item, [nwork, 2 nwork) = phase 2
+    for (;;) {   // every WAVE takes its own tickets: one per work item
         uint32_t tk = 0;
         if (lane == 0) tk = __hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // broadcast BY VALUE to every lane (not v_readfirstlane: were the compiler to treat this loop as divergent, the lanes that
         // are not lane 0 would carry ticket 0 for ever — seen: a build whose loop structure did exactly that hung the GPU)
         tk = (uint32_t)__shfl((int)tk, 0);
-        if (tk >= 2u * nwork) break;
-        const uint32_t phase = tk >= nwork ? 1u : 0u, wi = tk - phase * nwork;
+        if (tk >= nwork) break;
+        const uint32_t wi = tk;
 #ifdef S360_DBG_TIMING
         const long long t_begin = wall_clock64();
 #endif
@@ -1996,50 +2029,14 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(S360
         const uint32_t b0 = start + k * SEG_LEN, b1 = min(b0 + SEG_LEN, end);
         const size_t slot0 = u - k;                       // slot of segment 0 of this tile (= SEG_PER_CHUNK * chunk_start[t])
         const size_t li0 = (slot0 * 4 + wave) * 64 + lane, li = ((size_t)u * 4 + wave) * 64 + lane;
-        if (phase == 0u) {
-            // ---- phase 1: the segment's own transmittance per pixel
-            float T = 1.0f;
-            f2 c01 = f2{0.f, 0.f}, c2d = f2{0.f, 0.f};
-            uint32_t last = 0, cnt = 0;
-            bool done = !inside;
-            composite_segment<WITH_DEPTH, true>(list, recA, depths, start, b0, b1, pxf, pyf, x0, ys0, lane, L, inv_scale, v_near, v_far, depth_mode, T,
-                                                c01, c2d, last, done, nullptr, cnt);
-            st_devf(sg.part_t + li, (done && inside) ? 0.0f : T);   // stopped on its own: finished inside this segment at the latest
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_fetch_add(&sg.seg_arrive[4 * t + wave], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#ifdef S360_DBG_TIMING
-            if (lane == 0) {
-                const size_t di = 4 * ((size_t)4 * nt + wi);
-                dbg[di] = (uint32_t)t_begin;
-                dbg[di + 1] = (uint32_t)(wall_clock64() - t_begin);
-            }
-#endif
-            continue;
-        }
-        // ---- phase 2: wait for the quadrant's phase-1 results (lower tickets, held by running workgroups), then the segment itself
-        if (lane == 0) {
-            // bounded (~1 s): a logic error must surface as an error word in the header (header[7], checked by the tests), never as a hung GPU
-            uint32_t spins = 0;
-            while (__hip_atomic_load(&sg.seg_arrive[4 * t + wave], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < K - SEG_K0) {
-                __builtin_amdgcn_s_sleep(8);
-                if (++spins > (1u << 22)) {
-                    if (atomicAdd(&sg.header[7], 1u) == 0u) {
-                        sg.header[8] = (uint32_t)t; sg.header[9] = (k << 2) | (uint32_t)wave; sg.header[10] = K - SEG_K0;
-                        sg.header[11] = __hip_atomic_load(&sg.seg_arrive[4 * t + wave], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        sg.header[12] = tk; sg.header[13] = nwork;
-                    }
-                    break;
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
+        // ---- the segment itself, from the pixel's true incoming transmittance (phase-1 results: k_render's workers, the previous launch)
         float T;
         bool head_done;
         {   // the head's state (written by k_render: the previous launch) and the fixed left-to-right product of the segments in front
             const uint32_t l = sg.part_l[li0];
             head_done = (l >> 31) != 0u || !inside;
             T = sg.part_t[li0];
-            for (uint32_t kk = SEG_K0; kk < k; ++kk) T = T * ld_devf(sg.part_t + ((slot0 + kk) * 4 + wave) * 64 + lane);
+            for (uint32_t kk = SEG_K0; kk < k; ++kk) T = T * sg.part_t[((slot0 + kk) * 4 + wave) * 64 + lane];
         }
         {
             f2 C01 = f2{0.f, 0.f}, C2D = f2{0.f, 0.f};
@@ -2085,7 +2082,7 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(S360
                 const float c0 = ld_devf(pc), c1 = ld_devf(pc + 1), c2 = ld_devf(pc + 2), c3 = ld_devf(pc + 3);
                 const float te = ld_devf(sg.part_e + lik);
                 const uint32_t pl = ld_dev32(sg.part_l + lik);
-                Tin = Tin * ld_devf(sg.part_t + lik);
+                Tin = Tin * sg.part_t[lik];
                 f2 D01 = f2{0.f, 0.f}, D2D = f2{0.f, 0.f};
                 if (live) {
                     D01 = f2{c0, c1}; D2D = f2{c2, c3};
@@ -2445,15 +2442,16 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
                    (float4*)(ws + L.seg_c), (float*)(ws + L.seg_t), (uint32_t*)(ws + L.seg_cnt), (uint2*)(ws + L.seg_info), header};
         unsigned long long* cand = prm->header_mirror ? (unsigned long long*)prm->header_mirror + 1 : nullptr;   // word 1 of the mirror
         const SegBufs* sgp = split ? (const SegBufs*)(header + S360_HDR_SEGBUFS) : (const SegBufs*)nullptr;
+        const unsigned p1grid = (unsigned)min((size_t)1024, seg_slots_of(prm));   // phase-1 workers of the split lists, behind the tile workgroups
 #define S360_LAUNCH_RENDER(WD, SP)                                                                                                         \
-    hipLaunchKernelGGL((k_render<WD, SP>), rgrid, rblock, 0, st, kp, views, tile_start, list, recA, recB, recC, images, final_T, n_contrib,      \
+    hipLaunchKernelGGL((k_render<WD, SP>), SP ? dim3(nt + p1grid) : rgrid, rblock, 0, st, kp, views, tile_start, list, recA, recB, recC, images, final_T, n_contrib,      \
                        tile_max_contrib, strip_last, dbg, depths, depth_maps, depth_mode, ep, kp.P > 0 ? tile_order : (const uint32_t*)nullptr, \
-                       surv, surv_count, hdr_loss, sgp, chunk_start, cand)
+                       surv, surv_count, hdr_loss, sgp, chunk_start, cand, nt)
         if (depth_maps) { if (split) S360_LAUNCH_RENDER(true, true); else S360_LAUNCH_RENDER(true, false); }
         else { if (split) S360_LAUNCH_RENDER(false, true); else S360_LAUNCH_RENDER(false, false); }
 #undef S360_LAUNCH_RENDER
         if (split) {
-            const unsigned tgrid = (unsigned)min((size_t)S360_TAIL_GRID, 2 * seg_slots_of(prm));
+            const unsigned tgrid = (unsigned)min((size_t)S360_TAIL_GRID, seg_slots_of(prm));
             if (depth_maps)
                 hipLaunchKernelGGL(k_render_tail<true>, dim3(tgrid), rblock, 0, st, kp, views, tile_start, list, recA, images, final_T, n_contrib,
                                    tile_max_contrib, strip_last, depths, depth_maps, depth_mode, ep, surv, surv_count, sg, nt, dbg);
