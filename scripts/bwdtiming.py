@@ -14,6 +14,7 @@ ext, K, near, far = decoder.cube_cameras(torch.eye(4, device=dev), 0.1, 10.0)
 for _ in range(3):
     faces = decoder.render_views_fused(ext, K, near, far, (256, 256), torch.zeros(3, device=dev), *g, check="lazy", shared_campos=True)
     st = rasterizer.last_state()
+    st._arr(st.layout.keys_alt, 4 * (1536 * 4 + 65536), torch.int32).zero_()     # (the forward's own timing records live there)
     ((faces - 0.5) ** 2).mean().backward()
 torch.cuda.synchronize()
 nwork = int(st.header()[6].item()) if (st.prm.flags & 512) else 0      # segment units of split quadrants follow the (tile, quadrant) units

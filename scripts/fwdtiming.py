@@ -43,12 +43,12 @@ print("running waves at t:", [(round(x), int(((start <= x) & (end > x)).sum())) 
 if nseg:
     nwork = int(st.header()[6].item())
     d = st._arr(st.layout.keys_alt, 4 * (nu + nwork), torch.int32).cpu().numpy().astype(np.int64) & 0xFFFFFFFF
-    s0, p1, p2, tag = d[4 * nu::4], d[4 * nu + 1::4] / 100.0, d[4 * nu + 2::4] / 100.0, d[4 * nu + 3::4]
+    p2, tag = d[4 * nu + 2::4] / 100.0, d[4 * nu + 3::4]
     if nwork:
-        sst = ((s0 - origin) & 0xFFFFFFFF) / 100.0          # phase-1 start relative to k_render's first wave
         comb = (tag >> 31) & 1
-        print("k_render_tail: segment work items", nwork, "phase-1 start min/max", round(sst.min(), 1), round(sst.max(), 1), "phase-1 end max", round((sst + p1).max(), 1),
-              "| phase 1 mean/max us", round(p1.mean(), 1), round(p1.max(), 1), "| phase 2 (incl. wait) mean/max", round(p2.mean(), 1), round(p2.max(), 1),
-              "| combiners", int(comb.sum()), "phase 2 + combine mean/max", round(p2[comb == 1].mean(), 1), round(p2[comb == 1].max(), 1))
-        for i in np.argsort(-p2)[:8]:
-            print("  item tile", int((tag[i] >> 12) & 0x7FFFF), "k", int((tag[i] >> 2) & 0x3FF), "q", int(tag[i] & 3), "p1 start", round(sst[i], 1), "p1", round(p1[i], 1), "p2", round(p2[i], 1), "combiner", int(comb[i]))
+        print("k_render_tail (second launch; k_render's span above does not include its phase-1 worker workgroups): segment work items", nwork,
+              "| segment composite mean/max us", round(p2[comb == 0].mean(), 1), round(p2[comb == 0].max(), 1),
+              "| combining waves", int(comb.sum()), "segment + combine mean/max", round(p2[comb == 1].mean(), 1), round(p2[comb == 1].max(), 1),
+              "| longest item / mean item:", round(p2.max() / p2.mean(), 2))
+        for i in np.argsort(-p2)[:6]:
+            print("  item tile", int((tag[i] >> 12) & 0x7FFFF), "k", int((tag[i] >> 2) & 0x3FF), "q", int(tag[i] & 3), "us", round(p2[i], 1), "combined", int(comb[i]))

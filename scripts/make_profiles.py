@@ -59,7 +59,9 @@ for leg in ("rccl", "adapter", "dropin"):      # kernel-stat tables of the side 
             w = csv.writer(f)
             w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage"])
             for r in rr[:30]:
-                w.writerow([r["Name"].split("(")[0][:100], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"]])
+                nm = r["Name"]
+                nm = (nm[:nm.index("(", 6)] if nm.startswith("void (") and "(" in nm[6:] else nm.split("(")[0])[:110]
+                w.writerow([nm, r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"]])
 calib = R / "gpurun_out" / "calib" / "calibration.json"
 if calib.exists():
     shutil.copy(calib, P / "fetch_write_calibration.json")

@@ -32,8 +32,11 @@ def main():
     torch.cuda.set_device(0)
     dist.init_process_group(backend="nccl", rank=0, world_size=1)
     assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
-    from splatter360_amd import distributed as D
+    from splatter360_amd import distributed as D, rasterizer
     from test_gpu_factored_sync import POSITIONS, _cloud, _render_backward
+    # the comparisons below are bit-for-bit between calls: keep every call in ONE compositing mode (the adaptive default would run the
+    # first call of a cloud with long unsaturated lists sequentially and split the following ones: equal to 1e-7, not to the bit)
+    rasterizer.SPLIT_LONG_LISTS = False
     dev = torch.device("cuda:0")
     w = int(os.environ.get("S360_RCCL_TEST_W", "128"))
     ps = _cloud(dev, w=w)
