@@ -337,7 +337,6 @@ __global__ __launch_bounds__(SHE3_G * 3) void k_raw_eval(KParams kp, const S360V
                                                         float* __restrict__ sh_jac, uint32_t* __restrict__ zero_ptr, int zero_words) {
     __shared__ __attribute__((aligned(16))) float s_raw[7 * SHE3_G * 3 * 4];   // 64 records x 82 floats = 5 248 floats (+ pad to 7 rounds of 192 float4)
     __shared__ float s_D[2 * 628];        // the rotation matrices of the (at most two) context views of this workgroup's Gaussians
-    __shared__ float4 s_mean[SHE3_G];     // (scaled mean - campos direction inputs): mean xyz
     __shared__ float s_rgb[SHE3_G * 3];
     __shared__ float s_G[9 * SHE3_G];
     __shared__ float4 s_dir[SHE3_G];
@@ -371,59 +370,33 @@ __global__ __launch_bounds__(SHE3_G * 3) void k_raw_eval(KParams kp, const S360V
         if (!one_view)
             for (int i = tid; i < 625; i += SHE3_G * 3) s_D[628 + i] = rin.sh_rot[(size_t)v_last * 625 + i];
     }
-    __syncthreads();
+    // Every wave un-projects its Gaussian's mean itself (~150 instructions, in flight with the staging loads above): letting ONE wave
+    // do the whole geometry in front of a barrier left the other two idle for longer than that (145 us for this kernel); the
+    // covariance chain rides on wave 1 and the raw-geometry copy on wave 2, both behind their colour work.
     const int d = tid >> 6, l = tid & 63;
     const int g = g0 + l;
-    if (d == 0 && g < kp.P) {
-        // ---- geometry: the adapter tail's own expressions (k_adapter_fwd)
+    const S360View& vw = views[0];
+    const float sc = vw.scale;
+    float x = 0.f, y = 0.f, z = 1.f, inv = 0.f, depth = 0.f;
+    const float* E = rin.extrinsics;
+    if (g < kp.P) {
         const int v = g / rin.Gv, gi = g - v * rin.Gv;
-        const float* E = rin.extrinsics + 16 * v;
-        const float* rw = s_raw + l * RAW_C;
-        const float depth = rin.depths[g];
-        const float px = 1.0f / (float)max(rin.W, rin.H);
-        float sc3[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) sc3[k] = ((rin.smin + (rin.smax - rin.smin) * sigmoidf(rw[k])) * depth) * px;
-        QuatGeom qg;
-        const float qr[4] = {rw[3], rw[4], rw[5], rw[6]};
-        quat_geom(qr, rin.eps, qg);
-        float M[3][3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int b = 0; b < 3; ++b) M[a][b] = E[4 * a] * qg.R[0][b] + E[4 * a + 1] * qg.R[1][b] + E[4 * a + 2] * qg.R[2][b];
-        const float s2[3] = {sc3[0] * sc3[0], sc3[1] * sc3[1], sc3[2] * sc3[2]};
-        float S[3][3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int b = a; b < 3; ++b) S[a][b] = S[b][a] = M[a][0] * s2[0] * M[b][0] + M[a][1] * s2[1] * M[b][1] + M[a][2] * s2[2] * M[b][2];
-        float* oc = rin.cov6_out + 6 * (size_t)g;
-        oc[0] = S[0][0]; oc[1] = S[0][1]; oc[2] = S[0][2]; oc[3] = S[1][1]; oc[4] = S[1][2]; oc[5] = S[2][2];
+        E = rin.extrinsics + 16 * v;
+        depth = rin.depths[g];
         float dr[3];
         erp_dir(gi / rin.per_ray, rin.H, rin.W, rin.conv, dr);
         const float p[3] = {dr[0] * depth, dr[1] * depth, dr[2] * depth};
         float mn[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) mn[a] = (E[4 * a] * p[0] + E[4 * a + 1] * p[1] + E[4 * a + 2] * p[2]) + E[4 * a + 3];
-        rin.means_out[3 * (size_t)g] = mn[0]; rin.means_out[3 * (size_t)g + 1] = mn[1]; rin.means_out[3 * (size_t)g + 2] = mn[2];
-        s_mean[l] = make_float4(mn[0], mn[1], mn[2], 0.f);
-        if (rin.geo7) {
-            float* o7 = rin.geo7 + 7 * (size_t)g;
-#pragma unroll
-            for (int k = 0; k < 7; ++k) o7[k] = rw[k];
+        if (d == 0) {
+            rin.means_out[3 * (size_t)g] = mn[0]; rin.means_out[3 * (size_t)g + 1] = mn[1]; rin.means_out[3 * (size_t)g + 2] = mn[2];
         }
-    }
-    __syncthreads();
-    const S360View& vw = views[0];
-    const float sc = vw.scale;
-    float x = 0.f, y = 0.f, z = 1.f, inv = 0.f;
-    if (g < kp.P) {
-        const float4 mn = s_mean[l];
-        const float dx = mn.x * sc - vw.campos[0], dy = mn.y * sc - vw.campos[1], dz = mn.z * sc - vw.campos[2];
+        const float dx = mn[0] * sc - vw.campos[0], dy = mn[1] * sc - vw.campos[1], dz = mn[2] * sc - vw.campos[2];
         inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
         x = dx * inv; y = dy * inv; z = dz * inv;
     }
+    __syncthreads();      // the staged records and the rotation matrices
     // (the rotation matrix is read from LDS as broadcasts; a workgroup straddling a view boundary — only when a view's Gaussian
     // count is not a multiple of 64 — takes its views one after the other)
     if (g < kp.P) {
@@ -447,6 +420,36 @@ __global__ __launch_bounds__(SHE3_G * 3) void k_raw_eval(KParams kp, const S360V
             for (int ch = 0; ch < 3; ++ch) s_G[(3 * ch + d) * SHE3_G + l] = G[ch];
             if (d == 0) s_dir[l] = make_float4(x, y, z, sc * inv);
         }
+    }
+    if (d == 1 && g < kp.P) {
+        // ---- covariance: the adapter tail's own expressions (k_adapter_fwd)
+        const float* rw = s_raw + l * RAW_C;
+        const float px = 1.0f / (float)max(rin.W, rin.H);
+        float sc3[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sc3[k] = ((rin.smin + (rin.smax - rin.smin) * sigmoidf(rw[k])) * depth) * px;
+        QuatGeom qg;
+        const float qr[4] = {rw[3], rw[4], rw[5], rw[6]};
+        quat_geom(qr, rin.eps, qg);
+        float M[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) M[a][b] = E[4 * a] * qg.R[0][b] + E[4 * a + 1] * qg.R[1][b] + E[4 * a + 2] * qg.R[2][b];
+        const float s2[3] = {sc3[0] * sc3[0], sc3[1] * sc3[1], sc3[2] * sc3[2]};
+        float S[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = a; b < 3; ++b) S[a][b] = S[b][a] = M[a][0] * s2[0] * M[b][0] + M[a][1] * s2[1] * M[b][1] + M[a][2] * s2[2] * M[b][2];
+        float* oc = rin.cov6_out + 6 * (size_t)g;
+        oc[0] = S[0][0]; oc[1] = S[0][1]; oc[2] = S[0][2]; oc[3] = S[1][1]; oc[4] = S[1][2]; oc[5] = S[2][2];
+    }
+    if (d == 2 && g < kp.P && rin.geo7) {
+        const float* rw = s_raw + l * RAW_C;
+        float* o7 = rin.geo7 + 7 * (size_t)g;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) o7[k] = rw[k];
     }
     __syncthreads();
     if (JAC) {
