@@ -12,17 +12,19 @@ from splatter360_amd import _lib, decoder, rasterizer, synthetic
 dev = torch.device("cuda:0")
 name = sys.argv[1] if len(sys.argv) > 1 else "surface_like"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+FW = 512 if name.endswith("_4m") else 256
 cloud = {"encoder_like": lambda: synthetic.encoder_like_cloud(512, 1024), "surface_like": lambda: synthetic.surface_like_cloud(512, 1024),
+         "surface_like_4m": lambda: synthetic.surface_like_cloud(1024, 2048), "encoder_like_4m": lambda: synthetic.encoder_like_cloud(1024, 2048),
          "uniform": lambda: synthetic.uniform_cloud(1 << 20, seed=0, extent=5.0)}[name]()
 params = [torch.tensor(cloud[k], device=dev) for k in ("means", "covariances", "harmonics", "opacities")]
 ext, K, near, far = decoder.cube_cameras(torch.eye(4, device=dev), 0.1, 10.0)
 bg = torch.zeros(3, device=dev)
-gt = torch.full((6, 3, 256, 256), 0.5, device=dev)
+gt = torch.full((6, 3, FW, FW), 0.5, device=dev)
 
 
 def run(split, lean=True):
     ps = [p.clone().requires_grad_(True) for p in params]
-    faces, fm = decoder.render_views_fused(ext, K, near, far, (256, 256), bg, *ps, shared_campos=True, mse_target=gt, split_lists=split, lean=lean)
+    faces, fm = decoder.render_views_fused(ext, K, near, far, (FW, FW), bg, *ps, shared_campos=True, mse_target=gt, split_lists=split, lean=lean)
     st = rasterizer.last_state()
     fm.loss.backward()
     torch.cuda.synchronize()
@@ -57,6 +59,7 @@ for n, x, y in zip(("means", "cov", "sh", "opac"), a["grads"], b["grads"]):
 print("deterministic:", all(torch.equal(x, y) for x, y in zip([b["img"], b["T"]] + b["grads"], [b2["img"], b2["T"]] + b2["grads"])))
 if b["nsplit"]:
     fl = b["flag"].view(6, -1, 4)
+    print("segment work items", int(rasterizer.last_state().header()[6].item()), "split errors", rasterizer.last_state().split_errors())
     print("split quadrants per face:", [int((fl[f] == 1).sum()) for f in range(6)])
     bad = (a["nc"] != b["nc"]).nonzero()
     print("first n_contrib mismatches (view,y,x):", bad[:5].tolist(), [(int(a["nc"][tuple(i)]), int(b["nc"][tuple(i)])) for i in bad[:5]])

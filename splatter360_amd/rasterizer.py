@@ -186,11 +186,19 @@ SEG_PER_CHUNK = 8           # csrc/s360_device.h: segment slots per sort chunk
 _SPLIT_AGE: dict = {}       # hint key -> calls since the forward last reported a quadrant worth splitting
 
 
-def split_decision(key, mode) -> bool:
+AUTO_SPLIT_MAX_WAVES = 12288     # "auto": only where the (tile, quadrant) waves of a call fill the chip at most twice (6 144 resident waves)
+
+
+def split_decision(key, mode, quadrant_waves: int = 0) -> bool:
     """S360_FLAG_SPLIT_LISTS for the next call of this shape: `mode` itself when it is True / False, else adaptive — on while a
-    call of the last 16 reported (through word 1 of the pinned mirror, a plain host read) a quadrant worth splitting."""
+    call of the last 16 reported (through word 1 of the pinned mirror, a plain host read) a quadrant worth splitting, and only for
+    calls of at most AUTO_SPLIT_MAX_WAVES quadrant waves: the segment work runs in a second launch, i.e. after ALL tile workgroups —
+    at BASELINE configs[4]'s shape (4 M Gaussians, six 512x512 faces: 24 576 waves, four rounds of residency) a long list already
+    overlaps with three rounds of other tiles and splitting measured 837 vs 792 us forward, 567 vs 593 us backward: nothing."""
     if mode is True or mode is False:
         return mode
+    if quadrant_waves > AUTO_SPLIT_MAX_WAVES:
+        return False
     m = _MIRRORS.get(key)
     if m is not None and int(m[1]) != 0:
         m[1] = 0                      # (a report landing right after this clear is seen by the next call: never lost for long)
@@ -393,7 +401,7 @@ class _RasterizeViews(torch.autograd.Function):
             needs_bwd = any(ctx.needs_input_grad[:6])  # (grad mode is off inside Function.forward; this reflects apply-time)
             hkey = _hint_key(m3.device, p, v, int(h), int(w), lean)
             _mirror(hkey)
-            split_lists = split_decision(hkey, split_lists) and not spherical
+            split_lists = split_decision(hkey, split_lists, v * ((int(h) + 15) // 16) * ((int(w) + 15) // 16) * 4) and not spherical
             prm.flags = (_lib.FLAG_SHARED_CAMPOS if (shared_campos or v == 1) else 0) | (
                 _lib.FLAG_COV9 if cov9 else 0) | (_lib.FLAG_SH_CHANNEL_MAJOR if sh_channel_major else 0) | (
                 0 if (needs_bwd or keep_slots) else _lib.FLAG_FORWARD_ONLY) | (
@@ -567,7 +575,7 @@ class _RasterizeRaw(torch.autograd.Function):
             needs_bwd = any(ctx.needs_input_grad[:3])
             hkey = _hint_key(dev, p, v, int(h), int(w), lean)
             _mirror(hkey)
-            split_lists = split_decision(hkey, split_lists)
+            split_lists = split_decision(hkey, split_lists, v * ((int(h) + 15) // 16) * ((int(w) + 15) // 16) * 4)
             prm = _lib.S360Params()
             prm.P, prm.V, prm.H, prm.W, prm.sh_degree, prm.M = p, v, int(h), int(w), 4, 25
             prm.flags = _lib.FLAG_SHARED_CAMPOS | _lib.FLAG_RAW_INPUTS | (0 if needs_bwd else _lib.FLAG_FORWARD_ONLY) | (

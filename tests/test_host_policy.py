@@ -48,3 +48,6 @@ def test_split_flag_is_adaptive_by_default_and_can_be_forced():
     assert R.split_decision(key, "auto") is False
     R._MIRRORS[key][1] = 1
     assert R.split_decision(key, "auto") is True
+    # calls whose (tile, quadrant) waves fill the chip more than twice never split adaptively (second launch = after ALL tiles)
+    R._MIRRORS[key][1] = 1
+    assert R.split_decision(key, "auto", quadrant_waves=24576) is False and R.split_decision(key, True, quadrant_waves=24576) is True
