@@ -492,6 +492,7 @@ def main():
                        ", RCCL all-reduce of Gaussian grads"),
                    "num_rendered": L, "num_rendered_upstream_lists": L_upstream, "lean_over_upstream": L / max(L_upstream, 1),
                    "visible_pairs": visible_pairs, "split_lists": a.split_lists, "split_flag_set_in_timed_steps": bool(st_timed.prm.flags & _lib.FLAG_SPLIT_LISTS), "split_quadrants": n_split,
+                   "wide_rectangles": int(st_timed.header()[4].item()), "coop_walk_flag_set_in_timed_steps": bool(st_timed.prm.flags & _lib.FLAG_COOP_WALK),
                    "workspace_bytes_forward": ws_fwd, "workspace_bytes_backward": ws_bwd if a.mode == "fwdbwd" else 0,
                    "max_instances": int(st_timed.prm.max_instances)},
         "roofline": roofline,
@@ -548,6 +549,7 @@ def main():
             res["workloads"][name] = {"value": G / dtw / 1e6, "unit": "Msplats/s", "ms_per_step": dtw * 1e3, "steps": k2,
                                       "num_rendered": stw.num_rendered(), "overflowed": stw.overflowed(),
                                       "split_quadrants": int(stw.header()[5].item()) if (stw.prm.flags & _lib.FLAG_SPLIT_LISTS) else 0, "split_errors": stw.split_errors(),
+                                      "wide_rectangles": int(stw.header()[4].item()), "coop_walk": bool(stw.prm.flags & _lib.FLAG_COOP_WALK),
                                       "workspace_bytes_forward": int(stw.layout.total_bytes), "workspace_bytes_backward": int(stw.layout.backward_bytes),
                                       "visible_pairs": int((stw.tensors()["tiles_touched"] > 0).sum().item()),
                                       "finite": bool(torch.isfinite(out["faces"]).all()), "kernels_avg_us": kw_us}

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define S360_ABI_VERSION 20
+#define S360_ABI_VERSION 21
 #define S360_MAX_VIEWS 8
 #define S360_TILE 16
 
@@ -124,6 +124,14 @@ enum {
 #define S360_FLAG_RAW_INPUTS 1024u      /* the call is s360_forward_raw / s360_backward_raw (the workspace also keeps the 7 raw geometry
                                          words per Gaussian for the backward); required by those two, rejected by the others */
 
+#define S360_FLAG_COOP_WALK 2048u       /* binning variant for clouds with many LARGE footprints: a rectangle of more than 32 tiles is
+                                         counted (k_preprocess) and emitted (k_emit) by all 64 lanes of its wave, one tile per lane,
+                                         instead of by the one lane that owns the Gaussian while 63 wait (a near splat of a uniform
+                                         random cloud covers a whole 16x16-tile face).  Separately compiled instances of the two
+                                         kernels: the default ones carry none of it.  Every result of the call is bit-identical with
+                                         and without the flag (same counts, same slots; the order of a tile's unsorted bucket is
+                                         irrelevant).  header_mirror word 2 reports how many such rectangles a call had. */
+
 typedef struct S360View {
     float viewmatrix[16];
     float projmatrix[16];
@@ -149,9 +157,11 @@ typedef struct S360Params {
     uint32_t _reserved;
     void* header_mirror;    /* NULL, or a HOST-visible (pinned / mapped) 8-byte aligned address: the forward also stores
                                (num_instances | overflow flag << 32 | sort chunks of the long lists << 33) there as one 64-bit word,
-                               and 1 into the NEXT 64-bit word (16 bytes in all) when some 8x8 quadrant of the call was worth
+                               1 into the low half of the NEXT 64-bit word when some 8x8 quadrant of the call was worth
                                splitting (or was split) under S360_FLAG_SPLIT_LISTS's criterion — callers that set that flag
-                               adaptively clear the word before a call and read it after — the caller can size its next
+                               adaptively clear the word before a call and read it after — and the number of (Gaussian, view)
+                               pairs binned over more than 32 tiles into the THIRD word (24 bytes in all; what a caller sets
+                               S360_FLAG_COOP_WALK by) — the caller can size its next
                                call from the previous call's count without a device synchronisation (upstream reads the count
                                back synchronously inside every forward; this library's callers may run without that read,
                                and this is how they learn the count and the overflow flag anyway) */

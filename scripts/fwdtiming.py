@@ -50,5 +50,17 @@ if nseg:
               "| segment composite mean/max us", round(p2[comb == 0].mean(), 1), round(p2[comb == 0].max(), 1),
               "| combining waves", int(comb.sum()), "segment + combine mean/max", round(p2[comb == 1].mean(), 1), round(p2[comb == 1].max(), 1),
               "| longest item / mean item:", round(p2.max() / p2.mean(), 2))
+        b0 = d[4 * nu + 0::4]
+        st0 = ((b0 - b0.min()) & 0xFFFFFFFF) / 100.0
+        p2own = d[4 * nu + 1::4] / 100.0
+        print("  tail span us (first item start -> last item end)", round((st0 + p2).max(), 1), "| item starts: p50", round(np.percentile(st0, 50), 1), "p90",
+              round(np.percentile(st0, 90), 1), "max", round(st0.max(), 1), "| own segment (to arrival) mean/p90/max", round(p2own.mean(), 1),
+              round(np.percentile(p2own, 90), 1), round(p2own.max(), 1), "| combine part of combiners mean/max",
+              round((p2 - p2own)[comb == 1].mean(), 1), round((p2 - p2own)[comb == 1].max(), 1))
+        kk = (tag >> 2) & 0x3FF
+        for lo, hi in ((2, 4), (4, 8), (8, 16), (16, 64)):
+            m = (kk >= lo) & (kk < hi)
+            if m.any():
+                print("  segments k in [%d,%d): %d items, own-segment mean us %.1f" % (lo, hi, int(m.sum()), p2own[m].mean()))
         for i in np.argsort(-p2)[:6]:
             print("  item tile", int((tag[i] >> 12) & 0x7FFFF), "k", int((tag[i] >> 2) & 0x3FF), "q", int(tag[i] & 3), "us", round(p2[i], 1), "combined", int(comb[i]))

@@ -31,7 +31,8 @@ FLAG_DEFER_LOSS = 128
 FLAG_ATOMIC_GRADS = 256
 FLAG_SPLIT_LISTS = 512
 FLAG_RAW_INPUTS = 1024
-ABI_VERSION = 20
+FLAG_COOP_WALK = 2048
+ABI_VERSION = 21
 
 
 class S360Params(C.Structure):

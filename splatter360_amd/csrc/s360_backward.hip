@@ -828,7 +828,7 @@ static int backward_composite(const BwdCtx& c, const S360View* views, const void
         sb.seg_cnt = (const uint32_t*)(ws + L.seg_cnt);
         sb.seg_info = (const uint2*)(ws + L.seg_info);
         sb.seg_list = c.seg_list;
-        sb.n_seg_blocks = (uint32_t)min((size_t)256, c.n_slots * 4);
+        sb.n_seg_blocks = (uint32_t)min((size_t)S360_SEG_BWD_BLOCKS, c.n_slots * 4);
         sb.dbg_base = (uint32_t)c.nt * 4u;
     }
     {

@@ -57,12 +57,15 @@ struct KParams {
 #ifndef S360_SEG_HEAD
 #define S360_SEG_HEAD 1024
 #endif
+#ifndef S360_SEG_BWD_BLOCKS
+#define S360_SEG_BWD_BLOCKS 256   // workgroups (one wave each) of the backward composite that take the segment units, grid-stride
+#endif
 #ifndef S360_SEG_MIN_REST
 #define S360_SEG_MIN_REST 512
 #endif
 constexpr uint32_t SEG_LEN = S360_SEG_LEN, SEG_HEAD = S360_SEG_HEAD, SEG_MIN_REST = S360_SEG_MIN_REST, SEG_PER_CHUNK = 4096 / SEG_LEN;
 constexpr uint32_t SEG_K0 = SEG_HEAD / SEG_LEN;   // first segment index a segment wave takes
-static_assert(4096 % SEG_LEN == 0 && SEG_HEAD % SEG_LEN == 0 && SEG_LEN % 64 == 0 && SEG_K0 >= 2, "segments tile the sort's 4 096-key chunks; slots 0 and 1 hold the head's state");
+static_assert(4096 % SEG_LEN == 0 && SEG_HEAD % SEG_LEN == 0 && SEG_LEN % 64 == 0 && SEG_K0 >= 1, "segments tile the sort's 4 096-key chunks; slot 0 holds the head's state");
 __device__ constexpr float SEG_T_FAR = 1.0f / 16.0f;   // "far from saturating": at least four more opacity-0.5 contributions to go
 __host__ __device__ inline size_t seg_slots(size_t cap) { return (size_t)SEG_PER_CHUNK * (cap / 2048 + 1); }
 // segment slots of a call: S360Params.max_segments, or enough for every list of the binning capacity to be long

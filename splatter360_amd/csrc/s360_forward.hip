@@ -22,6 +22,8 @@
 
 namespace s360 {
 
+typedef float f4v __attribute__((ext_vector_type(4)));   // a 128-bit register tuple (vector loads, inline-asm operands)
+
 // ------------------------------------------------------------------------------ SH -> RGB (shared camera centre)
 // When all views of a call share one camera centre (the six faces of a panorama) the colour of a Gaussian does not
 // depend on the view: a streaming kernel evaluates it ONCE per Gaussian ahead of the geometry pass, and the geometry
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(SHE3_G * 3) void k_sh_eval3(KParams kp, const S360V
             // re-read the last vector into the pad): a guarded load compiles to a branch with a full wait per round
             float4* d4 = reinterpret_cast<float4*>(s_sh);
             float4 q[7];
-            typedef float f4v __attribute__((ext_vector_type(4)));   // non-temporal: every slab byte is read once per call (63 -> 54 us)
+            // (f4v loads non-temporal: every slab byte is read once per call, 63 -> 54 us)
 #pragma unroll
             for (int r = 0; r < 7; ++r) {
                 const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(src) + min(tid + r * (SHE3_G * 3), SHE3_G * 75 / 4 - 1));
@@ -211,7 +213,6 @@ __global__ __launch_bounds__(SHE3_G * 3) void k_sh_eval3_jac(KParams kp, const S
             float4* d4 = reinterpret_cast<float4*>(s_sh);
             float4 q[7];
             // non-temporal loads: every slab byte is read exactly once per call
-            typedef float f4v __attribute__((ext_vector_type(4)));
 #pragma unroll
             for (int r = 0; r < 7; ++r) {
                 const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(src) + min(tid + r * (SHE3_G * 3), SHE3_G * 75 / 4 - 1));
@@ -350,7 +351,6 @@ __global__ __launch_bounds__(SHE3_G * 3) void k_raw_eval(KParams kp, const S360V
         if ((((uintptr_t)src) & 15) == 0 && nb == SHE3_G) {
             float4* d4 = reinterpret_cast<float4*>(s_raw);
             float4 q[7];
-            typedef float f4v __attribute__((ext_vector_type(4)));
 #pragma unroll
             for (int r = 0; r < 7; ++r) {
                 const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(src) + min(tid + r * (SHE3_G * 3), SHE3_G * RAW_C / 4 - 1));
@@ -472,7 +472,8 @@ __global__ __launch_bounds__(SHE3_G * 3) void k_raw_eval(KParams kp, const S360V
 }
 
 // ------------------------------------------------------------------------------ preprocess
-template <bool USE_SH, bool CH_MAJOR, bool EAGER = false>  // EAGER: colours come from k_sh_eval (rgbc), no slab code here
+// COOP (S360_FLAG_COOP_WALK): rectangles of more than 32 tiles are counted by the whole wave, one tile per lane
+template <bool USE_SH, bool CH_MAJOR, bool EAGER = false, bool COOP = false>  // EAGER: colours come from k_sh_eval (rgbc), no slab code here
 __global__ __launch_bounds__(S360_BLOCK) void k_preprocess(
     KParams kp, const S360View* __restrict__ views, const float* __restrict__ means,
     const float* __restrict__ cov6, const float* __restrict__ opac, const float* __restrict__ shs,
@@ -526,6 +527,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess(
         const size_t p = (size_t)v * P + g;
         int radius = 0;
         uint32_t touched = 0;
+        uint32_t coop_lo = 0, coop_hi = 0;   // COOP: this lane's rectangle, if the wave is to count it (min | max corners, x | y << 16)
         // scale-invariant rescale fused here (cuda_splatting.py:68-69): same f32 products as torch
         const float sc = vw.scale, sc2 = sc * sc;
         const float mx = mx0 * sc, my = my0 * sc, mz = mz0 * sc;
@@ -611,6 +613,10 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess(
                                 bit <<= 1;
                             }
                         touched = (uint32_t)__builtin_popcount(hmask);
+                    } else if (COOP && area > 32) {
+                        touched = (uint32_t)area;
+                        coop_lo = (uint32_t)minx | ((uint32_t)miny << 16);
+                        coop_hi = (uint32_t)maxx | ((uint32_t)maxy << 16);
                     } else {
                         touched = (uint32_t)area;
                         for (int y = miny; y < maxy; ++y)
@@ -692,6 +698,19 @@ __global__ __launch_bounds__(S360_BLOCK) void k_preprocess(
                 }
             }
         }
+        if (COOP) {   // (wave-uniform here: every thread runs the view loop)
+            uint32_t* tc = lds_hist == 2 ? hist : (lds_hist ? hist : tile_count) + (size_t)image_of_view(kp, v) * kp.T;
+            const int lane = tid & 63;
+            for (unsigned long long big = __ballot(coop_hi != 0u); big; big &= big - 1ull) {
+                const int src = (int)__builtin_ctzll(big);
+                const uint32_t lo = (uint32_t)__shfl((int)coop_lo, src), hi = (uint32_t)__shfl((int)coop_hi, src);
+                const int minx = lo & 0xFFFFu, miny = lo >> 16, w = (int)(hi & 0xFFFFu) - minx, n = w * ((int)(hi >> 16) - miny);
+                for (int i = lane; i < n; i += 64) {
+                    const int y = i / w;
+                    atomicAdd(&tc[(miny + y) * kp.gx + minx + (i - y * w)], 1u);
+                }
+            }
+        }
         if (act && radii) radii[p] = radius;
         // visibility of the V (<= 8) views in ONE byte per Gaussian: k_emit and the backward test that instead of V words
         // (24 MB written here and read twice for six views of 1 M Gaussians); tiles_touched only exists for visible pairs
@@ -767,7 +786,7 @@ struct SegBufs {
     const uint32_t* chunk_start;  // null: splitting off
     uint32_t* seg_flag;
     uint32_t* seg_arrive;         // phase-1 deliveries per (tile, quadrant)
-    uint32_t* seg_arrive2;        // phase-2 deliveries per (tile, quadrant); [V*T*4] = the ticket counter of the work queue
+    uint32_t* seg_arrive2;        // phase-2 deliveries per (tile, quadrant)
     uint32_t n_slots;             // segment slots the workspace holds (quadrants whose segments do not fit are not split)
     float4* part_c;
     float* part_t;
@@ -851,7 +870,8 @@ __global__ __launch_bounds__(TS_BLOCK) void k_tile_scan(const uint32_t* __restri
 #endif
 constexpr int EMIT_PPT = S360_EMIT_PPT;  // pairs per thread: more instances per (block, tile) => fewer global atomics
 
-template <bool LDS_BIN>
+// COOP (S360_FLAG_COOP_WALK): pairs of more than 32 tiles are counted and placed by the whole wave, one tile per lane
+template <bool LDS_BIN, bool COOP = false>
 __global__ __launch_bounds__(S360_BLOCK) void k_emit(KParams kp, const uint32_t* __restrict__ tiles_touched,
                                                     const uint8_t* __restrict__ vis_mask, const float4* __restrict__ recA, const float4* __restrict__ recC,
                                                     const float* __restrict__ depths, const uint32_t* __restrict__ tile_start,
@@ -932,17 +952,32 @@ __global__ __launch_bounds__(S360_BLOCK) void k_emit(KParams kp, const uint32_t*
         // issued now, consumed after the counting phase
         if (threadIdx.x == 0 && carry) ticket = tile_start[tb] + atomicAdd(&slot_ticket[image_of_view(kp, v) * 64], carry);
     }
+    const int lane = threadIdx.x & 63;
     if (LDS_BIN) {
 #pragma unroll
         for (int j = 0; j < EMIT_PPT; ++j) {
-            if (!tt[j]) continue;
-            const int minx = rlo[j] & 0xFFFFu, miny = rlo[j] >> 16, maxx = rhi[j] & 0xFFFFu, maxy = rhi[j] >> 16;
-            uint32_t m = hm[j];
-            for (int y = miny; y < maxy; ++y)
-                for (int x = minx; x < maxx; ++x) {
-                    if (m & 1u) atomicAdd(&cnt[y * kp.gx + x], 1u);
-                    m = (m >> 1) | 0x80000000u;   // rectangles beyond 32 tiles: all ones
+            if (COOP && (uint32_t)j * S360_BLOCK >= nvis) break;   // block-uniform
+            const bool wide = COOP && tt[j] > 32u;   // (more than 32 instances = a rectangle of more than 32 tiles, binned whole)
+            if (tt[j] && !wide) {
+                const int minx = rlo[j] & 0xFFFFu, miny = rlo[j] >> 16, maxx = rhi[j] & 0xFFFFu, maxy = rhi[j] >> 16;
+                uint32_t m = hm[j];
+                for (int y = miny; y < maxy; ++y)
+                    for (int x = minx; x < maxx; ++x) {
+                        if (m & 1u) atomicAdd(&cnt[y * kp.gx + x], 1u);
+                        m = (m >> 1) | 0x80000000u;   // rectangles beyond 32 tiles: all ones
+                    }
+            }
+            if (COOP) {
+                for (unsigned long long big = __ballot(wide); big; big &= big - 1ull) {
+                    const int src = (int)__builtin_ctzll(big);
+                    const uint32_t lo = (uint32_t)__shfl((int)rlo[j], src), hi = (uint32_t)__shfl((int)rhi[j], src);
+                    const int minx = lo & 0xFFFFu, miny = lo >> 16, w = (int)(hi & 0xFFFFu) - minx, n = w * ((int)(hi >> 16) - miny);
+                    for (int i = lane; i < n; i += 64) {
+                        const int y = i / w;
+                        atomicAdd(&cnt[(miny + y) * kp.gx + minx + (i - y * w)], 1u);
+                    }
                 }
+            }
         }
         __syncthreads();
         for (int i = threadIdx.x; i < kp.T; i += S360_BLOCK) {
@@ -959,36 +994,59 @@ __global__ __launch_bounds__(S360_BLOCK) void k_emit(KParams kp, const uint32_t*
     }
 #pragma unroll
     for (int j = 0; j < EMIT_PPT; ++j) {
-        if (!tt[j]) continue;
+        if (COOP && (uint32_t)j * S360_BLOCK >= nvis) break;   // block-uniform
+        const bool wide = COOP && tt[j] > 32u;
         const uint32_t p = pr[j];
-        const int minx = rlo[j] & 0xFFFFu, miny = rlo[j] >> 16, maxx = rhi[j] & 0xFFFFu, maxy = rhi[j] >> 16;
-        const uint64_t key = ((uint64_t)dbits[j] << 32) | (uint64_t)p;
         // owner table of the pair's instance slots (slot = slot_base[p] + rank of the tile among the rectangle's instance-holding
         // tiles in this emission order: its position inside the rectangle when every tile holds one)
         uint32_t slot = 0;
-        if (slot_pair) {
-            slot = sl[j] + s_slot0;
-            slot_info[p].x = slot;
-            if (tt[j] > 32u) {   // more than 32 slots: summed by a whole wave in the backward (k_gather_slots, second phase)
+        if (tt[j]) {
+            if (slot_pair) {
+                slot = sl[j] + s_slot0;
+                slot_info[p].x = slot;
+            }
+            if (tt[j] > 32u) {   // more than 32 slots: summed by a whole wave in the backward (k_gather_slots, second phase);
+                                 // the count also tells the caller when S360_FLAG_COOP_WALK pays (header_mirror word 2)
                 const uint32_t k = atomicAdd(&header[4], 1u);
-                if (k < kp.cap / 32u + 1u) long_pairs[k] = p;
+                if (slot_pair && k < kp.cap / 32u + 1u) long_pairs[k] = p;
             }
         }
-        uint32_t m = hm[j];
-        for (int y = miny; y < maxy; ++y)
-            for (int x = minx; x < maxx; ++x) {
-                if (m & 1u) {
-                    const int t = y * kp.gx + x;
+        if (tt[j] && !wide) {
+            const int minx = rlo[j] & 0xFFFFu, miny = rlo[j] >> 16, maxx = rhi[j] & 0xFFFFu, maxy = rhi[j] >> 16;
+            const uint64_t key = ((uint64_t)dbits[j] << 32) | (uint64_t)p;
+            uint32_t m = hm[j];
+            for (int y = miny; y < maxy; ++y)
+                for (int x = minx; x < maxx; ++x) {
+                    if (m & 1u) {
+                        const int t = y * kp.gx + x;
+                        const uint32_t pos = LDS_BIN ? base[t] + atomicAdd(&cnt[t], 1u)
+                                                     : tile_start[tb + t] + atomicAdd(&tile_cursor[tb + t], 1u);
+                        if (pos < kp.cap) keys[pos] = key;
+                        if (slot_pair) {
+                            if (slot < kp.cap) slot_pair[slot] = p;
+                            ++slot;
+                        }
+                    }
+                    m = (m >> 1) | 0x80000000u;
+                }
+        }
+        if (COOP) {
+            for (unsigned long long big = __ballot(wide); big; big &= big - 1ull) {
+                const int src = (int)__builtin_ctzll(big);
+                const uint32_t lo = (uint32_t)__shfl((int)rlo[j], src), hi = (uint32_t)__shfl((int)rhi[j], src);
+                const uint32_t ps = (uint32_t)__shfl((int)p, src), ds = (uint32_t)__shfl((int)dbits[j], src), s0 = (uint32_t)__shfl((int)slot, src);
+                const uint64_t key = ((uint64_t)ds << 32) | (uint64_t)ps;
+                const int minx = lo & 0xFFFFu, miny = lo >> 16, w = (int)(hi & 0xFFFFu) - minx, n = w * ((int)(hi >> 16) - miny);
+                for (int i = lane; i < n; i += 64) {   // tile i of the rectangle in scan order = instance slot s0 + i
+                    const int y = i / w;
+                    const int t = (miny + y) * kp.gx + minx + (i - y * w);
                     const uint32_t pos = LDS_BIN ? base[t] + atomicAdd(&cnt[t], 1u)
                                                  : tile_start[tb + t] + atomicAdd(&tile_cursor[tb + t], 1u);
                     if (pos < kp.cap) keys[pos] = key;
-                    if (slot_pair) {
-                        if (slot < kp.cap) slot_pair[slot] = p;
-                        ++slot;
-                    }
+                    if (slot_pair && s0 + (uint32_t)i < kp.cap) slot_pair[s0 + (uint32_t)i] = ps;
                 }
-                m = (m >> 1) | 0x80000000u;
             }
+        }
     }
 }
 
@@ -1136,7 +1194,8 @@ __device__ __forceinline__ ChunkUnit chunk_unit(const uint32_t* __restrict__ til
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_stage1(const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ chunk_start,
                                                     int nt, uint64_t* __restrict__ keys, uint64_t* __restrict__ alt,
                                                     uint32_t* __restrict__ list, uint32_t cap, uint32_t max_passes, uint32_t cgrid,
-                                                    const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_order) {
+                                                    const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_order,
+                                                    const uint32_t* __restrict__ header, unsigned long long* __restrict__ wide_mirror) {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds_m[];
     const uint32_t bid = blockIdx.x;
     if (bid < cgrid) {  // 4 096-key chunks of the long lists, grid-stride over the chunk table
@@ -1160,6 +1219,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_stage1(const uint32_t* __
         block_merge_sort<SORT_THREADS, (int)(SORT_SHORT / SORT_THREADS)>(keys + s, keys + s, list + s, n, lds_m);
         return;
     }
+    // S360Params.header_mirror word 2: (Gaussian, view) pairs binned over more than 32 tiles (k_emit, the previous launch, counted them)
+    if (wide_mirror && threadIdx.x == 0) __hip_atomic_store(wide_mirror, (unsigned long long)header[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (tile_order) order_units_body<SORT_THREADS>(tile_count, tile_order, nt);  // longest list first (dispatch order of k_render)
 }
 
@@ -1687,6 +1748,8 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
     // (lists beyond SORT_SHORT keys only: those own segment slots through the sort's chunk table)
     const uint32_t split_at = ((SPLIT || cand_mirror) && end - start >= SEG_HEAD + SEG_MIN_REST && end - start > SORT_SHORT) ? start + SEG_HEAD : 0xFFFFFFFFu;
     bool went = false;
+    // (s_setprio 3 on the waves that may hand over — the 1 024-entry heads are this variant's critical path, ~135 us of its ~158 —
+    // measured no change: 137 us.  They are not short of issue slots.)
     for (uint32_t b = start; b < end; b += 64) {
         const unsigned long long act = __ballot(!done);
         if (act == 0ull) break;
@@ -1695,7 +1758,7 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
             const bool far_px = !done && T >= SEG_T_FAR;
             if (__ballot(far_px) != 0ull) {
                 // tell the host (next call): this cloud has quadrants worth splitting
-                if (cand_mirror && lane == 0) __hip_atomic_store(cand_mirror, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (cand_mirror && lane == 0) __hip_atomic_store(cand_mirror, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (word 1 of the mirror)
                 if (SPLIT && (SEG_PER_CHUNK * chunk_start[t] + (end - start + SEG_LEN - 1) / SEG_LEN) <= sgp->n_slots) {
                     went = true;
                     break;
@@ -1875,7 +1938,7 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
         if (lane == 0) {
             sg.part_n[slot * 4 + wave] = scount;        // survivor records of the head
             // ... and how many of them lie in front of the head's last contributor (what the backward replays if no segment adds one)
-            sg.part_n[(slot + 1) * 4 + wave] = wmh ? sv_cnt + (uint32_t)__popcll(sv_m & ((2ull << (wmh - 1u - sv_rel)) - 1ull)) : 0u;
+            sg.seg_cnt[slot * 4 + wave] = wmh ? sv_cnt + (uint32_t)__popcll(sv_m & ((2ull << (wmh - 1u - sv_rel)) - 1ull)) : 0u;
             sg.seg_flag[4 * t + wave] = 1u;
             atomicAdd(&sg.header[S360_HDR_SPLIT], 1u);
             wbase = atomicAdd(&sg.header[S360_HDR_SEGWORK], nseg);
@@ -1962,9 +2025,9 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
 // that differs from the sequential product only by floating-point association (T_in is a product of segment products): images
 // within 1e-6 of the unsplit composite, stop decisions identical except where a product lands within rounding of 1e-4.
 // No wave ever waits for another: the phase-1 results come from the previous launch, and the combine is done by whoever arrives last
-// (device-coherent stores, drained with s_waitcnt vmcnt(0), then ONE agent-scope counter — the pattern of k_merge_all).  Tickets and
-// arrival counts are broadcast BY VALUE (__shfl), never v_readfirstlane: a build whose compiler treated the ticket loop as divergent
-// left the lanes that are not lane 0 with ticket 0 for ever and hung the GPU.
+// (device-coherent stores, drained with s_waitcnt vmcnt(0), then ONE agent-scope counter — the pattern of k_merge_all).  The
+// arrival count is broadcast BY VALUE (__shfl), never v_readfirstlane: a build that handed out work through a ticket loop the
+// compiler treated as divergent left the lanes that are not lane 0 with ticket 0 for ever and hung the GPU.
 #ifndef S360_TAIL_GRID
 #define S360_TAIL_GRID 1024
 #endif
@@ -1987,33 +2050,27 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(S360
     const int pwave = threadIdx.x >> 6, lane = threadIdx.x & 63;   // pwave: this wave's LDS slices; its quadrant comes with the work item
     const WaveLds L{s_x[pwave], s_y[pwave], s_a[pwave], s_b[pwave], s_c[pwave], s_o[pwave], s_rg[pwave], s_bz[pwave], s_pos[pwave]};
     const uint32_t nwork = sg.header[S360_HDR_SEGWORK];       // (tile, quadrant, segment) items k_render queued
-    uint32_t* const queue = sg.seg_arrive2 + (size_t)nt * 4;   // the ticket counter (cleared with the arrival counters)
-    uint32_t guard = 0;
-    for (;;) {   // every WAVE takes its own tickets: one per work item
-        uint32_t tk = 0;
-        if (lane == 0) tk = __hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // broadcast BY VALUE to every lane (not v_readfirstlane: were the compiler to treat this loop as divergent, the lanes that
-        // are not lane 0 would carry ticket 0 for ever — seen: a build whose loop structure did exactly that hung the GPU)
-        tk = (uint32_t)__shfl((int)tk, 0);
-        if (tk >= nwork) break;
-        const uint32_t wi = tk;
+    // Work items are dealt STATICALLY, item i to wave slot i mod (4 gridDim): consecutive items — the segments of one quadrant — go to
+    // different workgroups, so a call with fewer items than wave slots (2 419 against 4 096 on the 1 M surface-like cloud) spreads
+    // them over every CU.  (A ticket counter — one agent-scope atomic per item on ONE address — let the last wave start 27 us into
+    // the kernel: ~10 ns per ticket, serialised in one L2 channel.)
+    for (uint32_t wi = (uint32_t)pwave * gridDim.x + blockIdx.x; wi < nwork; wi += (S360_BLOCK / 64) * gridDim.x) {
 #ifdef S360_DBG_TIMING
         const long long t_begin = wall_clock64();
 #endif
         const uint2 item = sg.seg_info[wi];
         const int t = (int)item.x, wave = (int)(item.y & 3u);
         const uint32_t k = item.y >> 2;
-        if ((uint32_t)t >= (uint32_t)nt || ++guard > 100000u) {   // corrupt work item / runaway loop: an error word, never a hung GPU
+        if ((uint32_t)t >= (uint32_t)nt) {   // corrupt work item: an error word (RasterState.split_errors), never a wild access
             if (lane == 0 && atomicAdd(&sg.header[7], 0x10000u) == 0u) {
-                sg.header[8] = item.x; sg.header[9] = item.y; sg.header[12] = tk; sg.header[13] = nwork; sg.header[14] = guard;
+                sg.header[8] = item.x; sg.header[9] = item.y; sg.header[12] = wi; sg.header[13] = nwork;
             }
-            if (guard > 100000u) break;
             continue;
         }
         const uint32_t start = min(tile_start[t], kp.cap), end = min(tile_start[t + 1], kp.cap), n = end - start;
         if (k < SEG_K0 || k * SEG_LEN >= n || sg.seg_flag[4 * t + wave] != 1u) {
             if (lane == 0 && atomicAdd(&sg.header[7], 0x100u) == 0u) {
-                sg.header[8] = item.x; sg.header[9] = item.y; sg.header[10] = n; sg.header[12] = tk; sg.header[13] = nwork;
+                sg.header[8] = item.x; sg.header[9] = item.y; sg.header[10] = n; sg.header[12] = wi; sg.header[13] = nwork;
             }
             continue;
         }
@@ -2039,6 +2096,7 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(S360
             const uint32_t l = sg.part_l[li0];
             head_done = (l >> 31) != 0u || !inside;
             T = sg.part_t[li0];
+#pragma unroll 8
             for (uint32_t kk = SEG_K0; kk < k; ++kk) T = T * sg.part_t[((slot0 + kk) * 4 + wave) * 64 + lane];
         }
         {
@@ -2061,7 +2119,8 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(S360
 #ifdef S360_DBG_TIMING
         if (lane == 0) {
             const size_t di = 4 * ((size_t)4 * nt + wi);
-            dbg[di + 2] = (uint32_t)(wall_clock64() - t_begin);
+            dbg[di] = (uint32_t)t_begin;
+            dbg[di + 1] = dbg[di + 2] = (uint32_t)(wall_clock64() - t_begin);
             dbg[di + 3] = ((uint32_t)t << 12) | (k << 2) | (uint32_t)wave;
         }
 #endif
@@ -2076,25 +2135,57 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(S360
             T = sg.part_t[li0];
         }
         const float head_T = T;
+        uint32_t kstop = SEG_K0;   // the pixel was live in segments [SEG_K0, kstop) (the products only shrink: one change-over)
         {
             float Tin = head_T;     // the same left-to-right product the segment waves formed: which segments this pixel was live in
-            for (uint32_t kk = SEG_K0; kk < K; ++kk) {
-                const size_t lik = ((slot0 + kk) * 4 + wave) * 64 + lane;
-                const bool live = !head_done && !(Tin < 0.0001f);
-                const float* pc = reinterpret_cast<const float*>(sg.part_c + lik);
-                const float c0 = ld_devf(pc), c1 = ld_devf(pc + 1), c2 = ld_devf(pc + 2), c3 = ld_devf(pc + 3);
-                const float te = ld_devf(sg.part_e + lik);
-                const uint32_t pl = ld_dev32(sg.part_l + lik);
-                Tin = Tin * sg.part_t[lik];
-                f2 D01 = f2{0.f, 0.f}, D2D = f2{0.f, 0.f};
-                if (live) {
-                    D01 = f2{c0, c1}; D2D = f2{c2, c3};
-                    T = te;
-                    last = pl ? pl : last;
+            bool alive = !head_done;
+            // The other waves' results are read with device-coherent loads, FOUR segments (12 loads) in flight per wait: one load per
+            // round trip — what a loop of atomic loads compiles to — cost the combining wave of a 34-segment list ~100 us.
+            for (uint32_t kb = SEG_K0; kb < K; kb += 4) {
+                size_t ix[4];
+                float tq[4];
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) {
+                    ix[j] = ((slot0 + min(kb + j, K - 1)) * 4 + wave) * 64 + lane;
+                    tq[j] = sg.part_t[ix[j]];      // (phase 1: the previous launch)
                 }
-                C01 = C01 + D01; C2D = C2D + D2D;
-                sg.seg_c[lik] = make_float4(D01.x, D01.y, D2D.x, D2D.y);   // the segment's own contribution; turned into "behind" sums below
-                sg.seg_t[lik] = T;                                         // transmittance behind the segment
+                f4v cq[4];
+                float teq[4];
+                uint32_t plq[4];
+                asm volatile(
+                    "global_load_dwordx4 %0, %12, off sc1\n"
+                    "global_load_dwordx4 %1, %13, off sc1\n"
+                    "global_load_dwordx4 %2, %14, off sc1\n"
+                    "global_load_dwordx4 %3, %15, off sc1\n"
+                    "global_load_dword %4, %16, off sc1\n"
+                    "global_load_dword %5, %17, off sc1\n"
+                    "global_load_dword %6, %18, off sc1\n"
+                    "global_load_dword %7, %19, off sc1\n"
+                    "global_load_dword %8, %20, off sc1\n"
+                    "global_load_dword %9, %21, off sc1\n"
+                    "global_load_dword %10, %22, off sc1\n"
+                    "global_load_dword %11, %23, off sc1\n"
+                    "s_waitcnt vmcnt(0)\n"
+                    : "=&v"(cq[0]), "=&v"(cq[1]), "=&v"(cq[2]), "=&v"(cq[3]), "=&v"(teq[0]), "=&v"(teq[1]), "=&v"(teq[2]), "=&v"(teq[3]),
+                      "=&v"(plq[0]), "=&v"(plq[1]), "=&v"(plq[2]), "=&v"(plq[3])
+                    : "v"(sg.part_c + ix[0]), "v"(sg.part_c + ix[1]), "v"(sg.part_c + ix[2]), "v"(sg.part_c + ix[3]),
+                      "v"(sg.part_e + ix[0]), "v"(sg.part_e + ix[1]), "v"(sg.part_e + ix[2]), "v"(sg.part_e + ix[3]),
+                      "v"(sg.part_l + ix[0]), "v"(sg.part_l + ix[1]), "v"(sg.part_l + ix[2]), "v"(sg.part_l + ix[3])
+                    : "memory");
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) {
+                    if (kb + j < K) {
+                        alive = alive && !(Tin < 0.0001f);
+                        Tin = Tin * tq[j];
+                        if (alive) {
+                            C01 = C01 + f2{cq[j].x, cq[j].y}; C2D = C2D + f2{cq[j].z, cq[j].w};
+                            T = teq[j];
+                            last = plq[j] ? plq[j] : last;
+                            kstop = kb + j + 1;
+                        }
+                        sg.seg_t[ix[j]] = T;                                   // transmittance behind the segment
+                    }
+                }
             }
         }
         // ---- the pixels, exactly as k_render's epilogue writes them
@@ -2139,20 +2230,40 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(S360
             if (wm) atomicMax(&tile_max_contrib[t], wm);
             // the backward's units of this quadrant: the head (all of its survivor records once a later segment contributes, else
             // those in front of its own last contributor) and every segment that starts in front of the last contributor
-            if (surv_count) surv_count[4 * t + wave] = wm > SEG_HEAD ? sg.part_n[slot0 * 4 + wave] : sg.part_n[(slot0 + 1) * 4 + wave];
-            for (uint32_t kk = SEG_K0; kk < K; ++kk)
-                sg.seg_cnt[(slot0 + kk) * 4 + wave] = (surv_count && kk * SEG_LEN < wm) ? ld_dev32(sg.part_n + (slot0 + kk) * 4 + wave) : 0u;
+            if (surv_count) surv_count[4 * t + wave] = wm > SEG_HEAD ? sg.part_n[slot0 * 4 + wave] : sg.seg_cnt[slot0 * 4 + wave];
         }
-        // ---- colour accumulated BEHIND every segment (back to front: the small terms first) and behind the head
+        for (uint32_t kk = SEG_K0 + (uint32_t)lane; kk < K; kk += 64)      // (one segment per lane: the loads overlap)
+            sg.seg_cnt[(slot0 + kk) * 4 + wave] = (surv_count && kk * SEG_LEN < wm) ? ld_dev32(sg.part_n + (slot0 + kk) * 4 + wave) : 0u;
+        // ---- colour accumulated BEHIND every segment (back to front: the small terms first) and behind the head: a second pass
+        // over the segments' contributions, four coherent loads in flight per wait
         {
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (uint32_t kk = K; kk-- > SEG_K0;) {
-                const size_t lik = ((slot0 + kk) * 4 + wave) * 64 + lane;
-                const float4 d = sg.seg_c[lik];
-                sg.seg_c[lik] = acc;
-                acc = make_float4(acc.x + d.x, acc.y + d.y, acc.z + d.z, acc.w + d.w);
+            f4v acc = {0.f, 0.f, 0.f, 0.f};
+            for (uint32_t kt = K; kt > SEG_K0;) {
+                // segments kt-1, kt-2, kt-3, kt-4 (those below SEG_K0 clamp to a valid slot and are skipped)
+                size_t ix[4];
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) ix[j] = ((slot0 + (kt - SEG_K0 > j ? kt - 1 - j : (uint32_t)SEG_K0)) * 4 + wave) * 64 + lane;
+                f4v dq[4];
+                asm volatile(
+                    "global_load_dwordx4 %0, %4, off sc1\n"
+                    "global_load_dwordx4 %1, %5, off sc1\n"
+                    "global_load_dwordx4 %2, %6, off sc1\n"
+                    "global_load_dwordx4 %3, %7, off sc1\n"
+                    "s_waitcnt vmcnt(0)\n"
+                    : "=&v"(dq[0]), "=&v"(dq[1]), "=&v"(dq[2]), "=&v"(dq[3])
+                    : "v"(sg.part_c + ix[0]), "v"(sg.part_c + ix[1]), "v"(sg.part_c + ix[2]), "v"(sg.part_c + ix[3])
+                    : "memory");
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) {
+                    if (kt - SEG_K0 > j) {
+                        const uint32_t kk = kt - 1 - j;
+                        sg.seg_c[ix[j]] = make_float4(acc.x, acc.y, acc.z, acc.w);
+                        if (kk < kstop) acc = acc + dq[j];      // (a segment the pixel had stopped in front of contributes nothing)
+                    }
+                }
+                kt = kt - SEG_K0 > 4 ? kt - 4 : (uint32_t)SEG_K0;
             }
-            sg.seg_c[li0] = acc;
+            sg.seg_c[li0] = make_float4(acc.x, acc.y, acc.z, acc.w);
             sg.seg_t[li0] = head_T;
         }
 #ifdef S360_DBG_TIMING
@@ -2352,7 +2463,11 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
         ProfScope ps(PS_PREPROCESS, st);
         if (shs) {
             const size_t lds = lds_hist ? hist_bytes : 0;
-            if (eager)
+            if (eager && (kp.flags & S360_FLAG_COOP_WALK))
+                hipLaunchKernelGGL((k_preprocess<true, true, true, true>), dim3(nblk), dim3(S360_BLOCK), lds, st, kp, views, means3D, cov6,
+                                   opacities, shs, colors_precomp, radii, tiles_touched, recA, recB, recC, clamped, depths,
+                                   tile_count, lds_hist, rgbc, vis_mask, slot_info);
+            else if (eager)
                 hipLaunchKernelGGL((k_preprocess<true, true, true>), dim3(nblk), dim3(S360_BLOCK), lds, st, kp, views, means3D, cov6,
                                    opacities, shs, colors_precomp, radii, tiles_touched, recA, recB, recC, clamped, depths,
                                    tile_count, lds_hist, rgbc, vis_mask, slot_info);
@@ -2388,7 +2503,10 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
         uint32_t* slot_pair = (kp.flags & S360_FLAG_FORWARD_ONLY) ? nullptr : (uint32_t*)(ws + L.slot_pair);
         {
         ProfScope ps(PS_EMIT, st);
-        if ((size_t)kp.T * 8 <= 64 * 1024)
+        if ((size_t)kp.T * 8 <= 64 * 1024 && (kp.flags & S360_FLAG_COOP_WALK))
+            hipLaunchKernelGGL((k_emit<true, true>), egrid, dim3(S360_BLOCK), (size_t)kp.T * 8, st, kp, tiles_touched, vis_mask, recA, recC,
+                               depths, tile_start, tile_cursor, keys, slot_info, slot_pair, slot_ticket, header, (uint32_t*)(ws + L.long_pairs));
+        else if ((size_t)kp.T * 8 <= 64 * 1024)
             hipLaunchKernelGGL(k_emit<true>, egrid, dim3(S360_BLOCK), (size_t)kp.T * 8, st, kp, tiles_touched, vis_mask, recA, recC,
                                depths, tile_start, tile_cursor, keys, slot_info, slot_pair, slot_ticket, header, (uint32_t*)(ws + L.long_pairs));
         else
@@ -2410,7 +2528,8 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
             const unsigned cgrid = (unsigned)min((size_t)1024, (size_t)kp.cap / SORT_CHUNK + (size_t)kp.cap / SORT_SHORT + 2);
             const size_t lds512 = (size_t)(SORT_CHUNK + SORT_CHUNK / 8) * 8;
             hipLaunchKernelGGL(k_sort_stage1, dim3(cgrid + nt + 1), dim3(SORT_THREADS), lds512, st, tile_start, chunk_start, nt, keys, keys_alt, list,
-                               kp.cap, passes, cgrid, tile_count, tile_order);
+                               kp.cap, passes, cgrid, tile_count, tile_order, header,
+                               prm->header_mirror ? (unsigned long long*)prm->header_mirror + 2 : (unsigned long long*)nullptr);
             // everything after the chunk sorts in ONE launch: persistent workgroups, pass by pass behind per-tile completion
             // counters; passes no list of the call needs are never entered, the global-memory fallback runs in the same launch
             if (passes > 0) {

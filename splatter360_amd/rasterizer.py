@@ -153,7 +153,8 @@ def _mirror(key) -> Tensor:
     one pinned int64 per (device, shape, list mode), never freed (a kernel in flight may still write it).  -1 = nothing yet."""
     m = _MIRRORS.get(key)
     if m is None:
-        m = torch.tensor([-1, 0], dtype=torch.int64).pin_memory()    # [1]: "some quadrant was worth splitting" (k_render)
+        # [1]: "some quadrant was worth splitting" (k_render); [2]: pairs binned over more than 32 tiles (k_emit's count)
+        m = torch.tensor([-1, 0, -1], dtype=torch.int64).pin_memory()
         _MIRRORS[key] = m
     return m
 
@@ -180,10 +181,26 @@ def _poll_mirror(key, warn: bool = True) -> None:
 
 _OVERFLOW_WARNED: dict = {}
 _CHUNK_HINT: dict = {}      # hint key -> most 4 096-key sort chunks of long tile lists any finished call of that shape reported
-SEG_PER_CHUNK = 8           # csrc/s360_device.h: segment slots per sort chunk
+SEG_PER_CHUNK = 8           # csrc/s360_device.h: segment slots per sort chunk (4096 / S360_SEG_LEN)
 
 
 _SPLIT_AGE: dict = {}       # hint key -> calls since the forward last reported a quadrant worth splitting
+
+COOP_WALK = "auto"          # S360_FLAG_COOP_WALK: True / False force; "auto": from the previous call's count of wide rectangles
+AUTO_COOP_MIN_PAIRS = 2048  # "auto": at least this many (Gaussian, view) pairs binned over more than 32 tiles in the latest finished
+                            # call of the shape (the 1 M uniform cloud: tens of thousands; the encoder-like headline cloud: a few hundred)
+
+
+def coop_decision(key, mode=None) -> bool:
+    """S360_FLAG_COOP_WALK for the next call of this shape (`mode` None = the module switch COOP_WALK): the separately compiled
+    binning kernels whose waves walk rectangles of more than 32 tiles cooperatively.  Results are bit-identical either way; the
+    variant costs the headline cloud ~5 us and saves a cloud of near, screen-filling splats ~100 us, so "auto"
+    follows word 2 of the pinned mirror — a plain host read, one call of delay, never a synchronisation."""
+    mode = COOP_WALK if mode is None else mode
+    if mode is True or mode is False:
+        return mode
+    m = _MIRRORS.get(key)
+    return m is not None and int(m[2]) >= AUTO_COOP_MIN_PAIRS
 
 
 AUTO_SPLIT_MAX_WAVES = 12288     # "auto": only where the (tile, quadrant) waves of a call fill the chip at most twice (6 144 resident waves)
@@ -409,7 +426,8 @@ class _RasterizeViews(torch.autograd.Function):
                 _lib.FLAG_LEAN_LISTS if lean else 0) | (
                 _lib.FLAG_DEFER_LOSS if (mse_defer and mse_target is not None and needs_bwd) else 0) | (
                 _lib.FLAG_ATOMIC_GRADS if (atomic_grads and needs_bwd) else 0) | (
-                _lib.FLAG_SPLIT_LISTS if (split_lists and not (atomic_grads and needs_bwd)) else 0)
+                _lib.FLAG_SPLIT_LISTS if (split_lists and not (atomic_grads and needs_bwd)) else 0) | (
+                _lib.FLAG_COOP_WALK if coop_decision(hkey) else 0)
             prm.max_instances = int(max_instances) if max_instances else default_capacity(
                 p, v, int(h), int(w), device=m3.device, lean=lean, lazy=(check != "sync"))
             # every forward reports (instance count, overflow flag, long-list chunks) into pinned host memory: how check="lazy" callers
@@ -580,7 +598,8 @@ class _RasterizeRaw(torch.autograd.Function):
             prm.P, prm.V, prm.H, prm.W, prm.sh_degree, prm.M = p, v, int(h), int(w), 4, 25
             prm.flags = _lib.FLAG_SHARED_CAMPOS | _lib.FLAG_RAW_INPUTS | (0 if needs_bwd else _lib.FLAG_FORWARD_ONLY) | (
                 _lib.FLAG_LEAN_LISTS if lean else 0) | (_lib.FLAG_SPLIT_LISTS if split_lists else 0) | (
-                _lib.FLAG_DEFER_LOSS if (mse_defer and mse_target is not None and needs_bwd) else 0)
+                _lib.FLAG_DEFER_LOSS if (mse_defer and mse_target is not None and needs_bwd) else 0) | (
+                _lib.FLAG_COOP_WALK if coop_decision(hkey) else 0)
             prm.max_instances = int(max_instances) if max_instances else default_capacity(p, v, int(h), int(w), device=dev, lean=lean,
                                                                                           lazy=(check != "sync"))
             prm.header_mirror = _mirror(hkey).data_ptr()

@@ -8,8 +8,8 @@ import torch
 from splatter360_amd import rasterizer as R
 
 
-def _fake_mirror(key, word, cand=0):
-    R._MIRRORS[key] = torch.tensor([word, cand], dtype=torch.int64)      # (the real one is pinned; the policy only reads / clears it)
+def _fake_mirror(key, word, cand=0, wide=-1):
+    R._MIRRORS[key] = torch.tensor([word, cand, wide], dtype=torch.int64)      # (the real one is pinned; the policy only reads / clears it)
 
 
 def test_lazy_capacity_follows_the_mirror_with_one_call_of_delay():
@@ -51,3 +51,15 @@ def test_split_flag_is_adaptive_by_default_and_can_be_forced():
     # calls whose (tile, quadrant) waves fill the chip more than twice never split adaptively (second launch = after ALL tiles)
     R._MIRRORS[key][1] = 1
     assert R.split_decision(key, "auto", quadrant_waves=24576) is False and R.split_decision(key, True, quadrant_waves=24576) is True
+
+
+def test_coop_walk_follows_the_wide_rectangle_count_of_the_previous_call():
+    key = R._hint_key(None, 1004, 6, 64, 64, True)
+    R._MIRRORS.pop(key, None)
+    assert R.coop_decision(key, "auto") is False                          # nothing known yet: the default kernels
+    _fake_mirror(key, 100, wide=300)                                      # the headline cloud's order of magnitude
+    assert R.coop_decision(key, "auto") is False
+    _fake_mirror(key, 100, wide=R.AUTO_COOP_MIN_PAIRS)                    # a cloud of near, screen-filling splats
+    assert R.coop_decision(key, "auto") is True
+    assert R.coop_decision(key, False) is False and R.coop_decision(key, True) is True
+    R._MIRRORS.pop(key, None)
