@@ -211,7 +211,9 @@ typedef struct S360Layout {
     size_t tile_max_contrib;    /* uint32[V*T] */
     size_t strip_last;          /* uint32[V*T*4] max n_contrib of each of the four 8x8 quadrants of a tile */
     size_t slot_pair;           /* uint32[max_instances] pair index p of every instance slot (training calls): lets the backward
-                                   sum the per-(instance, quadrant) partial gradients slot-parallel */
+                                   sum the per-(instance, quadrant) partial gradients slot-parallel.  Bit 31 is set on the slots
+                                   of a pair that owns more than 32 of them (a long_pairs entry): the slot-parallel pass skips
+                                   those — the wave-parallel pass reads them (V * P < 2^31 is required) */
     size_t long_pairs;          /* uint32[max_instances/32 + 1]  training calls: the pairs that own more than 32 instance slots
                                    (header[4] of them, in no particular order): the backward sums their slots wave-parallel */
     size_t rgbc;                /* float4[P]  SH colour of every Gaussian (r, g, b, clamp bits) when the views share a camera

@@ -50,7 +50,8 @@ __device__ __forceinline__ void slot_sum(const float4* __restrict__ part, const 
     }
 }
 
-// Pairs with more than 32 instance slots (footprints of more than 32 tiles: splats close to the camera) are NOT summed by their
+// Pairs with more than 32 instance slots (footprints of more than 32 tiles: splats close to the camera; k_emit tags their
+// slot_pair entries with bit 31, so phase 1 does not even read their partials) are NOT summed by their
 // owner thread — a serial chain of up to a whole image's tiles, 375 us of this kernel on the uniform stress cloud whose nearest
 // splats cover 256 tiles — but by a whole wave in a second phase of the same launch: lane l adds slots l, l + 64, ... of the
 // pair (rectangle order), then a fixed shuffle tree.  k_emit lists those pairs (header[4] of them, any order: each pair's sum is
@@ -73,13 +74,15 @@ __global__ __launch_bounds__(S360_BLOCK) void k_gather_slots(uint32_t cap, const
         uint32_t p = 0xFFFFFFFFu;
         if (i < L) {
             p = slot_pair[i];
-            slot_sum(part, valid_words, i, s);
+            if (!(p >> 31)) {    // (bit 31: a slot of a pair with more than 32 of them — phase 2 reads it, not this thread)
+                slot_sum(part, valid_words, i, s);
 #pragma unroll
-            for (int k = 0; k < 10; ++k) s_val[tid][k] = s[k];
+                for (int k = 0; k < 10; ++k) s_val[tid][k] = s[k];
+            }
         }
         s_pair[tid] = p;
         __syncthreads();
-        bool owner = i < L && (tid == 0 ? (i == 0 || slot_pair[i - 1] != p) : s_pair[tid - 1] != p);
+        bool owner = i < L && !(p >> 31) && (tid == 0 ? (i == 0 || slot_pair[i - 1] != p) : s_pair[tid - 1] != p);
         if (owner) {
             for (uint32_t j = i + 1; j < L; ++j) {  // the pair's remaining slots, in slot order
                 const uint32_t tj = j - i0;

@@ -1011,6 +1011,8 @@ __global__ __launch_bounds__(S360_BLOCK) void k_emit(KParams kp, const uint32_t*
                 if (slot_pair && k < kp.cap / 32u + 1u) long_pairs[k] = p;
             }
         }
+        // (slot_pair: bit 31 marks the slots of a pair with more than 32 of them — k_gather_slots' slot-parallel pass skips those)
+        const uint32_t ptag = p | (tt[j] > 32u ? 0x80000000u : 0u);
         if (tt[j] && !wide) {
             const int minx = rlo[j] & 0xFFFFu, miny = rlo[j] >> 16, maxx = rhi[j] & 0xFFFFu, maxy = rhi[j] >> 16;
             const uint64_t key = ((uint64_t)dbits[j] << 32) | (uint64_t)p;
@@ -1023,7 +1025,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_emit(KParams kp, const uint32_t*
                                                      : tile_start[tb + t] + atomicAdd(&tile_cursor[tb + t], 1u);
                         if (pos < kp.cap) keys[pos] = key;
                         if (slot_pair) {
-                            if (slot < kp.cap) slot_pair[slot] = p;
+                            if (slot < kp.cap) slot_pair[slot] = ptag;
                             ++slot;
                         }
                     }
@@ -1043,7 +1045,7 @@ __global__ __launch_bounds__(S360_BLOCK) void k_emit(KParams kp, const uint32_t*
                     const uint32_t pos = LDS_BIN ? base[t] + atomicAdd(&cnt[t], 1u)
                                                  : tile_start[tb + t] + atomicAdd(&tile_cursor[tb + t], 1u);
                     if (pos < kp.cap) keys[pos] = key;
-                    if (slot_pair && s0 + (uint32_t)i < kp.cap) slot_pair[s0 + (uint32_t)i] = ps;
+                    if (slot_pair && s0 + (uint32_t)i < kp.cap) slot_pair[s0 + (uint32_t)i] = ps | 0x80000000u;
                 }
             }
         }
@@ -2286,6 +2288,7 @@ static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a
 extern "C" int s360_layout(const S360Params* prm, S360Layout* out) {
     if (!prm || !out) return S360_E_BADARG;
     if (prm->P < 0 || prm->V < 1 || prm->V > S360_MAX_VIEWS || prm->H < 1 || prm->W < 1) return S360_E_BADARG;
+    if ((uint64_t)prm->V * (uint64_t)prm->P >= (1ull << 31)) return S360_E_BADARG;   // pair indices carry a tag in bit 31 (slot_pair)
     const size_t np = (size_t)prm->V * (size_t)(prm->P > 0 ? prm->P : 1);
     const size_t gx = (prm->W + 15) / 16, gy = (prm->H + 15) / 16;
     const size_t nt = (size_t)prm->V * gx * gy;

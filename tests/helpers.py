@@ -80,4 +80,6 @@ def check_instance_slots(slot_base, slot_pair, tiles_touched, L):
     b, n = base[vis][order], tt[vis][order]
     assert b[0] == 0 and (b[1:] == (b + n)[:-1]).all() and (b + n)[-1] == L
     owner = np.repeat(vis[order], n)
-    np.testing.assert_array_equal(np.asarray(slot_pair).reshape(-1)[:L].astype(np.int64) & 0xFFFFFFFF, owner)
+    sp = np.asarray(slot_pair).reshape(-1)[:L].astype(np.int64) & 0xFFFFFFFF
+    np.testing.assert_array_equal(sp & 0x7FFFFFFF, owner)
+    np.testing.assert_array_equal(sp >> 31, (tt[owner] > 32).astype(np.int64))      # bit 31: a slot of a pair that owns more than 32

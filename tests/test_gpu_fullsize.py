@@ -39,7 +39,7 @@ def test_binning_invariants_and_sortedness_at_1m(gpu, big):
     b, n = base[vis][order], tt[vis][order]
     assert int(b[0]) == 0 and torch.equal(b[1:], (b + n)[:-1]) and int((b + n)[-1]) == L
     owner = torch.repeat_interleave(torch.nonzero(vis).view(-1)[order], n)
-    assert torch.equal(owner.to(torch.int32), t["slot_pair"][:L])
+    assert torch.equal(owner.to(torch.int32), t["slot_pair"][:L] & 0x7FFFFFFF)       # (bit 31: slots of pairs owning more than 32)
     ts = t["tile_start"].to(torch.int64)
     assert int(ts[0]) == 0 and int(ts[-1]) == L and bool((ts[1:] >= ts[:-1]).all())
     assert torch.equal(ts[1:] - ts[:-1], t["tile_count"].to(torch.int64))
