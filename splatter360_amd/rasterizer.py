@@ -203,7 +203,7 @@ def coop_decision(key, mode=None) -> bool:
     return m is not None and int(m[2]) >= AUTO_COOP_MIN_PAIRS
 
 
-AUTO_SPLIT_MAX_WAVES = 12288     # "auto": only where the (tile, quadrant) waves of a call fill the chip at most twice (6 144 resident waves)
+AUTO_SPLIT_MAX_WAVES = 24576     # "auto": only where the (tile, quadrant) waves of a call fill the chip at most four times (6 144 resident waves)
 
 
 def split_decision(key, mode, quadrant_waves: int = 0) -> bool:
@@ -211,7 +211,8 @@ def split_decision(key, mode, quadrant_waves: int = 0) -> bool:
     call of the last 16 reported (through word 1 of the pinned mirror, a plain host read) a quadrant worth splitting, and only for
     calls of at most AUTO_SPLIT_MAX_WAVES quadrant waves: the segment work runs in a second launch, i.e. after ALL tile workgroups —
     at BASELINE configs[4]'s shape (4 M Gaussians, six 512x512 faces: 24 576 waves, four rounds of residency) a long list already
-    overlaps with three rounds of other tiles and splitting measured 837 vs 792 us forward, 567 vs 593 us backward: nothing."""
+    overlaps with three rounds of other tiles and splitting still measures 768 vs 792 us forward, 570 vs 593 us backward (1 % of
+    the step); beyond that shape nothing was measured and the flag stays off."""
     if mode is True or mode is False:
         return mode
     if quadrant_waves > AUTO_SPLIT_MAX_WAVES:
