@@ -48,9 +48,10 @@ def test_split_flag_is_adaptive_by_default_and_can_be_forced():
     assert R.split_decision(key, "auto") is False
     R._MIRRORS[key][1] = 1
     assert R.split_decision(key, "auto") is True
-    # calls whose (tile, quadrant) waves fill the chip more than twice never split adaptively (second launch = after ALL tiles)
+    # calls whose (tile, quadrant) waves fill the chip more than four times never split adaptively (second launch = after ALL tiles)
     R._MIRRORS[key][1] = 1
-    assert R.split_decision(key, "auto", quadrant_waves=24576) is False and R.split_decision(key, True, quadrant_waves=24576) is True
+    big = R.AUTO_SPLIT_MAX_WAVES + 4     # beyond the largest shape splitting was measured to pay at (4 M Gaussians, six 512^2 faces)
+    assert R.split_decision(key, "auto", quadrant_waves=big) is False and R.split_decision(key, True, quadrant_waves=big) is True
 
 
 def test_coop_walk_follows_the_wide_rectangle_count_of_the_previous_call():
