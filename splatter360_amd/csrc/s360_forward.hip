@@ -780,6 +780,13 @@ constexpr uint32_t SORT_SHORT = 2048;
 constexpr uint32_t SORT_CHUNK = 8 * SORT_THREADS;
 static_assert(SORT_SHORT % SORT_THREADS == 0 && SORT_SHORT <= SORT_CHUNK, "short lists: SORT_SHORT / SORT_THREADS keys per thread");
 constexpr uint32_t MAX_PASSES = 4;
+__device__ __forceinline__ uint32_t ceil_log2_u32(uint32_t x) { return x <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(x - 1); }
+// Lists of 2 .. LDSM_CHUNKS chunks (up to 16 384 keys: every long list of the encoder-like cloud, most of the surface-like one's) are
+// finished by ONE workgroup in LDS (merge_tile_lds: 128 KB of keys + padding, two in-LDS merge passes) — ONE write step after the chunk
+// sorts, so they count as one pass in the ping-pong parity; longer lists take ceil(log2 chunks) global merge passes.
+constexpr uint32_t LDSM_CHUNKS = 4;
+constexpr int LDSM_E = 32;   // outputs per thread and pass: SORT_THREADS * LDSM_E == LDSM_CHUNKS * SORT_CHUNK
+__device__ __forceinline__ uint32_t merge_passes_of(uint32_t nch) { return nch <= 1 ? 0u : nch <= LDSM_CHUNKS ? 1u : ceil_log2_u32(nch); }
 
 // S360_FLAG_SPLIT_LISTS state (S360Layout part_* / seg_*), by value into the composites
 struct SegBufs {
@@ -843,7 +850,7 @@ __global__ __launch_bounds__(TS_BLOCK) void k_tile_scan(const uint32_t* __restri
         {   // merge passes the longest (capacity-clamped) list needs: k_merge_all enters no pass beyond it
             const uint32_t nmax = min(lds_max, cap);
             const uint32_t nch = nmax > SORT_SHORT ? (nmax + SORT_CHUNK - 1) / SORT_CHUNK : 0u;
-            header[3] = nch <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(nch - 1);
+            header[3] = merge_passes_of(nch);
         }
         header[4] = 0;                        // pairs with more than 32 instance slots (k_emit counts and lists them)
         // S360_FLAG_SPLIT_LISTS: the segment-state pointers, parked in the header for k_render — which takes ONE pointer to them and
@@ -1156,7 +1163,7 @@ __device__ __forceinline__ void block_merge_sort(const uint64_t* __restrict__ in
 // search over chunk_start[].  A tile with c chunks needs P = ceil(log2 c) merge passes; it ping-pongs between
 // `keys` and `alt` such that the LAST pass lands in `keys`: the buffer holding the runs before pass i is
 // `alt` when (P - i) is odd.  Tiles needing more than max_passes passes are left to the global-memory network (sort_tiles_global_body).
-__device__ __forceinline__ uint32_t ceil_log2_u32(uint32_t x) { return x <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(x - 1); }
+
 
 struct ChunkUnit {
     uint32_t s, n, k, passes, t;  // tile start (clamped), tile length, chunk index inside the tile, merge passes of the tile, tile
@@ -1185,7 +1192,7 @@ __device__ __forceinline__ ChunkUnit chunk_unit(const uint32_t* __restrict__ til
     u.n = min(tile_start[lo + 1], cap) - u.s;
     u.k = b - chunk_start[lo];
     u.t = (uint32_t)lo;
-    u.passes = ceil_log2_u32((u.n + SORT_CHUNK - 1) / SORT_CHUNK);
+    u.passes = merge_passes_of((u.n + SORT_CHUNK - 1) / SORT_CHUNK);
     return u;
 }
 
@@ -1264,7 +1271,8 @@ __device__ __forceinline__ uint32_t merge_path_global_wave(const uint64_t* __res
 // (what the longest list of THIS call needs) get no tickets; lists beyond SORT_CHUNK << max_passes keys fall through to the
 // global-memory network at the end of the same launch.
 #ifndef S360_MERGE_GRID
-#define S360_MERGE_GRID 1024
+#define S360_MERGE_GRID 256   // one workgroup per CU: the kernel's 135 KB of LDS (merge_tile_lds) admit no more, and workgroups beyond
+                              // the resident ones would each be dispatched, take one void ticket and exit — three more rounds (1 024: +9 us)
 #endif
 __device__ __forceinline__ void merge_unit(const ChunkUnit& u, uint32_t pass, const uint64_t* __restrict__ keys_c, uint64_t* __restrict__ keys,
                                            uint64_t* __restrict__ alt, uint32_t* __restrict__ list, uint64_t* lds_m, uint32_t* s_part) {
@@ -1288,7 +1296,19 @@ __device__ __forceinline__ void merge_unit(const ChunkUnit& u, uint32_t pass, co
     __syncthreads();
     const uint32_t a0 = s_part[0], a1 = s_part[1], b0 = o - a0, b1 = o + len - a1;
     const uint32_t na = a1 - a0, nb = b1 - b0;  // na + nb == len
-    for (uint32_t i = threadIdx.x; i < len; i += THREADS) lds_m[S360_PHYS(i)] = ld_dev(i < na ? A + (a0 + i) : B + (b0 + (i - na)));
+    {   // the thread's E device-coherent loads in flight together (as a load-then-store loop: E dependent round trips)
+        uint64_t kin[E];
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+            const uint32_t i = (uint32_t)threadIdx.x + (uint32_t)q * THREADS;
+            kin[q] = i < len ? ld_dev(i < na ? A + (a0 + i) : B + (b0 + (i - na))) : 0ull;
+        }
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+            const uint32_t i = (uint32_t)threadIdx.x + (uint32_t)q * THREADS;
+            if (i < len) lds_m[S360_PHYS(i)] = kin[q];
+        }
+    }
     __syncthreads();
     // in-LDS merge of the two pieces: logical run A = [0, na), run B = [na, na + nb)
     const uint32_t out0 = (uint32_t)threadIdx.x * E;
@@ -1318,6 +1338,75 @@ __device__ __forceinline__ void merge_unit(const ChunkUnit& u, uint32_t pass, co
                 if (last_pass) lst[out0 + q] = (uint32_t)kq;
             }
         }
+    }
+#undef S360_PHYS
+}
+
+// Whole-list merge in LDS for a tile of 2 .. LDSM_CHUNKS sorted chunks (n <= 16 384 keys): ONE workgroup loads the chunk-sorted runs
+// (written by k_sort_stage1, the previous launch: plain loads), merges neighbouring runs in LDS until one remains — every thread finds
+// its LDSM_E consecutive outputs with a merge-path binary search and merges them serially into registers, barrier, write back — and
+// stores the sorted keys and the list.  Replaces two global merge passes (each: two 64-ary searches with device-coherent loads, a
+// 4 096-key LDS merge, write-through stores, a drain and a counter another workgroup polls: ~15 us a pass, 3 % VALU-busy) by ~10 us of
+// one workgroup's time with no cross-workgroup traffic at all.  Runs may be ragged (the last one short or missing).
+static_assert(SORT_THREADS * LDSM_E == (int)(LDSM_CHUNKS * SORT_CHUNK), "a thread merges LDSM_E outputs per pass");
+constexpr size_t LDSM_LDS_BYTES = (size_t)(LDSM_CHUNKS * SORT_CHUNK + LDSM_CHUNKS * SORT_CHUNK / LDSM_E) * 8;   // one pad slot per LDSM_E keys
+__device__ __forceinline__ void merge_tile_lds(uint32_t n, const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, uint32_t* __restrict__ lst,
+                                               uint64_t* lds_m) {
+    constexpr int E = LDSM_E;
+#define S360_PHYS(i) ((i) + (i) / E)
+    {   // all of a thread's (up to E) loads in flight at once: a load-then-store loop pays the memory latency per iteration (27 x ~0.7 us)
+        uint64_t k[E];
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+            const uint32_t i = (uint32_t)threadIdx.x + (uint32_t)q * SORT_THREADS;
+            k[q] = i < n ? src[i] : 0ull;
+        }
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+            const uint32_t i = (uint32_t)threadIdx.x + (uint32_t)q * SORT_THREADS;
+            if (i < n) lds_m[S360_PHYS(i)] = k[q];
+        }
+    }
+    __syncthreads();
+    const uint32_t out0 = (uint32_t)threadIdx.x * E;
+    for (uint32_t width = SORT_CHUNK; width < n; width <<= 1) {
+        uint64_t k[E];
+        if (out0 < n) {   // (threads past the end only take part in the barriers)
+            const uint32_t pa = out0 / (2 * width) * (2 * width), pb = pa + width;
+            const uint32_t la = min(width, n - pa), lb = pb < n ? min(width, n - pb) : 0u;
+            const uint32_t diag = out0 - pa;
+            uint32_t lo = diag > lb ? diag - lb : 0u, hi = diag < la ? diag : la;
+            while (lo < hi) {   // merge path: first a with A[a] > B[diag - 1 - a]
+                const uint32_t mid = (lo + hi) >> 1;
+                if (lds_m[S360_PHYS(pa + mid)] <= lds_m[S360_PHYS(pb + (diag - 1 - mid))]) lo = mid + 1; else hi = mid;
+            }
+            uint32_t a = lo, b = diag - lo;
+            uint64_t ka = a < la ? lds_m[S360_PHYS(pa + a)] : ~0ull, kb = b < lb ? lds_m[S360_PHYS(pb + b)] : ~0ull;
+#pragma unroll
+            for (int q = 0; q < E; ++q) {
+                const bool take_a = ka <= kb;
+                k[q] = take_a ? ka : kb;
+                if (take_a) {
+                    ++a;
+                    ka = a < la ? lds_m[S360_PHYS(pa + a)] : ~0ull;
+                } else {
+                    ++b;
+                    kb = b < lb ? lds_m[S360_PHYS(pb + b)] : ~0ull;
+                }
+            }
+        }
+        __syncthreads();          // every read of this pass precedes its writes
+        if (out0 < n) {
+#pragma unroll
+            for (int q = 0; q < E; ++q)
+                if (out0 + q < n) lds_m[S360_PHYS(out0 + q)] = k[q];
+        }
+        __syncthreads();
+    }
+    for (uint32_t i = threadIdx.x; i < n; i += SORT_THREADS) {
+        const uint64_t kq = lds_m[S360_PHYS(i)];
+        dst[i] = kq;
+        lst[i] = (uint32_t)kq;
     }
 #undef S360_PHYS
 }
@@ -1376,7 +1465,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_merge_all(const uint32_t* __re
                                                   uint32_t* __restrict__ list, uint32_t cap, uint32_t max_passes,
                                                   const uint32_t* __restrict__ header, uint32_t* __restrict__ merge_done,
                                                   uint32_t global_lo) {
-    extern __shared__ __attribute__((aligned(16))) uint64_t lds_m[];  // [SORT_CHUNK + SORT_CHUNK/E] skewed
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds_m[];  // LDSM_LDS_BYTES: [SORT_CHUNK + SORT_CHUNK/E] skewed for the pair merges, the whole list for merge_tile_lds
     __shared__ uint32_t s_part[2];
     __shared__ uint32_t s_ticket;
     const uint32_t npass = min(header[3], max_passes);   // merge passes the longest (capacity-clamped) list of this call needs
@@ -1393,6 +1482,10 @@ __global__ __launch_bounds__(SORT_THREADS) void k_merge_all(const uint32_t* __re
         const ChunkUnit u = chunk_unit(tile_start, chunk_start, nt, cap, blk);
         if (!u.valid || u.passes > max_passes || pass >= u.passes) continue;  // block-uniform
         const uint32_t nch = (u.n + SORT_CHUNK - 1) / SORT_CHUNK;
+        if (nch <= LDSM_CHUNKS) {   // (one pass by merge_passes_of: only pass 0 gets here) the whole list, by the unit of its first chunk
+            if (u.k == 0) merge_tile_lds(u.n, alt + u.s, keys + u.s, list + u.s, lds_m);
+            continue;               // (the barrier behind the next ticket separates this unit's LDS reads from the next one's writes)
+        }
         if (pass > 0) {
             if (threadIdx.x == 0) {
                 while (__hip_atomic_load(&merge_done[(size_t)u.t * MAX_PASSES + pass - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nch)
@@ -2537,7 +2630,16 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
             // counters; passes no list of the call needs are never entered, the global-memory fallback runs in the same launch
             if (passes > 0) {
                 const unsigned mgrid = cgrid < (unsigned)S360_MERGE_GRID ? cgrid : (unsigned)S360_MERGE_GRID;
-                hipLaunchKernelGGL(k_merge_all, dim3(mgrid), dim3(SORT_THREADS), lds512, st, tile_start, chunk_start, nt, keys, keys_alt, list,
+                {   // 135 KB of dynamic LDS needs the opt-in, once per device (idempotent: a race sets it twice)
+                    static bool attr_done[64] = {};
+                    int dev = 0;
+                    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !attr_done[dev]) {
+                        (void)hipFuncSetAttribute((const void*)k_merge_all, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDSM_LDS_BYTES);
+                        (void)hipGetLastError();
+                        attr_done[dev] = true;
+                    }
+                }
+                hipLaunchKernelGGL(k_merge_all, dim3(mgrid), dim3(SORT_THREADS), LDSM_LDS_BYTES, st, tile_start, chunk_start, nt, keys, keys_alt, list,
                                    kp.cap, passes, header, (uint32_t*)(ws + L.merge_done), (size_t)global_lo < cap_keys ? global_lo : 0xFFFFFFFFu);
             }
         }

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 SORT_SHORT, SORT_CHUNK, MAX_PASSES, E, THREADS = 2048, 4096, 4, 8, 512
+LDSM_CHUNKS, LDSM_E = 4, 32          # lists of 2..4 chunks: ONE workgroup merges the whole list in LDS (merge_tile_lds)
 
 
 def ceil_log2(x):
@@ -33,11 +34,51 @@ def merge_path_wave(A, la, B, lb, d):
     return lo
 
 
+def merge_passes_of(nch):
+    return 0 if nch <= 1 else 1 if nch <= LDSM_CHUNKS else ceil_log2(nch)
+
+
+def merge_tile_lds_model(src, n):
+    """merge_tile_lds: in-LDS merge of the 4 096-key sorted runs of a list of n <= 16 384 keys, ragged last run included; every
+    thread produces LDSM_E consecutive outputs per pass from a merge-path binary search."""
+    INF = np.uint64(0xFFFFFFFFFFFFFFFF)
+    lds = np.array(src[:n], dtype=np.uint64)
+    width = SORT_CHUNK
+    while width < n:
+        out = lds.copy()
+        for t in range(THREADS):
+            out0 = t * LDSM_E
+            if out0 >= n:
+                break
+            pa = out0 // (2 * width) * (2 * width)
+            pb = pa + width
+            la, lb = min(width, n - pa), (min(width, n - pb) if pb < n else 0)
+            diag = out0 - pa
+            lo, hi = max(diag - lb, 0), min(diag, la)
+            while lo < hi:
+                mid = (lo + hi) >> 1
+                if lds[pa + mid] <= lds[pb + diag - 1 - mid]:
+                    lo = mid + 1
+                else:
+                    hi = mid
+            a, b = lo, diag - lo
+            for q in range(LDSM_E):
+                ka = lds[pa + a] if a < la else INF
+                kb = lds[pb + b] if b < lb else INF
+                take_a = ka <= kb
+                if out0 + q < n:
+                    out[out0 + q] = ka if take_a else kb
+                a, b = (a + 1, b) if take_a else (a, b + 1)
+        lds = out
+        width <<= 1
+    return lds
+
+
 def sort_tile_model(keys_in):
     n = len(keys_in)
     assert n > SORT_SHORT
     nch = (n + SORT_CHUNK - 1) // SORT_CHUNK
-    passes = ceil_log2(nch)
+    passes = merge_passes_of(nch)
     assert passes <= MAX_PASSES
     bufs = [np.array(keys_in, dtype=np.uint64), np.zeros(n, np.uint64)]     # 0 = keys, 1 = alt
     lst = np.zeros(n, np.uint32)
@@ -47,7 +88,12 @@ def sort_tile_model(keys_in):
         bufs[passes & 1][c0:c0 + ln] = np.sort(src0[c0:c0 + ln])
         if passes == 0:
             lst[c0:c0 + ln] = (bufs[0][c0:c0 + ln] & np.uint64(0xFFFFFFFF)).astype(np.uint32)
-    for p in range(passes):                                                 # k_merge_pass launches
+    if 2 <= nch <= LDSM_CHUNKS:                                             # k_merge_all, whole-list unit: alt -> keys, one write step
+        assert passes == 1
+        res = merge_tile_lds_model(bufs[1], n)
+        bufs[0][:] = res
+        return bufs[0], (res & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    for p in range(passes):                                                 # k_merge_all, (pass, chunk) units
         R = SORT_CHUNK << p
         src, dst = bufs[(passes - p) & 1], bufs[(passes - p - 1) & 1]
         out = dst.copy()
@@ -90,7 +136,7 @@ def sort_tile_model(keys_in):
     return bufs[0], lst
 
 
-@pytest.mark.parametrize("n", [2049, 4096, 4097, 8192, 8193, 12288, 16384, 20001, 32768, 32769, 65535, 65536])
+@pytest.mark.parametrize("n", [2049, 4096, 4097, 8192, 8193, 9000, 12288, 12289, 13751, 16383, 16384, 16385, 20001, 32768, 32769, 65535, 65536])
 def test_chunk_and_merge_pass_arithmetic(n):
     rng = np.random.default_rng(n)
     depth = rng.integers(0, 1 << 20, n).astype(np.uint64)          # many equal depths: ties are broken by the low word
