@@ -1111,35 +1111,44 @@ __device__ __forceinline__ void block_merge_sort(const uint64_t* __restrict__ in
     // entirely in the padding (start >= n) never need merging, so stop once width covers n.
     uint32_t npad = E;
     while (npad < n) npad <<= 1;
+    // A thread whose E outputs all lie at or beyond n would merge padding into padding: every position >= n holds +inf from the
+    // load above and keeps it (the real keys of a pair sort in front of its padding), so such a thread only takes part in the
+    // barriers — whole waves of a 1 456-key list (the mean) in a 2 048-key capacity skip the search and the merge: a quarter of the
+    // stage's instructions.
+    const uint32_t out0 = (uint32_t)tid * E;                      // first output element of this thread
+    const bool live = out0 < n;
     for (uint32_t width = E; width < npad; width <<= 1) {
-        const uint32_t out0 = (uint32_t)tid * E;                  // first output element of this thread
         const uint32_t pair = out0 / (2 * width) * (2 * width);   // start of the run pair
         const uint32_t pa = pair, pb = pair + width;              // run starts (logical indices)
 #define S360_A(x) lds_m[S360_PHYS(pa + (x))]
 #define S360_B(x) lds_m[S360_PHYS(pb + (x))]
-        const uint32_t diag = out0 - pair;
-        uint32_t lo_a = diag > width ? diag - width : 0u, hi_a = diag < width ? diag : width;
-        while (lo_a < hi_a) {  // merge path: first a with A[a] > B[diag-1-a]
-            const uint32_t mid = (lo_a + hi_a) >> 1;
-            if (S360_A(mid) <= S360_B(diag - 1 - mid)) lo_a = mid + 1; else hi_a = mid;
-        }
-        uint32_t a = lo_a, b = diag - lo_a;
-        uint64_t ka = a < width ? S360_A(a) : ~0ull, kb = b < width ? S360_B(b) : ~0ull;
+        if (live) {
+            const uint32_t diag = out0 - pair;
+            uint32_t lo_a = diag > width ? diag - width : 0u, hi_a = diag < width ? diag : width;
+            while (lo_a < hi_a) {  // merge path: first a with A[a] > B[diag-1-a]
+                const uint32_t mid = (lo_a + hi_a) >> 1;
+                if (S360_A(mid) <= S360_B(diag - 1 - mid)) lo_a = mid + 1; else hi_a = mid;
+            }
+            uint32_t a = lo_a, b = diag - lo_a;
+            uint64_t ka = a < width ? S360_A(a) : ~0ull, kb = b < width ? S360_B(b) : ~0ull;
 #pragma unroll
-        for (int q = 0; q < E; ++q) {
-            const bool take_a = ka <= kb;
-            k[q] = take_a ? ka : kb;
-            if (take_a) {
-                ++a;
-                ka = a < width ? S360_A(a) : ~0ull;
-            } else {
-                ++b;
-                kb = b < width ? S360_B(b) : ~0ull;
+            for (int q = 0; q < E; ++q) {
+                const bool take_a = ka <= kb;
+                k[q] = take_a ? ka : kb;
+                if (take_a) {
+                    ++a;
+                    ka = a < width ? S360_A(a) : ~0ull;
+                } else {
+                    ++b;
+                    kb = b < width ? S360_B(b) : ~0ull;
+                }
             }
         }
         S360_SORT_SYNC(width);          // every read of this pass precedes its writes
+        if (live) {
 #pragma unroll
-        for (int q = 0; q < E; ++q) lds_m[S360_PHYS(out0 + q)] = k[q];
+            for (int q = 0; q < E; ++q) lds_m[S360_PHYS(out0 + q)] = k[q];
+        }
         S360_SORT_SYNC(2u * width);     // ... which the NEXT pass (runs of 2 * width, pairs of 4 * width) reads
 #undef S360_A
 #undef S360_B
@@ -1403,10 +1412,21 @@ __device__ __forceinline__ void merge_tile_lds(uint32_t n, const uint64_t* __res
         }
         __syncthreads();
     }
-    for (uint32_t i = threadIdx.x; i < n; i += SORT_THREADS) {
-        const uint64_t kq = lds_m[S360_PHYS(i)];
-        dst[i] = kq;
-        lst[i] = (uint32_t)kq;
+    {   // (LDS reads batched like the loads above: as a read-then-store loop every iteration waits for its own LDS read)
+        uint64_t k[E];
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+            const uint32_t i = (uint32_t)threadIdx.x + (uint32_t)q * SORT_THREADS;
+            k[q] = i < n ? lds_m[S360_PHYS(i)] : 0ull;
+        }
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+            const uint32_t i = (uint32_t)threadIdx.x + (uint32_t)q * SORT_THREADS;
+            if (i < n) {
+                dst[i] = k[q];
+                lst[i] = (uint32_t)k[q];
+            }
+        }
     }
 #undef S360_PHYS
 }
