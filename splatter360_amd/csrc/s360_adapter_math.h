@@ -75,4 +75,68 @@ __device__ __forceinline__ void quat_geom(const float* qr, float eps, QuatGeom& 
     g.R[2][0] = a * (i * k - j * r); g.R[2][1] = a * (j * k + i * r); g.R[2][2] = 1.0f - a * (i * i + j * j);
 }
 
+
+// ---- rotate_sh at degree 4 (d_sh = 25) with the view's matrix in SGPRs --------------------------------------------------------------
+// D is the context view's 25 x 25 block-diagonal Wigner-D matrix (row-major) behind a WAVE-UNIFORM global pointer: every entry is a
+// scalar load (s_load_dwordx*) and rides in the multiply-add as its SGPR operand — no LDS broadcast, no vector load.  (Round 5 kept
+// the matrix in LDS and paid one ds_read per multiply-add: 330 LDS instructions per lane in k_raw_eval.)  ROT = false: the identity
+// (rotate_sh skipped: sh_rot == NULL), only the mask is applied.
+//
+// harmonics = D_l (coefficients * sh_mask) per degree (gaussian_adapter_erp.py:86,113; src/misc/sh_rotation.py:10-30):
+//   out[o + a] = sum_b D[o + a][o + b] * (c[o + b] * mask_l),   o = l^2
+// (The matrix is read through the CONSTANT address space: nothing in a launch writes it, and only that tells the compiler so — through
+// a plain global pointer next to the kernels' own stores it emits 165 vector loads of a uniform address instead.)
+typedef const __attribute__((address_space(4))) float* sh_rot_ptr;
+__device__ __forceinline__ sh_rot_ptr sh_rot_const(const float* p) { return (sh_rot_ptr)(uintptr_t)p; }
+
+template <bool ROT>
+__device__ __forceinline__ void sh_rotate_coefs25(const float* Dg, const float* c, float* out) {
+    const sh_rot_ptr D = sh_rot_const(Dg);
+#pragma unroll
+    for (int l = 0; l <= 4; ++l) {
+        const int o = l * l, nl = 2 * l + 1;
+        float cm[9];
+#pragma unroll
+        for (int b = 0; b < nl; ++b) cm[b] = c[o + b] * kShMask[l];
+#pragma unroll
+        for (int a = 0; a < nl; ++a) {
+            if (ROT) {
+                float acc = D[(o + a) * 25 + o] * cm[0];
+#pragma unroll
+                for (int b = 1; b < nl; ++b) acc = __builtin_fmaf(D[(o + a) * 25 + o + b], cm[b], acc);
+                out[o + a] = acc;
+            } else {
+                out[o + a] = cm[a];
+            }
+        }
+    }
+}
+
+// The transpose, for gradients and for carrying a basis vector through the transform:
+//   out[o + b] = mask_l * sum_a D[o + a][o + b] * y[o + a]
+// OWNER / W: only the outputs k with owner(k) == W are computed (the others are left untouched), so that the waves of a workgroup
+// can share one vector's 165 multiply-adds; W < 0: all of them.
+__device__ constexpr int sh_half_owner(int k) { return k >= 16 ? 1 : 2; }   // two waves: degree 4 (81 multiply-adds) | degrees 0..3 (84)
+template <bool ROT, int W>
+__device__ __forceinline__ void sh_rotate_basis25(const float* Dg, const float* y, float* out) {
+    const sh_rot_ptr D = sh_rot_const(Dg);
+#pragma unroll
+    for (int l = 0; l <= 4; ++l) {
+        const int o = l * l, nl = 2 * l + 1;
+#pragma unroll
+        for (int b = 0; b < nl; ++b) {
+            if (W >= 0 && sh_half_owner(o + b) != W) continue;
+            float acc;
+            if (ROT) {
+                acc = D[o * 25 + o + b] * y[o];
+#pragma unroll
+                for (int a = 1; a < nl; ++a) acc = __builtin_fmaf(D[(o + a) * 25 + o + b], y[o + a], acc);
+            } else {
+                acc = y[o + b];
+            }
+            out[o + b] = acc * kShMask[l];
+        }
+    }
+}
+
 }  // namespace s360

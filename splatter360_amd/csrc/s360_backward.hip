@@ -583,61 +583,23 @@ struct RawBwd {
 };
 constexpr int RAWB_C = 82;
 
+// Round 6: workgroups dealt per context view (the view's Wigner-D matrix is wave-uniform: scalar loads, SGPR operands — round 5 read it
+// from LDS, one ds_read per multiply-add, on all three waves redundantly); the rotated masked basis is computed ONCE per Gaussian, its
+// 165 multiply-adds shared by waves 1 and 2 (degree 4 | degrees 0..3) through LDS, while wave 0 runs the geometry chain.
+template <bool ROT>
 __global__ __launch_bounds__(192) void k_raw_bwd(KParams kp, const S360View* __restrict__ views, RawBwd rb) {
     __shared__ __attribute__((aligned(16))) float s_out[64 * RAWB_C];
-    __shared__ float s_D[2 * 628];   // the rotation matrices of the (at most two) context views of this workgroup's Gaussians
+    __shared__ float s_yp[25 * 64];      // (mask . D^T Y)[k] of lane l at [k * 64 + l]
+    __shared__ float4 s_w[64];           // the group's dL/dRGB (0 where the Gaussian is invisible in the group's views)
     const int tid = threadIdx.x, d = tid >> 6, l = tid & 63;
-    const int g0 = blockIdx.x * 64, nb = min(64, kp.P - g0), g = g0 + l;
-    const int v_first = g0 / rb.Gv, v_last = (g0 + nb - 1) / rb.Gv;
-    if (rb.sh_rot) {
-        for (int i = tid; i < 625; i += 192) s_D[i] = rb.sh_rot[(size_t)v_first * 625 + i];
-        if (v_last != v_first)
-            for (int i = tid; i < 625; i += 192) s_D[628 + i] = rb.sh_rot[(size_t)v_last * 625 + i];
-    }
-    __syncthreads();
-    if (g < kp.P) {
-        // ---- colour channel d: sum over the camera groups of (mask . D^T Y(dir_j)) * dL/dRGB_j[d]
-        const float m0 = rb.means[3 * (size_t)g], m1 = rb.means[3 * (size_t)g + 1], m2 = rb.means[3 * (size_t)g + 2];
-        const float* D = rb.sh_rot ? s_D + 628 * (g / rb.Gv - v_first) : nullptr;   // LDS always (never a flat pointer)
-        float acc[25];
-#pragma unroll
-        for (int k = 0; k < 25; ++k) acc[k] = 0.f;
-#pragma unroll 1
-        for (int j = 0; j < rb.n_groups; ++j) {
-            const float4 dr = rb.d_rgb[(size_t)j * kp.P + g];
-            const int fv = __float_as_int(dr.w);
-            if (fv < 0) continue;   // invisible in that group's views
-            const S360View& vw = views[fv];
-            const float sc = vw.scale;
-            const float dx = m0 * sc - vw.campos[0], dy = m1 * sc - vw.campos[1], dz = m2 * sc - vw.campos[2];
-            const float inv = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
-            float Y[25];
-            sh_basis(4, dx * inv, dy * inv, dz * inv, Y);
-            const float w = d == 0 ? dr.x : (d == 1 ? dr.y : dr.z);
-#pragma unroll
-            for (int lq = 0; lq <= 4; ++lq) {   // (mask . D^T Y) * w, accumulated
-                const int o = lq * lq, nl = 2 * lq + 1;
-#pragma unroll
-                for (int b = 0; b < nl; ++b) {
-                    float t;
-                    if (D) {
-                        t = 0.f;
-#pragma unroll
-                        for (int a = 0; a < nl; ++a) t = __builtin_fmaf(D[(o + a) * 25 + o + b], Y[o + a], t);
-                    } else {
-                        t = Y[o + b];
-                    }
-                    acc[o + b] = __builtin_fmaf(t * kShMask[lq], w, acc[o + b]);
-                }
-            }
-        }
-        float* orec = s_out + l * RAWB_C + 7 + 25 * d;
-#pragma unroll
-        for (int k = 0; k < 25; ++k) orec[k] = acc[k];
-    }
-    if (d == 0 && g < kp.P) {
-        // ---- geometry: k_adapter_bwd's chain (scale map, quaternion, covariance), 6-entry covariance gradient
-        const int v = g / rb.Gv, gi = g - v * rb.Gv;
+    const int v = blockIdx.y, gi0 = blockIdx.x * 64;
+    const int nb = min(64, rb.Gv - gi0), g0 = v * rb.Gv + gi0, g = g0 + l;
+    const bool live = l < nb;
+    const float* D = ROT ? rb.sh_rot + (size_t)v * 625 : nullptr;   // wave-uniform
+    if (d == 0 && live) {
+        // ---- geometry: k_adapter_bwd's chain (scale map, quaternion, covariance), 6-entry covariance gradient — wave 0, while waves 1
+        // and 2 rotate the basis
+        const int gi = gi0 + l;
         const float* E = rb.extrinsics + 16 * v;
         const float* rw = rb.geo7 + 7 * (size_t)g;
         const float depth = rb.depths[g];
@@ -720,6 +682,53 @@ __global__ __launch_bounds__(192) void k_raw_bwd(KParams kp, const S360View* __r
             for (int x = 0; x < 3; ++x) dd += (E[x] * gm[0] + E[4 + x] * gm[1] + E[8 + x] * gm[2]) * dir[x];
         }
         rb.d_depths[g] = dd;
+    }
+    {
+        // ---- colour channel d: sum over the camera groups of (mask . D^T Y(dir_j)) * dL/dRGB_j[d]
+        float m0 = 0.f, m1 = 0.f, m2 = 1.f;
+        if (live && d >= 1) { m0 = rb.means[3 * (size_t)g]; m1 = rb.means[3 * (size_t)g + 1]; m2 = rb.means[3 * (size_t)g + 2]; }
+        float acc[25];
+#pragma unroll
+        for (int k = 0; k < 25; ++k) acc[k] = 0.f;
+#pragma unroll 1
+        for (int j = 0; j < rb.n_groups; ++j) {
+            if (j > 0) __syncthreads();   // the previous group's s_yp / s_w were read
+            if (d >= 1) {
+                float4 dr = make_float4(0.f, 0.f, 0.f, 0.f);
+                int fv = 0;
+                if (live) {
+                    dr = rb.d_rgb[(size_t)j * kp.P + g];
+                    fv = __float_as_int(dr.w);
+                    if (fv < 0) { fv = 0; dr = make_float4(0.f, 0.f, 0.f, 0.f); }   // invisible in that group's views: contributes 0
+                }
+                const S360View& vw = views[fv];
+                const float sc = vw.scale;
+                const float dx = m0 * sc - vw.campos[0], dy = m1 * sc - vw.campos[1], dz = m2 * sc - vw.campos[2];
+                const float inv = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
+                float Y[25], Yp[25];
+                sh_basis(4, dx * inv, dy * inv, dz * inv, Y);
+                if (d == 1) {
+                    sh_rotate_basis25<ROT, 1>(D, Y, Yp);
+#pragma unroll
+                    for (int k = 16; k < 25; ++k) s_yp[k * 64 + l] = Yp[k];
+                    s_w[l] = dr;
+                } else {
+                    sh_rotate_basis25<ROT, 2>(D, Y, Yp);
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) s_yp[k * 64 + l] = Yp[k];
+                }
+            }
+            __syncthreads();
+            const float4 dr = s_w[l];
+            const float w = d == 0 ? dr.x : (d == 1 ? dr.y : dr.z);
+#pragma unroll
+            for (int k = 0; k < 25; ++k) acc[k] = __builtin_fmaf(s_yp[k * 64 + l], w, acc[k]);
+        }
+        if (live) {
+            float* orec = s_out + l * RAWB_C + 7 + 25 * d;
+#pragma unroll
+            for (int k = 0; k < 25; ++k) orec[k] = acc[k];
+        }
     }
     __syncthreads();
     const int nfl = nb * RAWB_C;
@@ -1159,7 +1168,9 @@ extern "C" int s360_backward_raw(const S360Params* prm, const S360View* views, c
               raw->per_view > 0 ? raw->per_view : 1, raw->H, raw->W, raw->per_ray, raw->erp_convention, 1, raw->scale_min, raw->scale_max, raw->eps};
     {
         ProfScope ps(PS_SH_BWD, (hipStream_t)stream_);
-        hipLaunchKernelGGL(k_raw_bwd, dim3((prm->P + 63) / 64), dim3(192), 0, (hipStream_t)stream_, kp, views, rb);
+        const dim3 bgrid((rb.Gv + 63) / 64, (unsigned)(prm->P / rb.Gv));   // per context view: its rotation matrix is wave-uniform
+        if (rb.sh_rot) hipLaunchKernelGGL(k_raw_bwd<true>, bgrid, dim3(192), 0, (hipStream_t)stream_, kp, views, rb);
+        else hipLaunchKernelGGL(k_raw_bwd<false>, bgrid, dim3(192), 0, (hipStream_t)stream_, kp, views, rb);
     }
     S360_CHECK_LAUNCH();
     return S360_OK;

@@ -300,51 +300,29 @@ struct RawIn {
 };
 constexpr int RAW_C = 82;   // 7 + 3 * 25 floats per raw record
 
-// Y'[k] = mask_l * sum_a D[o+a][o+k] Y[o+a]  (D^T applied per degree block; D == null: the masked basis itself)
-__device__ __forceinline__ void raw_rotate_basis(const float* __restrict__ D, const float* Y, float* Yp) {
-#pragma unroll
-    for (int l = 0; l <= 4; ++l) {
-        const int o = l * l, nl = 2 * l + 1;
-#pragma unroll
-        for (int b = 0; b < nl; ++b) {
-            float acc;
-            if (D) {
-                acc = 0.f;
-#pragma unroll
-                for (int a = 0; a < nl; ++a) acc = __builtin_fmaf(D[(o + a) * 25 + o + b], Y[o + a], acc);
-            } else {
-                acc = Y[o + b];
-            }
-            Yp[o + b] = acc * kShMask[l];
-        }
-    }
-}
-
-template <int DC>
-__device__ __forceinline__ void raw_jac_component(float x, float y, float z, const float* __restrict__ D, const float* __restrict__ coef, float* G) {
-    float b0[25], b1[25], b2[25], bp[25];
-    sh_basis_grad(4, x, y, z, b0, b1, b2);
-    raw_rotate_basis(D, DC == 0 ? b0 : (DC == 1 ? b1 : b2), bp);
-    G[0] = G[1] = G[2] = 0.f;
-#pragma unroll
-    for (int k = 0; k < 25; ++k) {
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) G[ch] = __builtin_fmaf(bp[k], coef[25 * ch + k], G[ch]);
-    }
-}
-
-template <bool JAC>
+// Round 6: the transform is applied to the COEFFICIENTS, once per (Gaussian, channel), with the view's matrix in SGPRs
+// (sh_rotate_coefs25: 165 multiply-adds on wave ch, scalar loads of D — the kernel's workgroups are dealt per context view, so D is
+// wave-uniform), written back into the staged record in place; colours and jacobian are then k_sh_eval3_jac's own code on that slab.
+// Round 5 carried the BASIS through the transform instead (mask . D^T Y and the same for the basis derivative: 330 LDS-broadcast
+// multiply-adds per lane on every one of the three waves, 145 us); rotating three coefficient vectors is less work than rotating
+// four basis vectors, and the harmonics — hence colours, sh_jac, images — are now bit-identical to the two-step path's
+// (adapter kernel, then k_sh_eval3_jac).
+template <bool JAC, bool ROT>
 __global__ __launch_bounds__(SHE3_G * 3) void k_raw_eval(KParams kp, const S360View* __restrict__ views, RawIn rin, float4* __restrict__ rgbc,
                                                         float* __restrict__ sh_jac, uint32_t* __restrict__ zero_ptr, int zero_words) {
     __shared__ __attribute__((aligned(16))) float s_raw[7 * SHE3_G * 3 * 4];   // 64 records x 82 floats = 5 248 floats (+ pad to 7 rounds of 192 float4)
-    __shared__ float s_D[2 * 628];        // the rotation matrices of the (at most two) context views of this workgroup's Gaussians
     __shared__ float s_rgb[SHE3_G * 3];
     __shared__ float s_G[9 * SHE3_G];
     __shared__ float4 s_dir[SHE3_G];
-    if ((int)(blockIdx.x * (SHE3_G * 3) + threadIdx.x) < zero_words) zero_ptr[blockIdx.x * (SHE3_G * 3) + threadIdx.x] = 0u;
     const int tid = threadIdx.x;
-    const int g0 = blockIdx.x * SHE3_G;
-    const int nb = min(SHE3_G, kp.P - g0);
+    {
+        const int lin = (int)((blockIdx.y * gridDim.x + blockIdx.x) * (SHE3_G * 3)) + tid;
+        if (lin < zero_words) zero_ptr[lin] = 0u;
+    }
+    const int v = blockIdx.y;                                   // context view: wave-uniform (pose, SH rotation matrix in SGPRs)
+    const int gi0 = blockIdx.x * SHE3_G;                        // first Gaussian of the block inside its view
+    const int nb = min(SHE3_G, rin.Gv - gi0);
+    const int g0 = v * rin.Gv + gi0;
     {
         const float* src = rin.raw + (size_t)g0 * RAW_C;
         const int nfl = nb * RAW_C;
@@ -362,29 +340,19 @@ __global__ __launch_bounds__(SHE3_G * 3) void k_raw_eval(KParams kp, const S360V
             for (int i = tid; i < nfl; i += SHE3_G * 3) s_raw[i] = src[i];
         }
     }
-    // the context view of this workgroup's Gaussians (one view unless the block straddles a view boundary: then per-lane global reads)
-    const int v_first = g0 / rin.Gv, v_last = (g0 + nb - 1) / rin.Gv;
-    const bool one_view = v_first == v_last;
-    if (rin.sh_rot) {
-        for (int i = tid; i < 625; i += SHE3_G * 3) s_D[i] = rin.sh_rot[(size_t)v_first * 625 + i];
-        if (!one_view)
-            for (int i = tid; i < 625; i += SHE3_G * 3) s_D[628 + i] = rin.sh_rot[(size_t)v_last * 625 + i];
-    }
-    // Every wave un-projects its Gaussian's mean itself (~150 instructions, in flight with the staging loads above): letting ONE wave
-    // do the whole geometry in front of a barrier left the other two idle for longer than that (145 us for this kernel); the
-    // covariance chain rides on wave 1 and the raw-geometry copy on wave 2, both behind their colour work.
+    // Every wave un-projects its Gaussian's mean itself (~150 instructions, in flight with the staging loads above); the covariance
+    // chain rides on wave 1 and the raw-geometry copy on wave 2, both behind their colour work.
     const int d = tid >> 6, l = tid & 63;
     const int g = g0 + l;
+    const bool live = l < nb;
     const S360View& vw = views[0];
     const float sc = vw.scale;
     float x = 0.f, y = 0.f, z = 1.f, inv = 0.f, depth = 0.f;
-    const float* E = rin.extrinsics;
-    if (g < kp.P) {
-        const int v = g / rin.Gv, gi = g - v * rin.Gv;
-        E = rin.extrinsics + 16 * v;
+    const float* E = rin.extrinsics + 16 * v;
+    if (live) {
         depth = rin.depths[g];
         float dr[3];
-        erp_dir(gi / rin.per_ray, rin.H, rin.W, rin.conv, dr);
+        erp_dir((gi0 + l) / rin.per_ray, rin.H, rin.W, rin.conv, dr);
         const float p[3] = {dr[0] * depth, dr[1] * depth, dr[2] * depth};
         float mn[3];
 #pragma unroll
@@ -396,32 +364,39 @@ __global__ __launch_bounds__(SHE3_G * 3) void k_raw_eval(KParams kp, const S360V
         inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
         x = dx * inv; y = dy * inv; z = dz * inv;
     }
-    __syncthreads();      // the staged records and the rotation matrices
-    // (the rotation matrix is read from LDS as broadcasts; a workgroup straddling a view boundary — only when a view's Gaussian
-    // count is not a multiple of 64 — takes its views one after the other)
-    if (g < kp.P) {
-        // LDS, always (a pointer that may be LDS or global compiles to flat loads: 305 us for this kernel instead of ~100); a workgroup
-        // that straddles a view boundary holds both views' matrices and every lane takes its own
-        const float* D = rin.sh_rot ? s_D + 628 * (g / rin.Gv - v_first) : nullptr;
-        const float* coef = s_raw + l * RAW_C + 7;    // [3][25] channel-major raw coefficients
-        float Y[25], Yp[25];
+    __syncthreads();      // the staged records
+    float* slab = s_raw + l * RAW_C + 7;     // [3][25] channel-major coefficients of this lane's Gaussian
+    if (live) {
+        // channel d: harmonics = D (mask . raw), the adapter kernel's own expression
+        const float* D = ROT ? rin.sh_rot + (size_t)v * 625 : nullptr;
+        float c[25], h[25];
+#pragma unroll
+        for (int k = 0; k < 25; ++k) c[k] = slab[25 * d + k];
+        sh_rotate_coefs25<ROT>(D, c, h);
+        float Y[25];
         sh_basis(4, x, y, z, Y);
-        raw_rotate_basis(D, Y, Yp);
         float acc = 0.f;
 #pragma unroll
-        for (int k = 0; k < 25; ++k) acc += Yp[k] * coef[25 * d + k];
+        for (int k = 0; k < 25; ++k) acc += Y[k] * h[k];     // k_sh_eval3_jac's sum, term for term
         s_rgb[3 * l + d] = acc + 0.5f;
         if (JAC) {
+#pragma unroll
+            for (int k = 0; k < 25; ++k) slab[25 * d + k] = h[k];   // in place: only wave d ever touched these 25 words
+        }
+    }
+    if (JAC) {
+        __syncthreads();  // the three channels' harmonics
+        if (live) {
             float G[3];
-            if (d == 0) raw_jac_component<0>(x, y, z, D, coef, G);     // wave-uniform: each wave compiles ONE derivative component
-            else if (d == 1) raw_jac_component<1>(x, y, z, D, coef, G);
-            else raw_jac_component<2>(x, y, z, D, coef, G);
+            if (d == 0) sh_jac_component<0>(x, y, z, slab, G);     // wave-uniform: each wave compiles ONE derivative component
+            else if (d == 1) sh_jac_component<1>(x, y, z, slab, G);
+            else sh_jac_component<2>(x, y, z, slab, G);
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) s_G[(3 * ch + d) * SHE3_G + l] = G[ch];
             if (d == 0) s_dir[l] = make_float4(x, y, z, sc * inv);
         }
     }
-    if (d == 1 && g < kp.P) {
+    if (d == 1 && live) {
         // ---- covariance: the adapter tail's own expressions (k_adapter_fwd)
         const float* rw = s_raw + l * RAW_C;
         const float px = 1.0f / (float)max(rin.W, rin.H);
@@ -445,7 +420,7 @@ __global__ __launch_bounds__(SHE3_G * 3) void k_raw_eval(KParams kp, const S360V
         float* oc = rin.cov6_out + 6 * (size_t)g;
         oc[0] = S[0][0]; oc[1] = S[0][1]; oc[2] = S[0][2]; oc[3] = S[1][1]; oc[4] = S[1][2]; oc[5] = S[2][2];
     }
-    if (d == 2 && g < kp.P && rin.geo7) {
+    if (d == 2 && live && rin.geo7) {
         const float* rw = s_raw + l * RAW_C;
         float* o7 = rin.geo7 + 7 * (size_t)g;
 #pragma unroll
@@ -454,7 +429,7 @@ __global__ __launch_bounds__(SHE3_G * 3) void k_raw_eval(KParams kp, const S360V
     __syncthreads();
     if (JAC) {
         const int gl = tid / 3, ch = tid - 3 * gl;
-        if (g0 + gl < kp.P) {
+        if (gl < nb) {
             const float G0 = s_G[(3 * ch) * SHE3_G + gl], G1 = s_G[(3 * ch + 1) * SHE3_G + gl], G2 = s_G[(3 * ch + 2) * SHE3_G + gl];
             const float4 dr = s_dir[gl];
             const float dot = dr.x * G0 + dr.y * G1 + dr.z * G2;
@@ -464,7 +439,7 @@ __global__ __launch_bounds__(SHE3_G * 3) void k_raw_eval(KParams kp, const S360V
             o[2] = (G2 - dr.z * dot) * dr.w;
         }
     }
-    if (tid < SHE3_G && g0 + tid < kp.P) {
+    if (tid < nb) {
         const float a0 = s_rgb[3 * tid], a1 = s_rgb[3 * tid + 1], a2 = s_rgb[3 * tid + 2];
         const uint32_t clampbits = (a0 < 0.f ? 1u : 0u) | (a1 < 0.f ? 2u : 0u) | (a2 < 0.f ? 4u : 0u);
         rgbc[g0 + tid] = make_float4(fmaxf(a0, 0.f), fmaxf(a1, 0.f), fmaxf(a2, 0.f), __uint_as_float(clampbits));
@@ -2566,9 +2541,13 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
             if (rawin) {   // s360_forward_raw: geometry + colours straight from the encoder's raw records
                 RawIn rin = *rawin;
                 rin.geo7 = jac ? (float*)(ws + L.geo7) : nullptr;
-                const int nb3 = (kp.P + SHE3_G - 1) / SHE3_G;
-                if (jac) hipLaunchKernelGGL(k_raw_eval<true>, dim3(nb3), dim3(SHE3_G * 3), 0, st, kp, views, rin, rgbc, sh_jac, zero_ptr, zero_words);
-                else hipLaunchKernelGGL(k_raw_eval<false>, dim3(nb3), dim3(SHE3_G * 3), 0, st, kp, views, rin, rgbc, sh_jac, zero_ptr, zero_words);
+                // workgroups are dealt per context view (grid.y): pose and SH rotation matrix are wave-uniform
+                const dim3 rgrid((rin.Gv + SHE3_G - 1) / SHE3_G, (unsigned)(kp.P / rin.Gv));
+                const bool rot = rin.sh_rot != nullptr;
+#define S360_RAWE(J, R) hipLaunchKernelGGL((k_raw_eval<J, R>), rgrid, dim3(SHE3_G * 3), 0, st, kp, views, rin, rgbc, sh_jac, zero_ptr, zero_words)
+                if (jac) { if (rot) S360_RAWE(true, true); else S360_RAWE(true, false); }
+                else { if (rot) S360_RAWE(false, true); else S360_RAWE(false, false); }
+#undef S360_RAWE
             } else if (chm && kp.M == 25 && kp.deg == 4) {  // the reference's harmonics: one lane per (Gaussian, channel)
                 const int nb3 = (kp.P + SHE3_G - 1) / SHE3_G;
                 if (jac) hipLaunchKernelGGL(k_sh_eval3_jac, dim3(nb3), dim3(SHE3_G * 3), 0, st, kp, views, means3D, shs, rgbc, sh_jac, zero_ptr, zero_words);
@@ -2754,7 +2733,6 @@ extern "C" int s360_forward_raw(const S360Params* prm, const S360View* views, co
         (long long)raw->n_views * raw->per_view != (long long)prm->P || (long long)raw->H * raw->W * raw->per_ray != (long long)raw->per_view)
         return S360_E_BADARG;
     if (raw->erp_convention < 0 || raw->erp_convention > 3 || (raw->erp_convention != 0 && (raw->H < 2 || raw->W < 2))) return S360_E_BADARG;
-    if (raw->n_views > 1 && raw->per_view < 64) return S360_E_UNSUPPORTED;   // a 64-Gaussian workgroup spans at most two context views
     if (depth_maps && (depth_mode < 0 || depth_mode > 3)) return S360_E_BADARG;
     if (target && (!d_images || !partials)) return S360_E_BADARG;
     s360::RawIn rin{raw->extrinsics, raw->depths, raw->raw_gaussians, raw->sh_rotation, means_out, cov6_out, nullptr,
