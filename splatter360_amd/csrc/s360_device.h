@@ -76,6 +76,32 @@ __host__ __device__ inline size_t seg_slots_of(const S360Params* prm) {
 #define S360_HDR_SEGWORK 6   /* header word: (tile, quadrant, segment) work items k_render queued for k_render_tail (seg_info[]) */
 #define S360_HDR_SEGBUFS 32  /* header words [32, 64): the segment-state pointers (SegBufs), written by k_tile_scan for k_render */
 
+// compute units of the current device (256 on MI355X), cached per device: sizes the grids of the persistent kernels
+inline int device_cu_count() {
+    static int cached[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cached[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
+
+// workgroups of `fn` the whole device holds at once (occupancy API x CUs), cached per (device, slot < 16): the grid of a persistent kernel
+inline int resident_blocks(const void* fn, int block_threads, int slot) {
+    static int cached[64][16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || slot < 0 || slot >= 16) return 4 * 256;
+    if (!cached[dev][slot]) {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, block_threads, 0) != hipSuccess || per_cu <= 0) { (void)hipGetLastError(); per_cu = 4; }
+        cached[dev][slot] = per_cu * device_cu_count();
+    }
+    return cached[dev][slot];
+}
+
 // Real-SH constants (degree <= 3: public 3DGS table; degree 4: standard real-SH table).
 __device__ constexpr float kC0 = 0.28209479177387814f;
 __device__ constexpr float kC1 = 0.4886025119029199f;

@@ -307,7 +307,7 @@ constexpr int RAW_C = 82;   // 7 + 3 * 25 floats per raw record
 // multiply-adds per lane on every one of the three waves, 145 us); rotating three coefficient vectors is less work than rotating
 // four basis vectors, and the harmonics — hence colours, sh_jac, images — are now bit-identical to the two-step path's
 // (adapter kernel, then k_sh_eval3_jac).
-template <bool JAC, bool ROT>
+template <bool JAC, bool ROT, bool MFMA = false>
 __global__ __launch_bounds__(SHE3_G * 3) void k_raw_eval(KParams kp, const S360View* __restrict__ views, RawIn rin, float4* __restrict__ rgbc,
                                                         float* __restrict__ sh_jac, uint32_t* __restrict__ zero_ptr, int zero_words) {
     __shared__ __attribute__((aligned(16))) float s_raw[7 * SHE3_G * 3 * 4];   // 64 records x 82 floats = 5 248 floats (+ pad to 7 rounds of 192 float4)
@@ -340,33 +340,57 @@ __global__ __launch_bounds__(SHE3_G * 3) void k_raw_eval(KParams kp, const S360V
             for (int i = tid; i < nfl; i += SHE3_G * 3) s_raw[i] = src[i];
         }
     }
-    // Every wave un-projects its Gaussian's mean itself (~150 instructions, in flight with the staging loads above); the covariance
-    // chain rides on wave 1 and the raw-geometry copy on wave 2, both behind their colour work.
+    // Wave 0 un-projects the means (erp_dir: four full-precision sin / cos, ~280 instructions) while the staging loads fly, and hands
+    // the view direction to the other two through LDS (round 5 let every wave do it: 9 M of the launch's 39 M VALU instructions,
+    // profiles/r06_raw_pmc.txt); the covariance chain rides on wave 1 and the raw-geometry copy on wave 2, both behind their colour work.
+    // (Measured and dropped: PERSISTENT workgroups walking the blocks grid-stride with the next block's records prefetched into
+    // registers — 145 VGPRs, 3 waves per SIMD, 168 us instead of 92: a block's three barrier-separated phases are a serial chain,
+    // and what hides it is the number of OTHER workgroups resident on the CU, not the depth of one workgroup's prefetch.)
     const int d = tid >> 6, l = tid & 63;
     const int g = g0 + l;
     const bool live = l < nb;
     const S360View& vw = views[0];
     const float sc = vw.scale;
-    float x = 0.f, y = 0.f, z = 1.f, inv = 0.f, depth = 0.f;
     const float* E = rin.extrinsics + 16 * v;
-    if (live) {
-        depth = rin.depths[g];
+    if (d == 0 && live) {
+        const float depth = rin.depths[g];
         float dr[3];
         erp_dir((gi0 + l) / rin.per_ray, rin.H, rin.W, rin.conv, dr);
         const float p[3] = {dr[0] * depth, dr[1] * depth, dr[2] * depth};
         float mn[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) mn[a] = (E[4 * a] * p[0] + E[4 * a + 1] * p[1] + E[4 * a + 2] * p[2]) + E[4 * a + 3];
-        if (d == 0) {
-            rin.means_out[3 * (size_t)g] = mn[0]; rin.means_out[3 * (size_t)g + 1] = mn[1]; rin.means_out[3 * (size_t)g + 2] = mn[2];
-        }
+        rin.means_out[3 * (size_t)g] = mn[0]; rin.means_out[3 * (size_t)g + 1] = mn[1]; rin.means_out[3 * (size_t)g + 2] = mn[2];
         const float dx = mn[0] * sc - vw.campos[0], dy = mn[1] * sc - vw.campos[1], dz = mn[2] * sc - vw.campos[2];
-        inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
-        x = dx * inv; y = dy * inv; z = dz * inv;
+        const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+        s_dir[l] = make_float4(dx * inv, dy * inv, dz * inv, sc * inv);
     }
-    __syncthreads();      // the staged records
+    // (Measured and dropped: wave 1's covariance chain in front of the barrier too, its seven geometry words loaded straight from
+    // global memory — the non-temporal staging lines are not retained, FETCH_SIZE +113 MB, 98 us instead of 92.)
+    float depth = 0.f;
+    if (d == 1 && live) depth = rin.depths[g];
+    __syncthreads();      // the staged records, the view directions
     float* slab = s_raw + l * RAW_C + 7;     // [3][25] channel-major coefficients of this lane's Gaussian
+    float x = 0.f, y = 0.f, z = 1.f;
+    if (MFMA) {
+        // MFMA form (ROT only): the wave rotates its channel of all 64 records on the matrix cores, in place (every lane takes part:
+        // rows of a partial block compute on stale LDS words and are never read); the colour sum then reads the harmonics back
+        sh_rotate_coefs25_mfma(rin.sh_rot + (size_t)v * 625, s_raw, d, l);
+        __syncthreads();  // the three channels' harmonics (also orders this wave's own LDS writes before its reads below)
+        if (live) {
+            const float4 dr = s_dir[l];
+            x = dr.x; y = dr.y; z = dr.z;
+            float Y[25];
+            sh_basis(4, x, y, z, Y);
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 25; ++k) acc += Y[k] * slab[25 * d + k];
+            s_rgb[3 * l + d] = acc + 0.5f;
+        }
+    } else
     if (live) {
+        const float4 dr = s_dir[l];
+        x = dr.x; y = dr.y; z = dr.z;
         // channel d: harmonics = D (mask . raw), the adapter kernel's own expression
         const float* D = ROT ? rin.sh_rot + (size_t)v * 625 : nullptr;
         float c[25], h[25];
@@ -385,7 +409,7 @@ __global__ __launch_bounds__(SHE3_G * 3) void k_raw_eval(KParams kp, const S360V
         }
     }
     if (JAC) {
-        __syncthreads();  // the three channels' harmonics
+        if (!MFMA) __syncthreads();  // the three channels' harmonics
         if (live) {
             float G[3];
             if (d == 0) sh_jac_component<0>(x, y, z, slab, G);     // wave-uniform: each wave compiles ONE derivative component
@@ -393,7 +417,6 @@ __global__ __launch_bounds__(SHE3_G * 3) void k_raw_eval(KParams kp, const S360V
             else sh_jac_component<2>(x, y, z, slab, G);
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) s_G[(3 * ch + d) * SHE3_G + l] = G[ch];
-            if (d == 0) s_dir[l] = make_float4(x, y, z, sc * inv);
         }
     }
     if (d == 1 && live) {
@@ -2544,9 +2567,13 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
                 // workgroups are dealt per context view (grid.y): pose and SH rotation matrix are wave-uniform
                 const dim3 rgrid((rin.Gv + SHE3_G - 1) / SHE3_G, (unsigned)(kp.P / rin.Gv));
                 const bool rot = rin.sh_rot != nullptr;
-#define S360_RAWE(J, R) hipLaunchKernelGGL((k_raw_eval<J, R>), rgrid, dim3(SHE3_G * 3), 0, st, kp, views, rin, rgbc, sh_jac, zero_ptr, zero_words)
-                if (jac) { if (rot) S360_RAWE(true, true); else S360_RAWE(true, false); }
-                else { if (rot) S360_RAWE(false, true); else S360_RAWE(false, false); }
+#define S360_RAWE(J, R, M) hipLaunchKernelGGL((k_raw_eval<J, R, M>), rgrid, dim3(SHE3_G * 3), 0, st, kp, views, rin, rgbc, sh_jac, zero_ptr, zero_words)
+                // S360_RAW_MFMA=1: the coefficient rotation on the matrix cores (v_mfma_f32_16x16x4_f32) instead of SGPR-operand
+                // multiply-adds — same bits; measured side by side in DESIGN.md section 6
+                static const bool raw_mfma = [] { const char* e = getenv("S360_RAW_MFMA"); return e && e[0] == '1'; }();
+                if (rot && raw_mfma) { if (jac) S360_RAWE(true, true, true); else S360_RAWE(false, true, true); }
+                else if (jac) { if (rot) S360_RAWE(true, true, false); else S360_RAWE(true, false, false); }
+                else { if (rot) S360_RAWE(false, true, false); else S360_RAWE(false, false, false); }
 #undef S360_RAWE
             } else if (chm && kp.M == 25 && kp.deg == 4) {  // the reference's harmonics: one lane per (Gaussian, channel)
                 const int nb3 = (kp.P + SHE3_G - 1) / SHE3_G;
