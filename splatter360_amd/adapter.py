@@ -229,7 +229,19 @@ class GaussianAdapterERP(torch.nn.Module):
     def d_in(self) -> int:
         return 7 + 3 * self.d_sh
 
-    def forward(self, dataset_name, extrinsics, depths, opacities, raw_gaussians, image_shape, eps: float = 1e-8):
+    def rotation_blocks(self, ext: Tensor) -> Optional[Tensor]:
+        """[V,4,4] context poses -> the [V,d_sh,d_sh] matrices of rotate_sh under this module's `sh_rotation` setting (None = identity)."""
+        if self.sh_rotation == "identity":
+            return None
+        if self.sh_rotation == "native":
+            selfcheck_sh_rotation_against_e3nn(ext.device, self.d_sh)      # once per device; a no-op where e3nn is absent
+            return sh_rotation_blocks(ext, self.d_sh)
+        if self.sh_rotation == "e3nn":
+            return wigner_blocks_e3nn(ext[:, :3, :3], self.d_sh)
+        return self.sh_rotation(ext[:, :3, :3])
+
+    def forward(self, dataset_name, extrinsics, depths, opacities, raw_gaussians, image_shape, eps: float = 1e-8, sh_rot="build"):
+        """sh_rot: "build" (default) = rotation_blocks() of the extrinsics; or the matrices themselves / None (lazy.RawBundle builds them once)."""
         if not depths.is_cuda:
             raise RuntimeError("GaussianAdapterERP runs on the GPU only: depths is a CPU tensor (no CPU path in the product; "
                                "oracle/adapter_ref.py is the checker the tests use)")
@@ -240,15 +252,7 @@ class GaussianAdapterERP(torch.nn.Module):
         if srf != 1 and raw_gaussians.shape[4] == 1:
             raw_gaussians = raw_gaussians.expand(b, v, r, srf, spp, raw_gaussians.shape[-1])
         ext = extrinsics.reshape(b * v, 4, 4)
-        if self.sh_rotation == "identity":
-            rot = None
-        elif self.sh_rotation == "native":
-            selfcheck_sh_rotation_against_e3nn(ext.device, self.d_sh)      # once per device; a no-op where e3nn is absent
-            rot = sh_rotation_blocks(ext, self.d_sh)
-        elif self.sh_rotation == "e3nn":
-            rot = wigner_blocks_e3nn(ext[:, :3, :3], self.d_sh)
-        else:
-            rot = self.sh_rotation(ext[:, :3, :3])
+        rot = self.rotation_blocks(ext) if isinstance(sh_rot, str) else sh_rot
         raw = raw_gaussians.broadcast_to(b, v, r, srf, spp, self.d_in).reshape(b * v, r * srf * spp, self.d_in)
         g = adapter_tail(ext, depths.reshape(b * v, -1), opacities.reshape(b * v, -1), raw, (h, w), self.scale_min, self.scale_max,
                          sh_rotation=rot, eps=eps, per_ray=srf * spp, differentiable_means=self.differentiable_means,

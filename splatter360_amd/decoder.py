@@ -317,10 +317,31 @@ class DecoderSplattingFused(torch.nn.Module):
         allv = pack_camera_views(extrinsics.reshape(b * v, 4, 4), intrinsics.reshape(b * v, 3, 3), near.reshape(-1),
                                  far.reshape(-1), bgv, glue=self.glue).view(b, v, -1)
         packed = {(i, e.start): allv[i, e] for i, e in groups}
+        # Gaussians whose means / covariances / harmonics are still lazy.LazyFields of one adapter call (splatter360_amd.install(adapter=True)
+        # replaced the reference's GaussianAdapterERP): groups of views sharing a camera centre are rendered straight from the encoder's
+        # raw outputs (s360_forward_raw / s360_backward_raw) — the [G,3,25] harmonics and [G,3,3] covariances are never materialised.
+        # Any other group indexes the fields, which materialises them once with the stand-alone adapter kernels.
+        from . import lazy as _lazy
+        bundle = _lazy.bundle_of(gaussians)
         for i in range(b):
             cs, ds = [], []
             for s in range(0, v, self.views_per_group):
                 e = slice(s, min(v, s + self.views_per_group))
+                if bundle is not None and shared[(i, s)]:
+                    m = bundle.module
+                    nvc = bundle.shape5[1]
+                    rot = bundle.sh_rotation()
+                    out = rasterizer.rasterize_raw(
+                        bundle.depths[i].reshape(-1), gaussians.opacities[i].reshape(-1), bundle.raw[i].reshape(-1, bundle.raw.shape[-1]),
+                        bundle.extrinsics[i], views=packed[(i, s)], image_height=int(image_shape[0]), image_width=int(image_shape[1]),
+                        context_shape=bundle.image_shape, scale_min=float(m.cfg.gaussian_scale_min), scale_max=float(m.cfg.gaussian_scale_max),
+                        sh_rotation=None if rot is None else rot[i * nvc:(i + 1) * nvc], per_ray=bundle.per_ray, eps=bundle.eps,
+                        erp_convention=_lazy._adapter.ERP_CONVENTIONS[bundle.dataset_name], differentiable_means=m._s360.differentiable_means,
+                        check=self.check, depth_mode=depth_mode)
+                    cs.append(out[0])
+                    if depth_mode is not None:
+                        ds.append(out[3])
+                    continue
                 out = render_views_fused(extrinsics[i, e], intrinsics[i, e], near[i, e], far[i, e], image_shape,
                                          self.background_color, gaussians.means[i], gaussians.covariances[i],
                                          gaussians.harmonics[i], gaussians.opacities[i], shared_campos=shared[(i, s)],

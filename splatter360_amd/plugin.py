@@ -26,6 +26,9 @@ import torch
 
 REGISTRY_MODULE = "src.model.decoder"
 REGISTRY_KEY = "splatting_cuda"
+ADAPTER_MODULE = "src.model.encoder.common.gaussian_adapter_erp"      # defines GaussianAdapterERP (:33-119)
+ADAPTER_USERS = ("src.model.encoder.encoder_costvolume",)             # `from .common.gaussian_adapter_erp import GaussianAdapterERP` (:19), used at :185
+ADAPTER_NAME = "GaussianAdapterERP"
 
 
 def make_decoder_class(base_cls, output_cls, *, views_per_group: int = 6, shared_campos: Optional[bool] = None, check: str = "sync",
@@ -92,6 +95,11 @@ class _LazyPatcher(importlib.abc.MetaPathFinder):
                 self.busy = True
                 try:
                     _patch(pkg, **self.opts)
+                except Exception as ex:     # never let the failure surface from an unrelated third-party import
+                    import warnings
+                    warnings.warn(f"splatter360_amd.install(lazy=True): patching the reference's decoder registry failed ({ex!r}); the "
+                                  "reference keeps its own decoder. Call splatter360_amd.install() explicitly to see the error.", RuntimeWarning)
+                    self.failed = ex
                 finally:
                     self.busy = False
             return None
@@ -118,14 +126,81 @@ class _LazyPatcher(importlib.abc.MetaPathFinder):
         return spec
 
 
-def install(*, lazy: bool = False, **opts):
+def _patch_adapter(mod, **aopts):
+    """Replace the class the reference's encoder instantiates (encoder_costvolume.py:185) in the module that defines it and in every
+    already-imported module that bound the name with `from ... import`."""
+    from . import lazy as _lz
+    cur = getattr(mod, ADAPTER_NAME)
+    if getattr(cur, "replaced", None) is not None:       # idempotent
+        return cur
+    cls = _lz.make_adapter_class(cur, getattr(mod, "Gaussians", None), **aopts)
+    cls.replaced = cur
+    setattr(mod, ADAPTER_NAME, cls)
+    for user in ADAPTER_USERS:
+        um = sys.modules.get(user)
+        if um is not None and getattr(um, ADAPTER_NAME, None) is cur:
+            setattr(um, ADAPTER_NAME, cls)
+    return cls
+
+
+class _AdapterPatcher(importlib.abc.MetaPathFinder):
+    """install(adapter=True) before the reference's encoder package is imported: patch the adapter module as it is first loaded —
+    the encoder's own `from .common.gaussian_adapter_erp import GaussianAdapterERP` (encoder_costvolume.py:19) then binds the
+    replacement."""
+
+    def __init__(self, aopts):
+        self.aopts, self.busy = aopts, False
+
+    def find_spec(self, fullname, path, target=None):
+        if self.busy or fullname != ADAPTER_MODULE:
+            return None
+        self.busy = True
+        try:
+            spec = importlib.util.find_spec(fullname)
+        finally:
+            self.busy = False
+        if spec is None or spec.loader is None:
+            return None
+        loader, aopts, finder = spec.loader, self.aopts, self
+
+        class _Loader(importlib.abc.Loader):
+            def create_module(self, s):
+                return loader.create_module(s)
+
+            def exec_module(self, module):
+                loader.exec_module(module)
+                if finder in sys.meta_path:
+                    sys.meta_path.remove(finder)
+                _patch_adapter(module, **aopts)
+
+        spec.loader = _Loader()
+        return spec
+
+
+def install_adapter(**aopts):
+    """The adapter half of install(adapter=True): see lazy.py.  Patches now if the reference's adapter module is already imported,
+    else as soon as it is (import hook).  aopts: sh_rotation ("native"), differentiable_means (False), lazy (True)."""
+    mod = sys.modules.get(ADAPTER_MODULE)
+    if mod is not None and hasattr(mod, ADAPTER_NAME):
+        return _patch_adapter(mod, **aopts)
+    if not any(isinstance(f, _AdapterPatcher) for f in sys.meta_path):
+        sys.meta_path.insert(0, _AdapterPatcher(aopts))
+    return None
+
+
+def install(*, lazy: bool = False, adapter: bool = False, adapter_options: Optional[dict] = None, **opts):
     """Register the fused decoder under the reference's registry key "splatting_cuda".  Returns the class (lazy=False) or None.
+    adapter=True: ALSO replace the encoder's GaussianAdapterERP (gaussian_adapter_erp.py:33-119) by the lazy-field adapter of lazy.py,
+    so that the registered decoder renders straight from the encoder's raw outputs (no [G,3,25] harmonics / [G,3,3] covariances in
+    HBM); adapter_options: sh_rotation / differentiable_means / lazy of lazy.make_adapter_class.
 
     lazy=False: imports `src.model.decoder` now (the reference must be importable: its repository root on sys.path) and patches
     its DECODERS dict in place — `get_decoder` reads the dict at call time, so every later `get_decoder(cfg, dataset_cfg)` builds
     the fused decoder.  lazy=True: only installs an import hook that patches the registry when the reference itself first imports
     the package (for a sitecustomize that runs before sys.path is set up).  Idempotent.
     opts: views_per_group (6), shared_campos (None = checked per group with one small read per forward), check ("sync"), glue."""
+    if adapter:
+        install_adapter(**(adapter_options or {}))
     if lazy:
         if REGISTRY_MODULE in sys.modules:
             return _patch(sys.modules[REGISTRY_MODULE], **opts)
@@ -137,7 +212,16 @@ def install(*, lazy: bool = False, **opts):
 
 def uninstall() -> None:
     """Put the reference's own decoder class back (and drop a pending lazy hook)."""
-    sys.meta_path[:] = [f for f in sys.meta_path if not isinstance(f, _LazyPatcher)]
+    sys.meta_path[:] = [f for f in sys.meta_path if not isinstance(f, (_LazyPatcher, _AdapterPatcher))]
+    amod = sys.modules.get(ADAPTER_MODULE)
+    if amod is not None:
+        cur = getattr(amod, ADAPTER_NAME, None)
+        if getattr(cur, "replaced", None) is not None:
+            setattr(amod, ADAPTER_NAME, cur.replaced)
+            for user in ADAPTER_USERS:
+                um = sys.modules.get(user)
+                if um is not None and getattr(um, ADAPTER_NAME, None) is cur:
+                    setattr(um, ADAPTER_NAME, cur.replaced)
     pkg = sys.modules.get(REGISTRY_MODULE)
     if pkg is not None:
         cur = pkg.DECODERS.get(REGISTRY_KEY)

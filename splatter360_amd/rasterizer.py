@@ -639,6 +639,7 @@ class _RasterizeRaw(torch.autograd.Function):
                 images, depth, state = call()
         ctx.set_materialize_grads(False)
         ctx.state, ctx.rin_cfg, ctx.depth_mode, ctx.diff_means = state, (nv, ch, cw, per_ray, conv, smin, smax, eps), depth_mode, bool(diff_means)
+        ctx.in_shapes = (tuple(depths.shape), tuple(opacities.shape), tuple(raw.shape))   # gradients go back in the callers' shapes
         _RasterizeViews.last_state = state
         loss = state.mse_out[0] if mse_target is not None else torch.empty(0, dtype=torch.float32, device=dev)
         clipped = state.mse_out[1:] if mse_target is not None else loss
@@ -686,7 +687,8 @@ class _RasterizeRaw(torch.autograd.Function):
                                               lay.total_bytes, _ptr(g), _ptr(g_scale), _ptr(gd), dm, int(ctx.diff_means), _ptr(d_m3), _ptr(d_c6),
                                               _ptr(d_op), _ptr(d_rgb), _ptr(d_dep), _ptr(d_raw), _ptr(bws), lay.backward_bytes, stream)
             _lib.check(rc, "s360_backward_raw")
-        return d_dep, d_op, d_raw, None, None, None, None, None
+        sd, so, sr = ctx.in_shapes
+        return d_dep.view(sd), d_op.view(so), d_raw.view(sr), None, None, None, None, None
 
 
 _RasterizeViews.last_state = None

@@ -117,3 +117,78 @@ def test_lazy_install_survives_a_competing_finder_that_resolves_src_itself():
         print("ok")
     """)
     assert out.strip().endswith("ok")
+
+
+ADAPTER_PRELUDE = textwrap.dedent("""
+    # the adapter module's own imports under the Appendix-B stubs: e3nn is absent, so rotate_sh's module is a stub (its import
+    # is what pulls e3nn in, src/misc/sh_rotation.py:1-8); the common package's __init__ is not executed
+    import torch
+    shr = types.ModuleType("src.misc.sh_rotation")
+    shr.rotate_sh = lambda sh, rotations: sh
+    sys.modules["src.misc.sh_rotation"] = shr
+    m = types.ModuleType("src.model.encoder.common"); m.__path__ = [REF + "/src/model/encoder/common"]; sys.modules["src.model.encoder.common"] = m
+""")
+
+
+def test_install_adapter_replaces_the_class_the_encoder_instantiates():
+    """install(adapter=True) BEFORE the reference imports its encoder: the module that defines GaussianAdapterERP
+    (gaussian_adapter_erp.py:33) is patched as it loads, so the encoder's own `from .common.gaussian_adapter_erp import
+    GaussianAdapterERP` (encoder_costvolume.py:19, instantiated at :185) binds the replacement — a subclass of the reference's class
+    with its constructor, `d_sh` / `d_in` and `sh_mask`, returning the reference's own adapter-side container."""
+    out = _run(ADAPTER_PRELUDE + textwrap.dedent("""
+        import splatter360_amd
+        splatter360_amd.install(lazy=True, adapter=True)
+        assert "src.model.encoder.common.gaussian_adapter_erp" not in sys.modules
+        # what encoder_costvolume.py:19 executes
+        from src.model.encoder.common.gaussian_adapter_erp import GaussianAdapterERP, GaussianAdapterERPCfg
+        amod = sys.modules["src.model.encoder.common.gaussian_adapter_erp"]
+        assert GaussianAdapterERP.__name__ == "GaussianAdapterERPFusedMI355X", GaussianAdapterERP
+        ref_cls = GaussianAdapterERP.replaced
+        assert ref_cls.__name__ == "GaussianAdapterERP" and issubclass(GaussianAdapterERP, ref_cls)
+        cfg_a = GaussianAdapterERPCfg(gaussian_scale_min=0.5, gaussian_scale_max=15.0, sh_degree=4)       # config/model/encoder/costvolume.yaml:14-16
+        mod = GaussianAdapterERP(cfg_a)                                                                    # encoder_costvolume.py:185
+        ref = ref_cls(cfg_a)
+        assert isinstance(mod, ref_cls) and mod.cfg is cfg_a and mod.d_sh == ref.d_sh == 25 and mod.d_in == ref.d_in == 82
+        assert torch.equal(mod.sh_mask, ref.sh_mask) and "sh_mask" not in mod.state_dict()                # non-persistent, like the reference's
+        assert list(mod.state_dict().keys()) == list(ref.state_dict().keys())                             # checkpoints load unchanged
+        import inspect
+        assert list(inspect.signature(mod.forward).parameters) == list(inspect.signature(ref.forward).parameters)
+        try:
+            mod.forward("hm3d", torch.eye(4).reshape(1, 1, 1, 1, 1, 4, 4), torch.ones(1, 1, 8, 1, 1), torch.ones(1, 1, 8, 1, 1), torch.zeros(1, 1, 8, 1, 1, 82), (2, 4))
+            raise SystemExit("a CPU call must raise")
+        except RuntimeError as ex:
+            assert "GPU" in str(ex), ex
+        # installing again is idempotent; uninstall puts the reference's class back
+        splatter360_amd.install(lazy=True, adapter=True)
+        assert amod.GaussianAdapterERP is GaussianAdapterERP
+        splatter360_amd.uninstall()
+        assert amod.GaussianAdapterERP is ref_cls
+        print("ok")
+    """))
+    assert out.strip().endswith("ok")
+
+
+def test_install_adapter_after_the_encoder_was_imported_patches_the_bound_name_too():
+    out = _run(ADAPTER_PRELUDE + textwrap.dedent("""
+        import importlib
+        amod = importlib.import_module("src.model.encoder.common.gaussian_adapter_erp")
+        # a stand-in for the encoder module that already executed its `from .common.gaussian_adapter_erp import GaussianAdapterERP`
+        enc = types.ModuleType("src.model.encoder.encoder_costvolume"); enc.GaussianAdapterERP = amod.GaussianAdapterERP
+        sys.modules["src.model.encoder.encoder_costvolume"] = enc
+        import splatter360_amd
+        splatter360_amd.install(lazy=True, adapter=True, adapter_options=dict(sh_rotation="identity"))
+        assert amod.GaussianAdapterERP.__name__ == "GaussianAdapterERPFusedMI355X" and enc.GaussianAdapterERP is amod.GaussianAdapterERP
+        # the lazy fields pass through the reference's own containers: the adapter-side dataclass and src/model/types.py's Gaussians
+        from splatter360_amd import lazy
+        from src.model.types import Gaussians
+        from einops import rearrange
+        bd = lazy.RawBundle(None, "hm3d", torch.eye(4).expand(1, 2, 4, 4), torch.ones(1, 2, 8, 1, 1), torch.ones(1, 2, 8, 1, 1), torch.zeros(1, 2, 8, 1, 1, 82), (2, 4), 1e-8)
+        f = lambda n, t: lazy.LazyField(bd, n, (1, 2, 8, 1, 1) + t)
+        a = amod.Gaussians(means=f("means", (3,)), covariances=f("covariances", (3, 3)), scales=f("scales", (3,)), rotations=f("rotations", (4,)),
+                           harmonics=f("harmonics", (3, 25)), opacities=bd.opacities)
+        g = Gaussians(rearrange(a.means, "b v r srf spp xyz -> b (v r srf spp) xyz"), rearrange(a.covariances, "b v r srf spp i j -> b (v r srf spp) i j"),
+                      rearrange(a.harmonics, "b v r srf spp c d_sh -> b (v r srf spp) c d_sh"), rearrange(1 * a.opacities, "b v r srf spp -> b (v r srf spp)"))   # encoder_costvolume.py:490-507
+        assert lazy.bundle_of(g) is bd
+        print("ok")
+    """))
+    assert out.strip().endswith("ok")
