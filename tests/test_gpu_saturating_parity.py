@@ -96,18 +96,40 @@ def _got_grads(ps):
 
 def _face_case(cloud, params, face, dev, tag, seed, floor=1e-4):
     """One 256x256 face of a 1 M cloud: (a) parity lists, no splitting — everything against the oracle, integers bit-exact;
-    (b) the product default — observables against the same oracle results."""
+    (b) the product default — observables against the same oracle results.
+
+    The backward is compared on the pixels whose forward DECISIONS agree (round 6).  A stop / accept flip (counted and bounded by the
+    forward checks: <= 16 + 8 pixels of 65 536) changes which entries a pixel composites, and with them that pixel's gradient to
+    EVERY entry in front — for a face-sized splat at the front of 4 000-entry lists one flipped pixel is worth 100 ordinary pixels
+    (scripts/uniform_err_tiles.py: the whole 3.9x of VERDICT r05 weak #2 was one pixel of tile (4, 9) on the uniform cloud's face 0,
+    opacity gradient -1.29e-3 against -1.97e-3 for that tile, every other tile within 8e-7).  The image gradient is therefore zeroed
+    on the flipped pixels for the oracle and for the HIP calls alike, and the bar is the headline's again: max(1e-4, 1.1 x the float32
+    oracle's own distance from float64)."""
     rng = np.random.default_rng(seed)
     gimg = rng.standard_normal((3, 256, 256)).astype(np.float32)
     with _Mode(False, False):
-        out, st, ps = _single_face_call(params, face, 256, dev, grad_image=gimg)
+        out, st, _ = _single_face_call(params, face, 256, dev)
     S = settings_from_views(st.views, 0, 256, 256)
     means, cov6, shs, opac = boundary_tensors(cloud, S["scale"])
     o32 = oracle.rasterize(S, means3D=means, cov3D_precomp=cov6, opacities=opac, shs=shs)
     f = o32.forward()
     P = cloud["means"].shape[0]
     img = out[0].detach().cpu().numpy()
-    _check_forward_saturating(_face_state(st.tensors(), 0, P, 256), img, f, tag + "_fwd", 256)
+    fs = _face_state(st.tensors(), 0, P, 256)
+    _check_forward_saturating(fs, img, f, tag + "_fwd", 256)
+    amax = max(1.0, float(np.abs(f["image"]).max()))
+    flipped = (fs["n_contrib"] != f["n_contrib"]) | (np.abs(img.astype(np.float64) - f["image"]).mean(0) > 1e-5 * amax)
+    # (b) the product default: lean lists, long lists split into depth segments composited in parallel
+    with _Mode(True, True):
+        out2, st2, _ = _single_face_call(params, face, 256, dev)
+    img2 = out2[0].detach().cpu().numpy()
+    t2 = st2.tensors()
+    # (lean lists: n_contrib counts positions of shorter lists, so a flip shows as the pixel difference itself)
+    px = _check_pixels_saturating(img2, t2["n_contrib"][0].cpu().numpy().astype(np.uint32), t2["final_T"][0].cpu().numpy(), f, tag + "_default_mode_fwd",
+                                  same_lists=False)
+    flipped |= np.abs(img2.astype(np.float64) - f["image"]).mean(0) > 1e-5 * amax
+    assert int(flipped.sum()) <= 24, int(flipped.sum())
+    gimg = gimg * (~flipped)[None].astype(np.float32)
     # "saturated": the stop test tripped.  final_T itself never drops below 1e-4 (the tripping entry is not applied); with these
     # opacities a pixel that stopped has final_T < 1e-4 / (1 - 0.99) = 1e-2, and one that did not is far above it
     sat = float((f["final_T"] < 1e-2).mean())
@@ -117,25 +139,21 @@ def _face_case(cloud, params, face, dev, tag, seed, floor=1e-4):
     o64.forward()
     g64 = o64.backward(gimg)
     del o64
+    with _Mode(False, False):
+        _, _, ps = _single_face_call(params, face, 256, dev, grad_image=gimg)
     sc = np.float64(S["scale"])
     fold = dict(means3D=sc, cov3D=sc * sc, shs=1.0, opacities=1.0)       # oracle gradients are w.r.t. the scaled cloud
     got = _got_grads(ps)
     rep = dict(saturated_pixel_fraction=sat, longest_list=int(np.diff(f["ranges"].astype(np.int64), axis=1).max()),
-               max_n_contrib=int(f["n_contrib"].max()))
+               max_n_contrib=int(f["n_contrib"].max()), flipped_pixels_masked=int(flipped.sum()))
     bars = {}
     for k in got:
         e, e32 = _grad_err(got[k], np.asarray(g64[k]) * fold[k], np.asarray(g32[k], np.float64) * fold[k])
         rep[k], rep[k + "_oracle_f32"] = e, e32
         bars[k] = max(floor, 1.1 * e32)
         assert e <= bars[k], (tag, k, e, e32)
-    # (b) the product default: lean lists, long lists split into depth segments composited in parallel
     with _Mode(True, True):
-        out2, st2, ps2 = _single_face_call(params, face, 256, dev, grad_image=gimg)
-    img2 = out2[0].detach().cpu().numpy()
-    t2 = st2.tensors()
-    # (lean lists: n_contrib counts positions of shorter lists, so a flip shows as the pixel difference itself)
-    px = _check_pixels_saturating(img2, t2["n_contrib"][0].cpu().numpy().astype(np.uint32), t2["final_T"][0].cpu().numpy(), f, tag + "_default_mode_fwd",
-                                  same_lists=False)
+        _, st2, ps2 = _single_face_call(params, face, 256, dev, grad_image=gimg)
     rep["split_quadrants"] = int(st2.header()[5].item())
     assert st2.split_errors() == 0
     got2 = _got_grads(ps2)
@@ -161,10 +179,8 @@ def test_surface_like_1m_face_vs_oracle(gpu, surface1m, face):
 @pytest.mark.parametrize("face", [0, 3])
 def test_uniform_1m_face_vs_oracle(gpu, uniform1m, face):
     params = _params(uniform1m, gpu)
-    # (floor 3e-4: a splat covering a whole face sums its gradient over tens of thousands of pixels in 256 tile partials — the
-    # summation-order distance from the float64 oracle measured 1.1e-4 (means) / 2.1e-4 (covariances) of the largest entry, the
-    # float32 oracle's own 5e-5)
-    rep = _face_case(uniform1m, params, face, gpu, f"uniform_face{face}", 400 + face, floor=3e-4)
+    # (round 5 ran this cloud with floor=3e-4 and blamed summation order; it was one stop-flipped pixel — see _face_case)
+    rep = _face_case(uniform1m, params, face, gpu, f"uniform_face{face}", 400 + face)
     st = rasterizer.last_state()
     assert int(st.header()[4].item()) > 500                 # pairs with more than 32 instance slots: the wave-parallel gather
 
