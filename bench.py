@@ -199,6 +199,8 @@ def main():
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(a)      # does not return
     rasterizer.ATOMIC_GRADS = bool(a.atomic_grads)
+    rasterizer.LAZY_SHRINK = True    # check="lazy" calls sized at 1.25 x the largest instance count seen (config.workspace_bytes_*): the
+                                     # bench's scenes do not change between steps; the library default keeps the first-call guess as a floor
     rasterizer.SPLIT_LONG_LISTS = "auto" if a.split_lists == "auto" else bool(int(a.split_lists))
     rank, local_rank, world = distributed.init()
     if a.single_rank_rccl and world == 1 and not a.dry_run:

@@ -208,7 +208,7 @@ def render_views_fused(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far
     (views_share_camera_centre: one small synchronising read when they live on the device; with
     pre-packed `views` and no extrinsics the views are taken to be independent, False).
     lean: None = rasterizer.LEAN_LISTS (on: tile lists hold only the instances that can reach a pixel; results bit-identical).
-    split_lists: None = rasterizer.SPLIT_LONG_LISTS (on: long lists whose pixels do not saturate are composited segment-parallel).
+    split_lists: None = rasterizer.SPLIT_LONG_LISTS ("auto": adaptive; True: long lists whose pixels do not saturate are composited segment-parallel).
     exchange: distributed.ExchangeConfig — multi-GPU, the gradients come back summed over the ranks (rasterize_views).
     Host synchronisation: check="sync" (default) reads the binning-overflow flag back after the forward, like
     upstream's own scan read-back, and re-renders with the exact capacity if needed; check="lazy" together with an

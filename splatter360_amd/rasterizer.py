@@ -46,19 +46,40 @@ class GaussianRasterizationSettings(NamedTuple):
 # this switch or S360_LEAN_LISTS=0 select upstream's 3-sigma rectangles (what the integer-state parity tests compare).
 LEAN_LISTS = bool(int(os.environ.get("S360_LEAN_LISTS", "1")))
 
-# Segment-parallel compositing of long tile lists (S360_FLAG_SPLIT_LISTS, forward and backward): an 8x8 quadrant that is still busy
-# after the first 2 048 entries of a list hands the rest over in 1 024-entry segments, one wave each, combined per pixel in list
-# order (pixels whose stop test can trip inside a segment replay it sequentially).  Quadrants that do not split — all of them on
-# lists up to 3 071 entries — are bit-identical either way; inside split quadrants the floating-point association changes
-# (<= 1e-6 per pixel; integers, stop decisions and n_contrib stay those of the sequential walk).
-# rasterize_views(split_lists=False), this switch or S360_SPLIT_LISTS=0 keep every list a single sequential chain.
-# ADAPTIVE by default ("auto"): the forward always reports, into the caller's pinned mirror, whether some quadrant was worth splitting;
-# the flag is set for the calls that follow such a report (and dropped after 16 calls without one).  A cloud that never splits — the
-# headline's: its polar lists saturate within a few hundred entries — then runs the very kernels of a build without the feature
-# (the hand-over code costs the forward composite ~10 us and its second launch 3 us; the segment units cost the backward composite
-# 12 VGPRs).  The first call on a cloud that needs it runs sequentially (slow, correct) and the next ones split.  True / False force it.
+# Segment-parallel compositing of long tile lists (S360_FLAG_SPLIT_LISTS, forward and backward): an 8x8 quadrant whose list is longer
+# than SEG_HEAD + SEG_MIN_REST = 1 024 + 512 entries and that still holds a pixel far from saturating (T >= 1/16) after its first
+# SEG_HEAD = 1 024 entries hands the rest over in SEG_LEN = 512-entry segments, one wave each, combined per pixel in list order from
+# the pixel's true incoming transmittance (csrc/s360_device.h; nothing is ever replayed, no wave waits for another).  Quadrants that
+# do not hand over are bit-identical either way; inside split quadrants the floating-point association changes (<= 1e-6 per pixel;
+# integers, stop decisions and n_contrib stay those of the sequential walk).
+# True / False (rasterize_views(split_lists=...), this switch, S360_SPLIT_LISTS=1 / 0) force the mode; both are functions of the
+# call's own data.  "auto" (the default) is ADAPTIVE and therefore HISTORY-DEPENDENT: the forward reports, into the caller's pinned
+# mirror, whether some quadrant was worth splitting; the flag is set for the calls that follow such a report and dropped after 16
+# calls without one — a cloud that never splits (the headline's) then runs the very kernels of a build without the feature (the
+# hand-over code costs the forward composite ~10 us, its second launch 3 us, the backward's segment units 12 VGPRs), and the first
+# call on a cloud that needs it runs sequentially.  Identical inputs can thus give results 1e-7 apart depending on what was rendered
+# before; DETERMINISTIC below removes that.
 _sl = os.environ.get("S360_SPLIT_LISTS", "auto")
+if _sl not in ("auto", "0", "1"):            # a typo must not surface as a ValueError from int() at import
+    raise RuntimeError(f"S360_SPLIT_LISTS must be 'auto', '0' or '1', got {_sl!r}")
 SPLIT_LONG_LISTS = "auto" if _sl == "auto" else bool(int(_sl))
+
+# DETERMINISTIC (S360_DETERMINISTIC=1): results are a function of the call's inputs alone, bit for bit, whatever was rendered before —
+# every adaptive ("auto") choice that can change bits is pinned: list splitting is always compiled in (S360_FLAG_SPLIT_LISTS set
+# wherever "auto" could set it; the hand-over itself is decided inside the kernel from the data) with the library's worst-case
+# segment storage (no history-sized max_segments), and check="lazy" calls never size their buffers below the first-call guess.
+# Costs the headline step ~1.5 % (the SPLIT instances of both composites).  The binning variant (S360_FLAG_COOP_WALK) stays
+# adaptive: its results are bit-identical either way (tests/test_gpu_coop_walk.py).  tests/test_gpu_determinism.py: cloud A, cloud
+# B, cloud A again -> torch.equal.
+DETERMINISTIC = bool(int(os.environ.get("S360_DETERMINISTIC", "0")))
+
+# check="lazy" calls learn the instance count of their shape one call late from a pinned host word (default_capacity).  By default
+# they only ever RAISE the capacity above the first-call guess 1.5 G V — a lazy call can then be truncated only by a scene beyond
+# that guess, as in round 4.  LAZY_SHRINK = True (S360_LAZY_SHRINK=1; bench.py sets it and says so) sizes them at 1.25 x the largest
+# count seen instead: 1.09 + 1.06 GB of workspace + backward scratch at the headline instead of 2.56 + 2.84 GB, at the price that a
+# scene needing > 25 % more instances than any earlier one is truncated for one step (flagged by a RuntimeWarning at the next call
+# and counted in overflow_events() — poll it after a step to redo / skip a truncated one).
+LAZY_SHRINK = bool(int(os.environ.get("S360_LAZY_SHRINK", "0")))
 
 # Opt-in (S360_FLAG_ATOMIC_GRADS): the backward composite accumulates with float32 atomics instead of the deterministic
 # partial-record gather — a quarter of the backward scratch, one launch less, gradients no longer bit-reproducible run to run.
@@ -174,12 +195,22 @@ def _poll_mirror(key, warn: bool = True) -> None:
     if over and warn and _OVERFLOW_WARNED.get(key) != n:
         import warnings
         _OVERFLOW_WARNED[key] = n
+        _OVERFLOW_EVENTS[0] += 1
         warnings.warn(f"splatter360_amd: a check='lazy' rasteriser call needed {n} instances, more than its binning capacity — that "
                       "call's tile lists were truncated (memory-safe, image incomplete); the following calls are sized for it.  "
                       "Pass max_instances= or use check='sync' where a truncated frame is not acceptable.", RuntimeWarning, stacklevel=3)
 
 
 _OVERFLOW_WARNED: dict = {}
+_OVERFLOW_EVENTS = [0]
+
+
+def overflow_events() -> int:
+    """How many truncated check="lazy" calls have been DETECTED so far in this process (each is detected by the next lazy call of its
+    shape, from the pinned mirror: no synchronisation).  A training loop that runs lazy calls with LAZY_SHRINK can compare this
+    counter before and after a step's first rasteriser call to learn that the PREVIOUS step rendered a truncated frame."""
+    return _OVERFLOW_EVENTS[0]
+
 _CHUNK_HINT: dict = {}      # hint key -> most 4 096-key sort chunks of long tile lists any finished call of that shape reported
 SEG_PER_CHUNK = 8           # csrc/s360_device.h: segment slots per sort chunk (4096 / S360_SEG_LEN)
 
@@ -217,6 +248,8 @@ def split_decision(key, mode, quadrant_waves: int = 0) -> bool:
         return mode
     if quadrant_waves > AUTO_SPLIT_MAX_WAVES:
         return False
+    if DETERMINISTIC:                 # "auto" pinned: always the SPLIT instances (the hand-over is decided in the kernel, from the data)
+        return True
     m = _MIRRORS.get(key)
     if m is not None and int(m[1]) != 0:
         m[1] = 0                      # (a report landing right after this clear is seen by the next call: never lost for long)
@@ -231,7 +264,7 @@ def default_segments(key) -> int:
     (= the library's worst case, every list of the binning capacity long: ~48 B per instance of capacity) until a count is known.
     Quadrants whose segments do not fit are simply composited sequentially."""
     c = _CHUNK_HINT.get(key)
-    return 0 if c is None else SEG_PER_CHUNK * (2 * c + 64)
+    return 0 if (c is None or DETERMINISTIC) else SEG_PER_CHUNK * (2 * c + 64)
 
 
 def default_capacity(p: int, v: int, h: int = 0, w: int = 0, *, device=None, lean: bool = False, lazy: bool = False) -> int:
@@ -239,18 +272,21 @@ def default_capacity(p: int, v: int, h: int = 0, w: int = 0, *, device=None, lea
     (per instance of capacity: 24 B of keys / lists / owner table, 192 B of survivor records and 4 x 64 B of quadrant-partial
     slots in the backward scratch).  First-call guess 1.5 P V.  Once an instance count is known for this (device, shape, list
     mode) the size is 1.25 x the LARGEST count seen (a running maximum: one sparse scene never shrinks the buffers of the next,
-    denser one).  Where the count comes from: check="sync" reads it back with the overflow flag (and re-renders an overflowing
+    denser one); check="lazy" calls keep at least the first-call guess unless LAZY_SHRINK is set (module switch).  Where the count comes from: check="sync" reads it back with the overflow flag (and re-renders an overflowing
     call with the exact size); check="lazy" never synchronises — every forward also stores (count, overflow flag) into a pinned
     host word (S360Params.header_mirror), and the NEXT lazy call of the shape reads that word: the buffers follow the scene with
     one call of delay.  A lazy call whose scene outgrows 1.25 x everything seen before is truncated (flagged, memory-safe, a
     RuntimeWarning at the next call); pass max_instances= to rule that out."""
-    guess = (3 * p * v) // 2 + (1 << 18)
+    first = (3 * p * v) // 2 + (1 << 18)
+    guess = first
     key = _hint_key(device, p, v, h, w, lean)
     if lazy:
         _poll_mirror(key)
     hint = _CAPACITY_HINT.get(key)
     if hint is not None:
         guess = hint + hint // 4 + (1 << 16)
+        if lazy and (DETERMINISTIC or not LAZY_SHRINK):
+            guess = max(guess, first)      # lazy calls cannot be re-rendered: never below the first-call guess unless opted in (ADVICE r05)
     return int(min(2**32 - 1, max(1 << 16, guess)))
 
 
@@ -325,9 +361,9 @@ class RasterState:
         return int(a), int(b)
 
     def split_errors(self) -> int:
-        """header[7] (host read): 0 unless k_render_tail's watchdogs fired — a segment wave that waited ~1 s for its quadrant's
-        phase-1 results, or a corrupt work item.  The kernel then gives up on that item instead of hanging the GPU; the images of
-        such a call are invalid.  Never seen on a correct build; the tests and bench.py assert it stays 0."""
+        """header[7] (host read): 0 unless k_render_tail met a corrupt segment work item (it then skips the item; the images of such a
+        call are invalid).  No wave of the split path ever waits for another one, so there is no time-out any more.  Never seen on a
+        correct build; the tests and bench.py assert it stays 0."""
         return int(self.header()[7].item())
 
     def num_rendered(self) -> int:
@@ -774,7 +810,7 @@ def rasterize_views(means3D: Tensor, cov6: Tensor, opacities: Tensor, shs: Optio
     their values only AFTER .backward(); for training loops that read the scalar for logging after the step.
     atomic_grads (default: module switch ATOMIC_GRADS = False): S360_FLAG_ATOMIC_GRADS — float32 atomics in the backward
     composite instead of the deterministic gather (less scratch, one launch less; gradients not bit-reproducible).
-    split_lists (default: module switch SPLIT_LONG_LISTS = True): S360_FLAG_SPLIT_LISTS — long tile lists whose pixels do not
+    split_lists (default: module switch SPLIT_LONG_LISTS = "auto": adaptive, history-dependent — see the switch; True / False pin it): S360_FLAG_SPLIT_LISTS — long tile lists whose pixels do not
     saturate are composited segment-parallel, forward and backward (see the switch's comment).
     lean (default: module switch LEAN_LISTS = True): bin a (Gaussian, tile) instance only where the splat can reach
     alpha >= 1/255 on that tile — same images / radii / gradients bit for bit, shorter lists; lean=False = upstream's rectangles.
