@@ -73,7 +73,10 @@ def parse():
     ap.add_argument("--grad-sync", choices=("chunked", "factored", "allreduce"), default="chunked",
                     help="N>1 gradient exchange: chunked (default: factored bytes, exchanged range by range inside the backward), "
                          "factored (one exchange per step, see --overlap-exchange) or allreduce (the full 352 B/Gaussian set)")
-    ap.add_argument("--chunks", type=int, default=4, help="Gaussian ranges of the chunked exchange")
+    ap.add_argument("--chunks", type=int, default=0, help="Gaussian ranges of the chunked exchange (0 = chosen from the cloud's size: one per 2 M Gaussians)")
+    ap.add_argument("--exchange-mode", choices=("auto", "gather", "reduce"), default="auto",
+                    help="form of the exchange: gather = ONE coalesced all-gather per range + local sum (auto up to 2 ranks), "
+                         "reduce = all-reduce of the packed rows + all-gather of the dRGB rows (auto beyond)")
     ap.add_argument("--forward-figure", type=int, default=1,
                     help="fwdbwd mode: 1 (default) = K more forward-only steps after the timed region, reported as `forward_only` "
                          "(BASELINE configs[1]); 0 = skip them (the rocprofv3 passes of scripts/collect_profiles.sh: per-kernel averages "
@@ -294,7 +297,9 @@ def main():
     forced = bool(a.single_rank_rccl) and world == 1     # one RCCL rank, collectives really issued
     factored = world > 1 and a.mode == "fwdbwd" and a.grad_sync == "factored"
     chunked = (world > 1 or forced) and a.mode == "fwdbwd" and a.grad_sync == "chunked"
-    exchange_cfg = distributed.ExchangeConfig(n_chunks=a.chunks, force_collectives=forced) if chunked else None
+    exchange_cfg = distributed.ExchangeConfig(n_chunks=a.chunks or None, force_collectives=forced,
+                                              mode=None if a.exchange_mode == "auto" else a.exchange_mode) if chunked else None
+    ex_bounds, ex_mode = distributed.exchange_plan(G, world, a.chunks or None, None if a.exchange_mode == "auto" else a.exchange_mode)
     step = step_eval if a.mode == "eval" else step_train
     views_per_step = 3 if a.mode == "eval" else 1
 
@@ -362,7 +367,10 @@ def main():
             local_only[0] = False
             extra["exchange"] = {"mode": a.grad_sync, "ms_per_step_without_exchange": dt_l / a.steps * 1e3,
                                  "exposed_ms_per_step": (dt - dt_l) / a.steps * 1e3,
-                                 "bytes_received_per_rank": (2 * (world - 1) / world * 40 + (world - 1) * 16) * G if a.grad_sync != "allreduce"
+                                 "form": ex_mode if a.grad_sync == "chunked" else a.grad_sync, "ranges": len(ex_bounds),
+                                 "collective_calls_per_step": len(ex_bounds) * (1 if ex_mode == "gather" else 2) if a.grad_sync == "chunked" else None,
+                                 "bytes_received_per_rank": ((world - 1) * 56 * G if (a.grad_sync == "chunked" and ex_mode == "gather") else
+                                                             (2 * (world - 1) / world * 40 + (world - 1) * 16) * G) if a.grad_sync != "allreduce"
                                  else 2 * (world - 1) / world * 352 * G}
     extra.update(distributed.rank_report(dev))   # backend, rccl_ranks (as the process group reports it), device index of every rank
 
@@ -489,7 +497,7 @@ def main():
                    "gaussians": G, "erp": [erp_w, erp_h], "face": face_w, "views_per_gpu": views_per_step,
                    "parallelism": f"view-sharded x{world}" + (
                        "" if not (world > 1 and a.mode == "fwdbwd") else
-                       f", RCCL chunked exchange inside the backward ({a.chunks} Gaussian ranges: all-reduce 40 B/G packed + all-gather dRGB 16 B/G/rank)" if chunked else
+                       f", RCCL exchange inside the backward ({len(ex_bounds)} Gaussian range(s), " + ("ONE coalesced all-gather of packed 40 B/G + dRGB 16 B/G rows per range, summed locally" if ex_mode == "gather" else "all-reduce 40 B/G packed + all-gather dRGB 16 B/G/rank per range") + "; chunked exchange inside the backward)" if chunked else
                        ", RCCL factored grad exchange (all-reduce 40 B/G packed + all-gather dRGB 16 B/G/rank" + (", overlapped with the next micro-batch's forward" if a.overlap_exchange else "") + ")" if factored else
                        ", RCCL all-reduce of Gaussian grads"),
                    "num_rendered": L, "num_rendered_upstream_lists": L_upstream, "lean_over_upstream": L / max(L_upstream, 1),

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define S360_ABI_VERSION 21
+#define S360_ABI_VERSION 22
 #define S360_MAX_VIEWS 8
 #define S360_TILE 16
 
@@ -387,6 +387,11 @@ int s360_backward_gaussians(const S360Params* prm, const S360View* views, const 
                             float* d_means2D, float* d_rgb_sum, void* bwd_workspace, size_t bwd_workspace_bytes, void* stream);
 int s360_unpack_gradients(const float* packed, int32_t P, int32_t cov9, float* d_means3D, float* d_cov, float* d_opacities,
                           void* stream);
+/* The all-gather form of the exchange (up to two ranks: one collective per Gaussian range instead of two): packed_blocks holds n_blocks
+ * gathered [g_count,10] row blocks, one per rank, back to back; their sum (rank order: the same bits on every rank) is written to rows
+ * [g_begin, g_begin + g_count) of d_means3D / d_cov / d_opacities — the local reduction and s360_unpack_gradients in one pass. */
+int s360_reduce_unpack_gradients(const float* packed_blocks, int32_t n_blocks, int32_t g_begin, int32_t g_count, int32_t cov9,
+                                 float* d_means3D, float* d_cov, float* d_opacities, void* stream);
 
 /*
  * Camera records of a call in one launch: replaces the reference's per-call camera glue
@@ -454,6 +459,17 @@ int s360_backward_raw(const S360Params* prm, const S360View* views, const S360Ra
                       const float* dL_dimages_scale, const float* dL_ddepth, int32_t depth_mode, int32_t differentiable_means,
                       float* d_means3D, float* d_cov6, float* d_opacities, float* d_rgb_sum, float* d_depths, float* d_raw_gaussians,
                       void* bwd_workspace, size_t bwd_workspace_bytes, void* stream);
+/*
+ * The last kernel of s360_backward_raw on its own, for the multi-GPU exchange on the raw path (no reference counterpart: the reference
+ * leaves the gradient exchange to Lightning DDP, /root/reference/src/main.py:117-130): s360_backward_composite +
+ * s360_backward_gaussians produce the rows the exchange moves (packed[P,10], d_rgb_sum[P,4]); after it, d_cov6 [, d_means3D] hold the
+ * sums over the ranks and d_rgb_sums[n_groups,P,4] one clamp-masked dL/dRGB sum per rank (.w = index of that rank's record in
+ * group_views[n_groups], int32 bits, or -1) — exactly k_raw_bwd's inputs: dL/d(SH coefficient) = sum over groups of
+ * (mask . D^T Y(dir_group)) (x) dL/dRGB_group.  d_means3D == NULL: the reference's detached means.
+ */
+int s360_backward_raw_tail(const S360Params* prm, const S360View* group_views, int32_t n_groups, const S360RawInputs* raw,
+                           const float* means, const void* workspace, size_t workspace_bytes, const float* d_means3D,
+                           const float* d_cov6, const float* d_rgb_sums, float* d_depths, float* d_raw_gaussians, void* stream);
 int s360_sh_rotation_blocks(const float* rotations, int32_t row_major_stride, int32_t n_views, int32_t d_sh,
                             float* sh_rotation_out, void* stream);
 int s360_adapter_forward(const float* extrinsics, const float* depths, const float* raw_gaussians,

@@ -51,6 +51,47 @@ def main():
             for p, g in zip(ps, want):
                 assert torch.equal(p.grad, g), (n_chunks, rep)
             checked += 1
+    # both forms of the exchange (exchange_plan picks "gather" — ONE coalesced all-gather per range — up to two ranks, all-reduce +
+    # all-gather beyond), and the default plan (one range for a cloud of this size)
+    for ex_kw in (dict(mode="reduce", n_chunks=3), dict(mode="gather", n_chunks=3), dict()):
+        for p in ps:
+            p.grad = None
+        _render_backward(dev, ps, POSITIONS[1], 5, False, exchange=D.ExchangeConfig(force_collectives=True, **ex_kw))
+        for p, g in zip(ps, want):
+            assert torch.equal(p.grad, g), ex_kw
+        checked += 1
+    # the RAW path (s360_forward_raw / s360_backward_raw): the exchange feeds k_raw_bwd the gathered dL/dRGB factors
+    from splatter360_amd import adapter, decoder
+    gen = torch.Generator().manual_seed(9)
+    hw, nv = (w // 2, w), 2
+    n = hw[0] * hw[1]
+    rdep = torch.exp(torch.empty(nv, n).uniform_(-0.2, 1.8, generator=gen)).to(dev)
+    rop = torch.sigmoid(torch.randn(nv, n, generator=gen)).to(dev)
+    rraw = torch.randn(nv, n, 82, generator=gen)
+    rraw[..., 7:] *= 0.7
+    rraw = rraw.to(dev)
+    cext = torch.eye(4).repeat(nv, 1, 1)
+    cext[0, :3, 3] = torch.tensor([-0.3, 0.0, 0.1]); cext[1, :3, 3] = torch.tensor([0.3, 0.05, -0.1])
+    cext = cext.to(dev)
+    rot = adapter.sh_rotation_blocks(cext, 25)
+    e6, K6, n6, f6 = decoder.cube_cameras(torch.eye(4, device=dev), 0.1, 10.0)
+    views = decoder.pack_camera_views(e6, K6, n6, f6, torch.zeros(3, device=dev))
+    gw = torch.randn((6, 3, 64, 64), generator=gen).to(dev)
+
+    def raw_step(exchange):
+        leaves = [t.clone().requires_grad_(True) for t in (rdep, rop, rraw)]
+        img = rasterizer.rasterize_raw(leaves[0].reshape(-1), leaves[1].reshape(-1), leaves[2].reshape(-1, 82), cext, views=views, image_height=64,
+                                       image_width=64, context_shape=hw, scale_min=0.5, scale_max=15.0, sh_rotation=rot, exchange=exchange)[0]
+        (img * gw).sum().backward()
+        return [t.grad for t in leaves]
+
+    want_raw = raw_step(None)
+    for ex_kw in (dict(), dict(mode="reduce", n_chunks=3), dict(mode="gather", n_chunks=2)):
+        for rep in range(2):
+            got_raw = raw_step(D.ExchangeConfig(force_collectives=True, **ex_kw))
+            for a, b in zip(got_raw, want_raw):
+                assert torch.equal(a, b), ("raw", ex_kw, rep)
+        checked += 1
     # a second communicator for the all-gathers (they then do not queue behind earlier ranges' all-reduces)
     gg = dist.new_group(ranks=[0], backend="nccl")
     for p in ps:

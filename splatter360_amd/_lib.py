@@ -32,7 +32,7 @@ FLAG_ATOMIC_GRADS = 256
 FLAG_SPLIT_LISTS = 512
 FLAG_RAW_INPUTS = 1024
 FLAG_COOP_WALK = 2048
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 
 class S360Params(C.Structure):
@@ -56,7 +56,7 @@ class S360RawInputs(C.Structure):
                 ("erp_convention", C.c_int32), ("scale_min", C.c_float), ("scale_max", C.c_float), ("eps", C.c_float)]
 
 
-EXPORTS = ("s360_forward_raw", "s360_backward_raw", "s360_abi_version", "s360_error_string", "s360_layout", "s360_forward", "s360_forward_depth", "s360_forward_mse", "s360_backward", "s360_backward_split", "s360_backward_composite", "s360_backward_gaussians", "s360_unpack_gradients", "s360_sh_backward", "s360_pack_views", "s360_adapter_forward", "s360_adapter_backward", "s360_sh_rotation_blocks",
+EXPORTS = ("s360_forward_raw", "s360_backward_raw", "s360_backward_raw_tail", "s360_abi_version", "s360_error_string", "s360_layout", "s360_forward", "s360_forward_depth", "s360_forward_mse", "s360_backward", "s360_backward_split", "s360_backward_composite", "s360_backward_gaussians", "s360_unpack_gradients", "s360_reduce_unpack_gradients", "s360_sh_backward", "s360_pack_views", "s360_adapter_forward", "s360_adapter_backward", "s360_sh_rotation_blocks",
            "s360_cube2erp_forward", "s360_cube2erp_backward", "s360_count_contributions", "s360_profile_slots", "s360_profile_slot_name",
            "s360_profile_enable", "s360_profile_collect")
 
@@ -161,12 +161,16 @@ def lib() -> C.CDLL:
     l.s360_backward_composite.argtypes = [C.POINTER(S360Params), vp, vp, sz, vp, vp, vp, i32, vp, sz, vp]
     l.s360_backward_gaussians.restype = C.c_int
     l.s360_backward_gaussians.argtypes = [C.POINTER(S360Params), vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp]
+    l.s360_reduce_unpack_gradients.restype = C.c_int
+    l.s360_reduce_unpack_gradients.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp]
     l.s360_unpack_gradients.restype = C.c_int
     l.s360_unpack_gradients.argtypes = [vp, i32, i32, vp, vp, vp, vp]
     l.s360_sh_backward.restype = C.c_int
     l.s360_sh_backward.argtypes = [C.POINTER(S360Params), i32] + [vp] * 5
     l.s360_forward_raw.restype = C.c_int
     l.s360_forward_raw.argtypes = [C.POINTER(S360Params), vp, C.POINTER(S360RawInputs)] + [vp] * 5 + [i32, vp, vp, C.c_float] + [vp] * 4 + [sz, vp]
+    l.s360_backward_raw_tail.restype = C.c_int
+    l.s360_backward_raw_tail.argtypes = [C.POINTER(S360Params), vp, i32, C.POINTER(S360RawInputs), vp, vp, sz] + [vp] * 6
     l.s360_backward_raw.restype = C.c_int
     l.s360_backward_raw.argtypes = [C.POINTER(S360Params), vp, C.POINTER(S360RawInputs)] + [vp] * 4 + [sz] + [vp] * 3 + [i32, i32] + [vp] * 7 + [sz, vp]
     l.s360_pack_views.restype = C.c_int

@@ -1100,7 +1100,49 @@ __global__ __launch_bounds__(S360_BLOCK) void k_unpack_gradients(const float* __
     }
     d_opac[g] = s[9];
 }
+
+// The local reduction of the exchange's "gather" form fused with the unpack: n_blocks gathered [count,10] row blocks (one per rank,
+// block_stride floats apart) are summed in block order and written straight into rows [g_begin, g_begin + count) of the three tensors.
+__global__ __launch_bounds__(S360_BLOCK) void k_reduce_unpack(const float* __restrict__ blocks, int n_blocks, size_t block_stride, int g_begin,
+                                                              int count, int cov9, float* __restrict__ d_means, float* __restrict__ d_cov,
+                                                              float* __restrict__ d_opac) {
+    const int i = blockIdx.x * S360_BLOCK + threadIdx.x;
+    if (i >= count) return;
+    float acc[10];
+    {
+        const float* s = blocks + 10 * (size_t)i;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) acc[k] = s[k];
+    }
+    for (int b = 1; b < n_blocks; ++b) {
+        const float* s = blocks + (size_t)b * block_stride + 10 * (size_t)i;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) acc[k] += s[k];
+    }
+    const size_t g = (size_t)g_begin + i;
+    d_means[3 * g] = acc[0]; d_means[3 * g + 1] = acc[1]; d_means[3 * g + 2] = acc[2];
+    if (cov9) {
+        float* o = d_cov + 9 * g;
+        o[0] = acc[3]; o[1] = acc[4]; o[2] = acc[5];
+        o[3] = 0.f;    o[4] = acc[6]; o[5] = acc[7];
+        o[6] = 0.f;    o[7] = 0.f;    o[8] = acc[8];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) d_cov[6 * g + k] = acc[3 + k];
+    }
+    d_opac[g] = acc[9];
+}
 }  // namespace s360
+
+extern "C" int s360_reduce_unpack_gradients(const float* packed_blocks, int32_t n_blocks, int32_t g_begin, int32_t g_count, int32_t cov9,
+                                            float* d_means3D, float* d_cov, float* d_opacities, void* stream_) {
+    if (n_blocks < 1 || g_begin < 0 || g_count < 0 || (g_count > 0 && (!packed_blocks || !d_means3D || !d_cov || !d_opacities))) return S360_E_BADARG;
+    if (g_count == 0) return S360_OK;
+    hipLaunchKernelGGL(s360::k_reduce_unpack, dim3((g_count + S360_BLOCK - 1) / S360_BLOCK), dim3(S360_BLOCK), 0, (hipStream_t)stream_,
+                       packed_blocks, n_blocks, (size_t)g_count * 10, g_begin, g_count, cov9, d_means3D, d_cov, d_opacities);
+    S360_CHECK_LAUNCH();
+    return S360_OK;
+}
 
 extern "C" int s360_unpack_gradients(const float* packed, int32_t P, int32_t cov9, float* d_means3D, float* d_cov, float* d_opacities,
                                      void* stream_) {
@@ -1137,6 +1179,31 @@ extern "C" int s360_count_contributions(const S360Params* prm, const void* works
     return S360_OK;
 }
 
+// the last kernel of the raw backward: per-Gaussian dL/dcov6 [, dL/dmean] and n_groups clamp-masked dL/dRGB sums (one per camera
+// centre: one for a single-GPU call, one per rank after the multi-GPU exchange) -> dL/d(raw record), dL/ddepth
+static int raw_tail(const S360Params* prm, const S360View* views, int n_groups, const S360RawInputs* raw, const float* means, const void* workspace,
+                    const float* d_means_or_null, const float* d_cov6, const float* d_rgb_sums, float* d_depths, float* d_raw_gaussians,
+                    void* stream_) {
+    S360Layout L;
+    const int rc = s360_layout(prm, &L);
+    if (rc) return rc;
+    KParams kp;
+    kp.P = prm->P; kp.V = prm->V; kp.H = prm->H; kp.W = prm->W; kp.deg = 4; kp.M = 25;
+    kp.gx = (prm->W + 15) / 16; kp.gy = (prm->H + 15) / 16; kp.T = kp.gx * kp.gy;
+    kp.flags = prm->flags; kp.cap = prm->max_instances;
+    RawBwd rb{raw->extrinsics, raw->depths, (const float*)((const char*)workspace + L.geo7), raw->sh_rotation, means,
+              d_means_or_null, d_cov6, (const float4*)d_rgb_sums, d_depths, d_raw_gaussians,
+              raw->per_view > 0 ? raw->per_view : 1, raw->H, raw->W, raw->per_ray, raw->erp_convention, n_groups, raw->scale_min, raw->scale_max, raw->eps};
+    {
+        ProfScope ps(PS_SH_BWD, (hipStream_t)stream_);
+        const dim3 bgrid((rb.Gv + 63) / 64, (unsigned)(prm->P / rb.Gv));   // per context view: its rotation matrix is wave-uniform
+        if (rb.sh_rot) hipLaunchKernelGGL(k_raw_bwd<true>, bgrid, dim3(192), 0, (hipStream_t)stream_, kp, views, rb);
+        else hipLaunchKernelGGL(k_raw_bwd<false>, bgrid, dim3(192), 0, (hipStream_t)stream_, kp, views, rb);
+    }
+    S360_CHECK_LAUNCH();
+    return S360_OK;
+}
+
 extern "C" int s360_backward_raw(const S360Params* prm, const S360View* views, const S360RawInputs* raw, const float* means, const float* cov6,
                                  const float* opacities, const void* workspace, size_t workspace_bytes, const float* dL_dimages,
                                  const float* dL_dimages_scale, const float* dL_ddepth, int32_t depth_mode, int32_t differentiable_means,
@@ -1156,22 +1223,22 @@ extern "C" int s360_backward_raw(const S360Params* prm, const S360View* views, c
                            bwd_workspace_bytes, stream_);
     if (rc || prm->P == 0) return rc;
     // ... then ONE kernel down to the encoder's outputs
+    return raw_tail(prm, views, 1, raw, means, workspace, differentiable_means ? d_means3D : (const float*)nullptr, d_cov6, d_rgb_sum, d_depths,
+                    d_raw_gaussians, stream_);
+}
+
+extern "C" int s360_backward_raw_tail(const S360Params* prm, const S360View* group_views, int32_t n_groups, const S360RawInputs* raw,
+                                      const float* means, const void* workspace, size_t workspace_bytes, const float* d_means3D,
+                                      const float* d_cov6, const float* d_rgb_sums, float* d_depths, float* d_raw_gaussians, void* stream_) {
+    if (!prm || !group_views || !raw || !means || !workspace || !d_cov6 || !d_rgb_sums || !d_depths || !d_raw_gaussians || n_groups < 1)
+        return S360_E_BADARG;
+    if (!(prm->flags & S360_FLAG_RAW_INPUTS) || (prm->flags & (S360_FLAG_COV9 | S360_FLAG_SPHERICAL | S360_FLAG_FORWARD_ONLY))) return S360_E_BADARG;
+    if (prm->M != 25 || prm->sh_degree != 4) return S360_E_UNSUPPORTED;
+    if ((long long)raw->n_views * raw->per_view != (long long)prm->P) return S360_E_BADARG;
     S360Layout L;
-    rc = s360_layout(prm, &L);
+    const int rc = s360_layout(prm, &L);
     if (rc) return rc;
-    KParams kp;
-    kp.P = prm->P; kp.V = prm->V; kp.H = prm->H; kp.W = prm->W; kp.deg = 4; kp.M = 25;
-    kp.gx = (prm->W + 15) / 16; kp.gy = (prm->H + 15) / 16; kp.T = kp.gx * kp.gy;
-    kp.flags = prm->flags; kp.cap = prm->max_instances;
-    RawBwd rb{raw->extrinsics, raw->depths, (const float*)((const char*)workspace + L.geo7), raw->sh_rotation, means,
-              differentiable_means ? d_means3D : (const float*)nullptr, d_cov6, (const float4*)d_rgb_sum, d_depths, d_raw_gaussians,
-              raw->per_view > 0 ? raw->per_view : 1, raw->H, raw->W, raw->per_ray, raw->erp_convention, 1, raw->scale_min, raw->scale_max, raw->eps};
-    {
-        ProfScope ps(PS_SH_BWD, (hipStream_t)stream_);
-        const dim3 bgrid((rb.Gv + 63) / 64, (unsigned)(prm->P / rb.Gv));   // per context view: its rotation matrix is wave-uniform
-        if (rb.sh_rot) hipLaunchKernelGGL(k_raw_bwd<true>, bgrid, dim3(192), 0, (hipStream_t)stream_, kp, views, rb);
-        else hipLaunchKernelGGL(k_raw_bwd<false>, bgrid, dim3(192), 0, (hipStream_t)stream_, kp, views, rb);
-    }
-    S360_CHECK_LAUNCH();
-    return S360_OK;
+    if (workspace_bytes < L.total_bytes) return S360_E_WORKSPACE;
+    if (prm->P == 0) return S360_OK;
+    return raw_tail(prm, group_views, n_groups, raw, means, workspace, d_means3D, d_cov6, d_rgb_sums, d_depths, d_raw_gaussians, stream_);
 }

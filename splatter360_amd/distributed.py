@@ -196,34 +196,81 @@ def chunk_bounds(p: int, n_chunks: int, align: int = 256) -> List[tuple]:
     return [(lo, min(p, lo + per)) for lo in range(0, p, per)] if p > 0 else []
 
 
-def exchange_chunked(p: int, packed: Tensor, rgb: Tensor, rep_view: Tensor, produce, rebuild_sh, n_chunks: int = 4, group=None,
-                     group_gather=None, timings: Optional[dict] = None, force_collectives: bool = False) -> None:
-    """The gradient exchange of ONE step hidden inside that step (no gradient accumulation assumed): the per-Gaussian tail of
-    the backward is cut into Gaussian ranges and every range's collectives start as soon as its rows exist, so RCCL runs under
-    the tail kernels of the following ranges and under the local dL/dSH rebuilds of the preceding ones.
+GATHER_ONLY_MAX_WORLD = 2     # up to this many ranks the whole exchange is ONE all-gather per range (see exchange_plan)
 
-        for each range c (in order):   produce(lo, hi)                 -> packed[lo:hi] (40 B/Gaussian), rgb[lo:hi] (16 B)
-                                       all-gather  rgb[lo:hi]          (async, `group_gather` or `group`)
-                                       all-reduce  packed[lo:hi]       (async, `group`)
-        for each range c (in order):   wait its all-gather;  rebuild_sh(lo, hi, rgb_all_c[world, hi-lo, 4], rep_all[world, 44])
-        wait every all-reduce                                           -> packed holds the sums over ranks
 
-    `produce` / `rebuild_sh` are the caller's kernels (rasterizer._RasterizeViews.backward: s360_backward_gaussians /
-    s360_sh_backward; the CPU tests: numpy slices of oracle gradients).  rep_view[44]: this rank's representative camera record
-    (all views of a call share the camera centre).  A second process group (`group_gather`) puts the all-gathers on their own
-    communicator so that they do not queue behind the all-reduces of earlier ranges.  Works for world size 1 (no collectives).
-    Per rank and step at N ranks: receives 2 (N-1)/N * 40 B + (N-1) * 16 B per Gaussian (0.19 GB at N = 8, 1 M Gaussians) —
-    what it can hide under: the tail kernels of the following ranges and the dL/dSH rebuilds of the preceding ones (a few hundred
-    microseconds at 1 M, N = 8) — DESIGN.md section 5 does the arithmetic.
-    rebuild_sh=None (harmonics frozen on EVERY rank): the dL/dRGB factors are neither gathered nor rebuilt — only the packed
-    all-reduces run.  The collectives are issued from inside the caller's backward: every rank of `group` must run this backward
-    the same number of times with the same p / n_chunks / rebuild_sh-or-None, or the ranks that did wait forever.
-    force_collectives=True (with an initialised process group): a world of ONE rank also goes through the collective branch
-    instead of the short cut — how the RCCL path (communicator streams against the ctypes-launched kernels on torch's current
-    stream, in-place all-reduces of slices whose neighbours the next produce() writes) is exercised on a one-GPU box
-    (tests/test_gpu_rccl_single_rank.py); the results are those of the short cut bit for bit."""
+def exchange_plan(p: int, world: int, n_chunks: Optional[int] = None, mode: Optional[str] = None):
+    """(Gaussian ranges, mode) of one step's gradient exchange.
+
+    mode "gather": every rank all-gathers its rows — packed[., 10] (40 B) and dRGB[., 4] (16 B) in ONE coalesced all-gather per range —
+    and sums the packed rows of the N ranks locally (a fixed rank order: every rank holds the same bits).  Receives (N-1) x 56 B per
+    Gaussian.  mode "reduce": all-reduce of the packed rows + all-gather of the dRGB rows: 2 (N-1)/N x 40 + (N-1) x 16 B per Gaussian,
+    two collective calls per range.  At N = 2 both move 56 B (gather: one call instead of two); at N = 4: 168 against 108 B; at N = 8:
+    392 against 182 B — so "gather" up to GATHER_ONLY_MAX_WORLD ranks, "reduce" beyond.
+
+    n_chunks None: chosen from P — one range per 2 M Gaussians (1 M: a single range, 4 M: two, capped at four).  Every collective call
+    costs ~16 us of host-side issue + launch on the step's critical path whatever it moves (profiles/r05_bench_1rank_nccl.json: nine
+    calls, 0.145 ms exposed for an exchange of zero bytes), while what a further range can hide under is a share of the 45 + 65 us of
+    per-Gaussian tail kernels at 1 M: ranges only pay when those kernels are long."""
+    if mode is None:
+        mode = "gather" if world <= GATHER_ONLY_MAX_WORLD else "reduce"
+    if mode not in ("gather", "reduce"):
+        raise ValueError("exchange mode must be 'gather' or 'reduce'")
+    if n_chunks is None:
+        n_chunks = max(1, min(4, p >> 21))
+    return chunk_bounds(p, n_chunks), mode
+
+
+def _coalesced_all_gather(outs, ins, group):
+    """ONE collective call for several (output, input) pairs (c10d's fast-path coalescing: allgather_into_tensor_coalesced — a single
+    ncclGroup on RCCL, implemented by gloo as well).  Returns the handle to wait on."""
+    if ins[0].is_cuda and dist.get_backend(group) == "gloo":
+        # gloo with device tensors (only the one-GPU test configuration): its coalesced entry point does not order itself behind the
+        # producing kernels on the current stream the way its plain collectives do — issue the gathers one by one
+        works = [dist.all_gather_into_tensor(o, i, group=group, async_op=True) for o, i in zip(outs, ins)]
+
+        class _All:
+            def wait(self):
+                for w in works:
+                    w.wait()
+        return _All()
+    from torch.distributed.distributed_c10d import _coalescing_manager
+    with _coalescing_manager(group=group, async_ops=True) as cm:
+        for o, i in zip(outs, ins):
+            dist.all_gather_into_tensor(o, i, group=group)
+    return cm
+
+
+def exchange_chunked(p: int, packed: Tensor, rgb: Tensor, rep_view: Tensor, produce, rebuild_sh, n_chunks: Optional[int] = None, group=None,
+                     group_gather=None, timings: Optional[dict] = None, force_collectives: bool = False, mode: Optional[str] = None,
+                     reduce_rows=None) -> str:
+    """The gradient exchange of ONE step inside that step's backward (no gradient accumulation assumed), in at most THREE collective
+    calls for a cloud of up to 2 M Gaussians (round 5 issued nine: an all-gather and an all-reduce per range, four ranges, and a
+    camera-record gather — 0.145 ms of exposed call overhead per 0.79-ms step before a byte moved):
+
+        for each range c (exchange_plan: one per 2 M Gaussians):
+            produce(lo, hi)                                  -> packed[lo:hi] (40 B/Gaussian), rgb[lo:hi] (16 B)
+            mode "gather" (N <= 2):  ONE coalesced all-gather of (packed rows, rgb rows[, this rank's camera record with range 0])
+            mode "reduce" (N  > 2):  all-reduce of the packed rows + ONE coalesced all-gather of (rgb rows[, camera record])
+        for each range c:  wait;  "gather": packed[lo:hi] = sum over ranks of the gathered rows (rank order) — or, when the caller
+                           passes reduce_rows(lo, hi, rows[world, hi-lo, 10]), that callback consumes the gathered rows itself (the
+                           rasteriser: s360_reduce_unpack_gradients, the reduction fused with the unpack) and packed is left alone;
+                           rebuild_sh(lo, hi, rgb_all_c[world, hi-lo, 4], rep_all[world, 44])
+    Returns "local" (one rank, no collective: packed holds this rank's rows), "reduce" (packed holds the sums) or "gather" (sums in
+    packed, or handed to reduce_rows).
+
+    `produce` / `rebuild_sh` are the caller's kernels (rasterizer: s360_backward_gaussians / s360_sh_backward or, on the raw path,
+    the single k_raw_bwd launch over all ranges; the CPU tests: numpy slices of oracle gradients).  rep_view[44]: this rank's
+    representative camera record (all views of a call share the camera centre).  `group_gather`: a second process group for the
+    all-gathers of mode "reduce", so that they do not queue behind the all-reduces of earlier ranges.  Works for world size 1 (no
+    collectives).  rebuild_sh=None (harmonics frozen on EVERY rank): the dL/dRGB factors are neither gathered nor rebuilt.  The
+    collectives are issued from inside the caller's backward: every rank of `group` must run this backward the same number of times
+    with the same p / n_chunks / mode / rebuild_sh-or-None, or the ranks that did wait forever.
+    force_collectives=True (with an initialised process group): a world of ONE rank also goes through the collective branch — how
+    the RCCL path is exercised on a one-GPU box (tests/test_gpu_rccl_single_rank.py); the results are those of the short cut bit
+    for bit."""
     world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
-    bounds = chunk_bounds(p, n_chunks)
+    bounds, mode = exchange_plan(p, world, n_chunks, mode)
     if world == 1 and not (force_collectives and dist.is_available() and dist.is_initialized()):
         for lo, hi in bounds:
             produce(lo, hi)
@@ -231,28 +278,44 @@ def exchange_chunked(p: int, packed: Tensor, rgb: Tensor, rep_view: Tensor, prod
         if rebuild_sh is not None:
             for lo, hi in bounds:
                 rebuild_sh(lo, hi, rgb[lo:hi].reshape(1, hi - lo, 4), rep_all)
-        return
-    gg = group_gather if group_gather is not None else group
-    gathers, reduces = [], []
-    if rebuild_sh is not None:
-        rep_all = torch.empty((world * rep_view.numel(),), dtype=rep_view.dtype, device=rep_view.device)
-        work_rep = dist.all_gather_into_tensor(rep_all, rep_view.reshape(-1).contiguous(), group=gg, async_op=True)
-    for lo, hi in bounds:
+        return "local"
+    gg = group_gather if (group_gather is not None and mode == "reduce") else group
+    pending = []
+    rep_all = None
+    for idx, (lo, hi) in enumerate(bounds):
         produce(lo, hi)
+        n = hi - lo
+        outs, ins = [], []
+        pk_all = rgb_all = None
+        if mode == "gather":
+            pk_all = torch.empty((world * n, packed.shape[1]), dtype=packed.dtype, device=packed.device)      # dim-0 concat: gloo-compatible
+            outs.append(pk_all); ins.append(packed[lo:hi])
         if rebuild_sh is not None:
-            buf = torch.empty((world * (hi - lo), 4), dtype=rgb.dtype, device=rgb.device)      # dim-0 concat: gloo-compatible
-            gathers.append((buf, dist.all_gather_into_tensor(buf, rgb[lo:hi], group=gg, async_op=True)))
-        reduces.append(dist.all_reduce(packed[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True))
-    if rebuild_sh is not None:
-        work_rep.wait()
-        rep_all = rep_all.reshape(world, -1)
-        for (lo, hi), (buf, w) in zip(bounds, gathers):
-            w.wait()
-            rebuild_sh(lo, hi, buf.view(world, hi - lo, 4), rep_all)
-    for w in reduces:
-        w.wait()
+            rgb_all = torch.empty((world * n, 4), dtype=rgb.dtype, device=rgb.device)
+            outs.append(rgb_all); ins.append(rgb[lo:hi])
+            if idx == 0:      # the camera records ride with the first range's gather
+                rep_all = torch.empty((world * rep_view.numel(),), dtype=rep_view.dtype, device=rep_view.device)
+                outs.append(rep_all); ins.append(rep_view.reshape(-1).contiguous())
+        w_g = _coalesced_all_gather(outs, ins, gg) if outs else None
+        w_r = dist.all_reduce(packed[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True) if mode == "reduce" else None
+        pending.append((lo, hi, pk_all, rgb_all, w_g, w_r))
+    for lo, hi, pk_all, rgb_all, w_g, w_r in pending:
+        if w_g is not None:
+            w_g.wait()
+        if pk_all is not None:    # the local reduction of mode "gather": same order on every rank
+            if reduce_rows is not None:
+                reduce_rows(lo, hi, pk_all.view(world, hi - lo, packed.shape[1]))
+            else:
+                torch.sum(pk_all.view(world, hi - lo, packed.shape[1]), dim=0, out=packed[lo:hi])
+        if rebuild_sh is not None:
+            rebuild_sh(lo, hi, rgb_all.view(world, hi - lo, 4), rep_all.reshape(world, -1))
+    for _, _, _, _, _, w_r in pending:
+        if w_r is not None:
+            w_r.wait()
     if timings is not None:
-        timings["chunks"] = len(bounds)
+        timings["chunks"], timings["mode"] = len(bounds), mode
+        timings["collective_calls"] = sum((w_g is not None) + (w_r is not None) for _, _, _, _, w_g, w_r in pending)
+    return mode
 
 
 class ExchangeConfig:
@@ -263,9 +326,11 @@ class ExchangeConfig:
     does not reach the render would leave the others waiting in the collectives).  Frozen harmonics (no gradient required on any
     rank) skip the dL/dRGB gathers and the dL/dSH rebuild."""
 
-    def __init__(self, group=None, n_chunks: int = 4, group_gather=None, force_collectives: bool = False):
-        self.group, self.n_chunks, self.group_gather = group, int(n_chunks), group_gather
+    def __init__(self, group=None, n_chunks: Optional[int] = None, group_gather=None, force_collectives: bool = False, mode: Optional[str] = None):
+        """n_chunks / mode None: chosen by exchange_plan from the cloud's size / the number of ranks."""
+        self.group, self.n_chunks, self.group_gather = group, (None if n_chunks is None else int(n_chunks)), group_gather
         self.force_collectives = bool(force_collectives)      # world size 1: still issue the collectives (see exchange_chunked)
+        self.mode = mode
 
     def world(self) -> int:
         return dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1

@@ -569,12 +569,19 @@ class _RasterizeViews(torch.autograd.Function):
                                                     C.c_void_p(m3.data_ptr() + 12 * lo), _ptr(rgb_all.contiguous()),
                                                     C.c_void_p(d_sh.data_ptr() + 4 * slab * lo), st2), "s360_sh_backward")
 
+                def reduce_rows(lo, hi, rows):      # "gather" form: sum the ranks' rows + unpack, one pass
+                    _lib.check(lib.s360_reduce_unpack_gradients(_ptr(rows), int(rows.shape[0]), lo, hi - lo, int(c6.dim() == 3), _ptr(d_m3), _ptr(d_c6),
+                                                                _ptr(d_op), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                               "s360_reduce_unpack_gradients")
+
                 # harmonics frozen (need[2] False — on every rank, it is the same model): no dL/dRGB gathers, no dL/dSH rebuild
-                distributed.exchange_chunked(p, packed, rgb, vw[0], produce, rebuild_sh if d_sh is not None else None,
-                                             n_chunks=ex.n_chunks, group=ex.group, group_gather=ex.group_gather,
-                                             force_collectives=getattr(ex, "force_collectives", False))
-                _lib.check(lib.s360_unpack_gradients(_ptr(packed), p, int(c6.dim() == 3), _ptr(d_m3), _ptr(d_c6), _ptr(d_op), stream),
-                           "s360_unpack_gradients")
+                form = distributed.exchange_chunked(p, packed, rgb, vw[0], produce, rebuild_sh if d_sh is not None else None,
+                                                    n_chunks=ex.n_chunks, group=ex.group, group_gather=ex.group_gather,
+                                                    force_collectives=getattr(ex, "force_collectives", False), mode=getattr(ex, "mode", None),
+                                                    reduce_rows=reduce_rows)
+                if form != "gather":
+                    _lib.check(lib.s360_unpack_gradients(_ptr(packed), p, int(c6.dim() == 3), _ptr(d_m3), _ptr(d_c6), _ptr(d_op), stream),
+                               "s360_unpack_gradients")
                 if d_m2 is not None:
                     d_m2 = d_m2.sum(0) if v > 1 else d_m2[0]
                 return d_m3, d_m2, d_sh, None, d_op.view(-1, 1), d_c6, None, None, None
@@ -610,7 +617,8 @@ class _RasterizeRaw(torch.autograd.Function):
     @staticmethod
     def forward(ctx, depths, opacities, raw, ctx_extrinsics, sh_rot, views, cfg, mse_target=None):
         (h, w, ch, cw, per_ray, smin, smax, eps, conv, diff_means, max_instances, check, depth_mode, mse_weight, mse_count, lean, mse_defer,
-         split_lists) = cfg
+         split_lists, exchange) = cfg
+        ctx.exchange = exchange
         if not depths.is_cuda:
             raise RuntimeError("depths must live on the GPU (hip device); the rasteriser has no CPU path")
         dev = depths.device
@@ -719,6 +727,51 @@ class _RasterizeRaw(torch.autograd.Function):
             d_raw = torch.empty((p, 82), dtype=torch.float32, device=dev)
             bws = torch.empty(lay.backward_bytes, dtype=torch.uint8, device=dev)
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            if ctx.exchange is not None:
+                # multi-GPU (one target panorama per rank, the same raw cloud on every rank): the rows the exchange moves — packed
+                # [P,10] (dL/dmean | dL/dcov6 | dL/dopacity) and the clamp-masked dL/dRGB sums [P,4] — are exactly what k_raw_bwd takes,
+                # so after the exchange ONE launch forms dL/d(raw record) from the summed rows and the N ranks' dL/dRGB factors
+                from . import distributed
+                ex = ctx.exchange
+                lib = _lib.lib()
+                _lib.check(lib.s360_backward_composite(C.byref(prm), _ptr(vw), _ptr(state.workspace), lay.total_bytes, _ptr(g), _ptr(g_scale),
+                                                       _ptr(gd), dm, _ptr(bws), lay.backward_bytes, stream), "s360_backward_composite")
+                packed = torch.empty((p, 10), dtype=torch.float32, device=dev)
+                rgb = torch.empty((p, 4), dtype=torch.float32, device=dev)
+                rank = ex.rank()
+                gathered = {}
+
+                def produce(lo, hi):
+                    _lib.check(lib.s360_backward_gaussians(C.byref(prm), _ptr(vw), _ptr(means), _ptr(cov6), _ptr(rw), _ptr(state.workspace),
+                                                           lay.total_bytes, int(gd is not None), dm, lo, hi - lo, rank, _ptr(packed),
+                                                           None, _ptr(rgb), _ptr(bws), lay.backward_bytes, stream), "s360_backward_gaussians")
+
+                def collect(lo, hi, rgb_all, rep_all):      # keep every range's gathered factors: k_raw_bwd runs once, over all of them
+                    gathered[(lo, hi)] = rgb_all
+                    gathered["rep"] = rep_all
+
+                def reduce_rows(lo, hi, rows):      # "gather" form: sum the ranks' rows + unpack, one pass
+                    _lib.check(lib.s360_reduce_unpack_gradients(_ptr(rows), int(rows.shape[0]), lo, hi - lo, 0, _ptr(d_m3), _ptr(d_c6), _ptr(d_op),
+                                                                C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "s360_reduce_unpack_gradients")
+
+                form = distributed.exchange_chunked(p, packed, rgb, vw[0], produce, collect, n_chunks=ex.n_chunks, group=ex.group,
+                                                    group_gather=ex.group_gather, force_collectives=getattr(ex, "force_collectives", False),
+                                                    mode=getattr(ex, "mode", None), reduce_rows=reduce_rows)
+                rep_all = gathered.pop("rep").contiguous()
+                world = int(rep_all.shape[0])
+                if len(gathered) == 1:
+                    rgb_all = next(iter(gathered.values())).contiguous()
+                else:
+                    rgb_all = torch.empty((world, p, 4), dtype=torch.float32, device=dev)
+                    for (lo, hi), t in gathered.items():
+                        rgb_all[:, lo:hi] = t
+                if form != "gather":
+                    _lib.check(lib.s360_unpack_gradients(_ptr(packed), p, 0, _ptr(d_m3), _ptr(d_c6), _ptr(d_op), stream), "s360_unpack_gradients")
+                _lib.check(lib.s360_backward_raw_tail(C.byref(prm), _ptr(rep_all), world, C.byref(rin), _ptr(means), _ptr(state.workspace),
+                                                      lay.total_bytes, _ptr(d_m3) if ctx.diff_means else None, _ptr(d_c6), _ptr(rgb_all),
+                                                      _ptr(d_dep), _ptr(d_raw), stream), "s360_backward_raw_tail")
+                sd, so, sr = ctx.in_shapes
+                return d_dep.view(sd), d_op.view(so), d_raw.view(sr), None, None, None, None, None
             rc = _lib.lib().s360_backward_raw(C.byref(prm), _ptr(vw), C.byref(rin), _ptr(means), _ptr(cov6), _ptr(op), _ptr(state.workspace),
                                               lay.total_bytes, _ptr(g), _ptr(g_scale), _ptr(gd), dm, int(ctx.diff_means), _ptr(d_m3), _ptr(d_c6),
                                               _ptr(d_op), _ptr(d_rgb), _ptr(d_dep), _ptr(d_raw), _ptr(bws), lay.backward_bytes, stream)
@@ -838,19 +891,21 @@ def rasterize_raw(depths: Tensor, opacities: Tensor, raw_gaussians: Tensor, cont
                   per_ray: int = 1, eps: float = 1e-8, erp_convention: int = 0, differentiable_means: bool = False,
                   max_instances: Optional[int] = None, check: str = "sync", depth_mode: Optional[str] = None,
                   mse_target: Optional[Tensor] = None, mse_weight: float = 1.0, mse_count: Optional[int] = None, lean: Optional[bool] = None,
-                  mse_defer: bool = False, split_lists: Optional[bool] = None):
+                  mse_defer: bool = False, split_lists: Optional[bool] = None, exchange=None):
     """Render V views sharing one camera centre ([V,44] packed) straight from the encoder's raw outputs: depths / opacities [n*h*w*per_ray]
     (view-major, ray-major), raw_gaussians [same, 82] (3 scale logits, quaternion xyzw, 3 x 25 SH coefficients), context_extrinsics
     [n,4,4], sh_rotation [n,25,25] (adapter.sh_rotation_blocks) or None.  = adapter.adapter_tail(...) followed by rasterize_views(...)
     on its result, in fewer bytes: see _RasterizeRaw.  Returns (images[V,3,H,W], means[P,3], cov6[P,6]) (+ depth maps, + FusedMse as
     in rasterize_views).  Gradients flow to depths, opacities and raw_gaussians; the means are detached like the reference's unless
-    differentiable_means."""
+    differentiable_means.  exchange=distributed.ExchangeConfig(...): multi-GPU — every rank renders its own target panorama of the same
+    raw cloud and the gradients w.r.t. depths / opacities / raw_gaussians come back SUMMED over the ranks (the exchange of
+    rasterize_views, with k_raw_bwd fed the N ranks' dL/dRGB factors)."""
     if depth_mode is not None and depth_mode not in DEPTH_MODES:
         raise ValueError(f"depth_mode must be one of {sorted(DEPTH_MODES)}")
     ch, cw = context_shape
     cfg = (image_height, image_width, int(ch), int(cw), int(per_ray), float(scale_min), float(scale_max), float(eps), int(erp_convention),
            bool(differentiable_means), max_instances, check, depth_mode, mse_weight, mse_count, LEAN_LISTS if lean is None else bool(lean),
-           bool(mse_defer), SPLIT_LONG_LISTS if split_lists is None else (split_lists if split_lists == "auto" else bool(split_lists)))
+           bool(mse_defer), SPLIT_LONG_LISTS if split_lists is None else (split_lists if split_lists == "auto" else bool(split_lists)), exchange)
     images, depth, loss, clipped, means, cov6 = _RasterizeRaw.apply(depths, opacities, raw_gaussians, context_extrinsics, sh_rotation, views, cfg,
                                                                     mse_target)
     out = (images, means, cov6) if depth_mode is None else (images, means, cov6, depth)

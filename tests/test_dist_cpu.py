@@ -280,7 +280,7 @@ def _chunk_inputs(rank, p):
                 campos=np.array([0.1 * rank, 0.03 * rank, -0.07 * rank], np.float32))
 
 
-def _chunked_worker(rank, world, port, q, p, n_chunks, two_groups):
+def _chunked_worker(rank, world, port, q, p, n_chunks, two_groups, mode=None):
     import sys
     from pathlib import Path
     root = Path(__file__).resolve().parent.parent
@@ -313,23 +313,28 @@ def _chunked_worker(rank, world, port, q, p, n_chunks, two_groups):
 
     frozen = n_chunks < 0        # harmonics frozen on every rank: no dL/dRGB gathers, no rebuild — only the packed all-reduces
     n_chunks = abs(n_chunks)
-    D.exchange_chunked(p, packed, rgb, rep, produce, None if frozen else rebuild_sh, n_chunks=n_chunks, group=None, group_gather=gg)
+    tm = {}
+    D.exchange_chunked(p, packed, rgb, rep, produce, None if frozen else rebuild_sh, n_chunks=n_chunks, group=None, group_gather=gg, mode=mode, timings=tm)
+    want_mode = mode or ("gather" if world <= D.GATHER_ONLY_MAX_WORLD else "reduce")
+    # collective calls of the step: one coalesced all-gather per range ("gather"), + one all-reduce per range ("reduce")
+    assert tm["mode"] == want_mode and tm["collective_calls"] == len(produced) * ((1 if want_mode == "gather" else 2) - (1 if (frozen and want_mode == "reduce") else 0))
     assert produced == D.chunk_bounds(p, n_chunks) and produced[0][0] == 0 and produced[-1][1] == p
     assert rebuilt == ([] if frozen else produced)
     q.put((rank, packed.numpy(), d_sh.double().numpy(), len(produced)))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,p,n_chunks,two_groups", [(8, 1000, 4, False), (8, 1000, 4, True), (3, 700, 8, False), (2, 100, 4, False),
-                                                         (3, 700, -3, False)])   # negative: harmonics frozen (no SH exchange)
-def test_chunked_exchange_sums_every_range_over_the_ranks(world, p, n_chunks, two_groups):
+@pytest.mark.parametrize("world,p,n_chunks,two_groups,mode", [(8, 1000, 4, False, None), (8, 1000, 4, True, None), (3, 700, 8, False, None), (2, 100, 4, False, None),
+                                                              (3, 700, -3, False, None),   # negative: harmonics frozen (no SH exchange)
+                                                              (3, 700, 2, False, "gather"), (2, 700, 1, False, "reduce"), (2, 700, -2, False, "gather")])
+def test_chunked_exchange_sums_every_range_over_the_ranks(world, p, n_chunks, two_groups, mode):
     """distributed.exchange_chunked at world size 8 (gloo): ragged Gaussian ranges (1000 = 3 x 256 + 232), more ranges asked
     for than the cloud has workgroups, a cloud smaller than one workgroup, all-gathers on their own process group — every
     rank ends with the packed gradients summed over the ranks and dL/dSH rebuilt from all ranks' factors, range by range."""
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_chunked_worker, args=(r, world, port, q, p, n_chunks, two_groups)) for r in range(world)]
+    procs = [ctx.Process(target=_chunked_worker, args=(r, world, port, q, p, n_chunks, two_groups, mode)) for r in range(world)]
     [pr.start() for pr in procs]
     outs = [q.get(timeout=300) for _ in range(world)]
     [pr.join(timeout=60) for pr in procs]
@@ -352,6 +357,18 @@ def test_chunked_exchange_sums_every_range_over_the_ranks(world, p, n_chunks, tw
             assert not d_sh.any()         # frozen harmonics: nothing gathered, nothing rebuilt
         else:
             np.testing.assert_allclose(d_sh, want_sh, rtol=1e-5, atol=1e-5)
+
+
+def test_exchange_plan_picks_ranges_from_the_cloud_and_the_form_from_the_ranks():
+    """One range per 2 M Gaussians (every collective call is ~16 us on the critical path whatever it moves); one all-gather per range
+    up to 2 ranks (56 B/Gaussian either way), all-reduce + all-gather beyond (182 instead of 392 B/Gaussian at 8 ranks)."""
+    from splatter360_amd import distributed as D
+    assert [len(D.exchange_plan(p, 8)[0]) for p in (1000, 1 << 20, 1 << 22, 1 << 24)] == [1, 1, 2, 4]
+    assert [D.exchange_plan(1 << 20, w)[1] for w in (1, 2, 3, 8)] == ["gather", "gather", "reduce", "reduce"]
+    assert D.exchange_plan(1 << 20, 8, n_chunks=3, mode="gather") == (D.chunk_bounds(1 << 20, 3), "gather")
+    for n in (2, 4, 8):     # bytes received per Gaussian and rank: what the choice is made on
+        gather, reduce_ = (n - 1) * 56, 2 * (n - 1) / n * 40 + (n - 1) * 16
+        assert (gather <= reduce_) == (n <= D.GATHER_ONLY_MAX_WORLD)
 
 
 def test_chunked_exchange_single_process_and_bounds():

@@ -188,6 +188,43 @@ def _worker(rank, world, port, q):
     _render_backward(dev, ps, POSITIONS[rank], 10 + rank, False, exchange=D.ExchangeConfig(n_chunks=3))
     for p, w in zip(ps, plain):
         err.append((p.grad - w).abs().max().item() / (w.abs().max().item() + 1e-20))
+    # ... in its other form too (world 2 defaults to ONE coalesced all-gather per range; "reduce" = all-reduce + all-gather)
+    for p in ps:
+        p.grad = None
+    _render_backward(dev, ps, POSITIONS[rank], 10 + rank, False, exchange=D.ExchangeConfig(n_chunks=2, mode="reduce"))
+    for p, w in zip(ps, plain):
+        err.append((p.grad - w).abs().max().item() / (w.abs().max().item() + 1e-20))
+    # the RAW path: every rank renders its own target panorama from the same encoder outputs; rasterize_raw(exchange=...) returns the
+    # gradients w.r.t. depths / opacities / raw records summed over the ranks (k_raw_bwd fed both ranks' dL/dRGB factors)
+    from splatter360_amd import adapter, decoder, rasterizer
+    gen = torch.Generator().manual_seed(21)
+    hw, nv = (24, 48), 2
+    n = hw[0] * hw[1]
+    rdep = torch.exp(torch.empty(nv, n).uniform_(-0.2, 1.8, generator=gen)).to(dev)
+    rop = torch.sigmoid(torch.randn(nv, n, generator=gen)).to(dev)
+    rraw = torch.randn(nv, n, 82, generator=gen)
+    rraw[..., 7:] *= 0.7
+    rraw = rraw.to(dev)
+    cext = torch.eye(4).repeat(nv, 1, 1)
+    cext[0, :3, 3] = torch.tensor([-0.3, 0.0, 0.1]); cext[1, :3, 3] = torch.tensor([0.3, 0.05, -0.1])
+    cext = cext.to(dev)
+    rot = adapter.sh_rotation_blocks(cext, 25)
+    e6, K6, n6, f6 = _cams(dev, POSITIONS[rank])
+    views = decoder.pack_camera_views(e6, K6, n6, f6, torch.zeros(3, device=dev))
+    gw = torch.randn((6, 3, 64, 64), generator=torch.Generator().manual_seed(40 + rank)).to(dev)
+
+    def raw_step(exchange):
+        leaves = [t.clone().requires_grad_(True) for t in (rdep, rop, rraw)]
+        img = rasterizer.rasterize_raw(leaves[0].reshape(-1), leaves[1].reshape(-1), leaves[2].reshape(-1, 82), cext, views=views, image_height=64,
+                                       image_width=64, context_shape=hw, scale_min=0.5, scale_max=15.0, sh_rotation=rot, exchange=exchange)[0]
+        (img * gw).sum().backward()
+        return [t.grad for t in leaves]
+
+    plain_raw = raw_step(None)
+    D.allreduce_gradients(plain_raw)
+    for ex in (D.ExchangeConfig(), D.ExchangeConfig(n_chunks=2, mode="reduce")):
+        for a, w in zip(raw_step(ex), plain_raw):
+            err.append((a - w).abs().max().item() / (w.abs().max().item() + 1e-20))
     q.put((rank, err, float(plain[2].abs().sum().item())))
     torch.distributed.destroy_process_group()
 
