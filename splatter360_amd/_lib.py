@@ -57,7 +57,7 @@ class S360RawInputs(C.Structure):
 
 
 EXPORTS = ("s360_forward_raw", "s360_backward_raw", "s360_backward_raw_tail", "s360_abi_version", "s360_error_string", "s360_layout", "s360_forward", "s360_forward_depth", "s360_forward_mse", "s360_backward", "s360_backward_split", "s360_backward_composite", "s360_backward_gaussians", "s360_unpack_gradients", "s360_reduce_unpack_gradients", "s360_sh_backward", "s360_pack_views", "s360_adapter_forward", "s360_adapter_backward", "s360_sh_rotation_blocks",
-           "s360_cube2erp_forward", "s360_cube2erp_backward", "s360_count_contributions", "s360_profile_slots", "s360_profile_slot_name",
+           "s360_cube2erp_forward", "s360_cube2erp_backward", "s360_count_contributions", "s360_count_backward_slots", "s360_profile_slots", "s360_profile_slot_name",
            "s360_profile_enable", "s360_profile_collect")
 
 
@@ -186,6 +186,8 @@ def lib() -> C.CDLL:
     l.s360_cube2erp_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(C.c_int64), vp]
     l.s360_cube2erp_backward.restype = C.c_int
     l.s360_cube2erp_backward.argtypes = [vp, vp, vp, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(C.c_int64), vp]
+    l.s360_count_backward_slots.restype = C.c_int
+    l.s360_count_backward_slots.argtypes = [C.POINTER(S360Params), vp, sz, vp, vp]
     l.s360_count_contributions.restype = C.c_int
     l.s360_count_contributions.argtypes = [C.POINTER(S360Params), vp, sz, vp, vp]
     l.s360_profile_slot_name.restype = C.c_char_p

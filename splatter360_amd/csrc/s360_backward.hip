@@ -1081,6 +1081,91 @@ __global__ __launch_bounds__(64) void k_count_pairs(KParams kp, const uint32_t* 
     }
 }
 
+// Measurement aid, second form: WHERE the backward composite's evaluated (entry, pixel) slots go.  One wave per
+// (tile, quadrant) replays the survivor records in k_render_bwd_em's own structure — groups of 64 records in the lanes, back to front,
+// sixteen four-pixel runs per group, a run skipped when none of its pixels reaches back to the group — and classifies every lane x
+// pixel slot of every EXECUTED run:
+//   out[0] slots executed (64 lanes x 4 pixels per run)      out[1] padding: lanes beyond the group's records
+//   out[2] "stopped": the entry lies at or behind the pixel's last contributor (the pixel saturated in front of it, or nothing of
+//          the list reaches it any more)                      out[3] "miss": power > 0 or alpha < 1/255 (the splat does not reach)
+//   out[4] contributing                                       out[5] slots of runs the qmask test skipped (not executed)
+//   out[6] units with records                                 out[7] groups executed
+//   out[8 + b], b = 0..9: executed slots of the units whose contributing fraction falls in [b/10, (b+1)/10)
+//   out[18 + r], r = 0..7: executed runs by the number of records among the group's 64 that contribute to at least one of the
+//          run's four pixels: r = 0: none, 1: 1-4, 2: 5-8, 3: 9-16, 4: 17-24, 5: 25-32, 6: 33-48, 7: 49-64
+__global__ __launch_bounds__(64) void k_count_bwd_slots(KParams kp, const uint32_t* __restrict__ tile_start, const float4* __restrict__ surv,
+                                                       const uint32_t* __restrict__ surv_count, const uint32_t* __restrict__ n_contrib,
+                                                       unsigned long long* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_last[64];
+    const uint32_t unit = blockIdx.x;
+    const int t = (int)(unit >> 2), wave = (int)(unit & 3u), lane = threadIdx.x;
+    const int v = t / kp.T, rem = t - v * kp.T;
+    const int ty = rem / kp.gx, tx = rem - ty * kp.gx;
+    const int qx = tx * 16 + sub_ox(wave), qy = ty * 16 + sub_oy(wave);
+    const uint32_t start = min(tile_start[t], kp.cap), end = min(tile_start[t + 1], kp.cap);
+    {
+        const int px = qx + (lane & 7), py = qy + (lane >> 3);
+        s_last[lane] = (px < kp.W && py < kp.H) ? n_contrib[((size_t)v * kp.H + py) * kp.W + px] : 0u;
+    }
+    __syncthreads();
+    const uint32_t n_surv = surv_count[unit];
+    if (n_surv == 0) return;
+    const float4* const sv = surv + 3 * ((size_t)4 * start + (size_t)wave * (end - start));
+    uint32_t c_pad = 0, c_stop = 0, c_miss = 0, c_hit = 0;
+    unsigned long long runs_exec = 0, runs_skip = 0, groups = 0;
+    unsigned long long rh[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t top = (int64_t)n_surv - 1; top >= 0; top -= 64) {
+        const uint32_t n = (uint32_t)(top + 1 < 64 ? top + 1 : 64);
+        const bool lane_ok = (uint32_t)lane < n;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, c = a;
+        if (lane_ok) {
+            const float4* r = sv + 3 * (size_t)(top - lane);
+            a = r[0]; b = r[1]; c = r[2];
+        }
+        const uint32_t pos = lane_ok ? __float_as_uint(c.z) : 0xFFFFFFFFu;
+        const uint32_t pos_min = (uint32_t)__builtin_amdgcn_readlane((int)pos, (int)n - 1);
+        const uint4 l4 = *reinterpret_cast<const uint4*>(&s_last[(lane & 15) * 4]);
+        const uint32_t qmask = (uint32_t)__ballot(max(max(l4.x, l4.y), max(l4.z, l4.w)) > pos_min) & 0xFFFFu;
+        ++groups;
+        for (int run = 0; run < 16; ++run) {
+            if (!((qmask >> run) & 1u)) { ++runs_skip; continue; }
+            ++runs_exec;
+            bool any = false;
+            for (int k = 0; k < 4; ++k) {
+                const int p = run * 4 + k;
+                if (!lane_ok) { ++c_pad; continue; }
+                const float dx = a.x - (float)(qx + (p & 7)), dy = a.y - (float)(qy + (p >> 3));
+                const float power = power2(a.z, a.w, b.x, dx, dy);
+                const float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(power));
+                if (!(pos < s_last[p])) ++c_stop;
+                else if (power > 0.0f || alpha < 1.0f / 255.0f) ++c_miss;
+                else { ++c_hit; any = true; }
+            }
+            const int na = __popcll(__ballot(any));
+            ++rh[na == 0 ? 0 : na <= 4 ? 1 : na <= 8 ? 2 : na <= 16 ? 3 : na <= 24 ? 4 : na <= 32 ? 5 : na <= 48 ? 6 : 7];
+        }
+    }
+    uint32_t tot[4] = {c_pad, c_stop, c_miss, c_hit};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tot[k] += (uint32_t)__shfl_xor((int)tot[k], o);
+    if (lane == 0) {
+        const unsigned long long exec = runs_exec * 256ull;
+        atomicAdd(&out[0], exec);
+        atomicAdd(&out[1], (unsigned long long)tot[0]);
+        atomicAdd(&out[2], (unsigned long long)tot[1]);
+        atomicAdd(&out[3], (unsigned long long)tot[2]);
+        atomicAdd(&out[4], (unsigned long long)tot[3]);
+        atomicAdd(&out[5], runs_skip * 256ull);
+        atomicAdd(&out[6], 1ull);
+        atomicAdd(&out[7], groups);
+        const int bin = exec ? min(9, (int)(10ull * tot[3] / exec)) : 0;
+        atomicAdd(&out[8 + bin], exec);
+        for (int r = 0; r < 8; ++r) atomicAdd(&out[18 + r], rh[r]);
+    }
+}
+
 // [P,10] packed gradients (3 mean + 6 unique covariance entries + 1 opacity) -> the three tensors of the reference's layouts
 __global__ __launch_bounds__(S360_BLOCK) void k_unpack_gradients(const float* __restrict__ packed, int P, int cov9,
                                                                  float* __restrict__ d_means, float* __restrict__ d_cov,
@@ -1225,6 +1310,28 @@ extern "C" int s360_backward_raw(const S360Params* prm, const S360View* views, c
     // ... then ONE kernel down to the encoder's outputs
     return raw_tail(prm, views, 1, raw, means, workspace, differentiable_means ? d_means3D : (const float*)nullptr, d_cov6, d_rgb_sum, d_depths,
                     d_raw_gaussians, stream_);
+}
+
+extern "C" int s360_count_backward_slots(const S360Params* prm, const void* workspace, size_t workspace_bytes, uint64_t* counts, void* stream_) {
+    if (!prm || !workspace || !counts) return S360_E_BADARG;
+    if (prm->flags & (S360_FLAG_FORWARD_ONLY | S360_FLAG_SPLIT_LISTS | S360_FLAG_SPHERICAL)) return S360_E_BADARG;   // the unsplit training composite's structure
+    S360Layout L;
+    const int rc = s360_layout(prm, &L);
+    if (rc) return rc;
+    if (workspace_bytes < L.total_bytes) return S360_E_WORKSPACE;
+    KParams kp;
+    kp.P = prm->P; kp.V = prm->V; kp.H = prm->H; kp.W = prm->W; kp.deg = s360_effective_degree(prm); kp.M = prm->M;
+    kp.gx = (prm->W + 15) / 16; kp.gy = (prm->H + 15) / 16; kp.T = kp.gx * kp.gy;
+    kp.flags = prm->flags; kp.cap = prm->max_instances;
+    const int nt = kp.V * kp.T;
+    const char* ws = (const char*)workspace;
+    hipStream_t st = (hipStream_t)stream_;
+    if (hipMemsetAsync(counts, 0, 26 * sizeof(uint64_t), st) != hipSuccess) return S360_E_LAUNCH;
+    if (prm->P == 0) return S360_OK;
+    hipLaunchKernelGGL(s360::k_count_bwd_slots, dim3(nt * 4), dim3(64), 0, st, kp, (const uint32_t*)(ws + L.tile_start), (const float4*)(ws + L.surv),
+                       (const uint32_t*)(ws + L.surv_count), (const uint32_t*)(ws + L.n_contrib), (unsigned long long*)counts);
+    S360_CHECK_LAUNCH();
+    return S360_OK;
 }
 
 extern "C" int s360_backward_raw_tail(const S360Params* prm, const S360View* group_views, int32_t n_groups, const S360RawInputs* raw,
