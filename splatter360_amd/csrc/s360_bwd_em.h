@@ -131,7 +131,8 @@ __global__ __launch_bounds__(64) void k_render_bwd_em(
     size_t sli = 0;     // split units: index of this (slot, quadrant)'s pixel 0 in seg_c / seg_t
     if (seg_blk) {
         if (sj >= sb.seg_list[0]) return;
-        const uint2 info = sb.seg_info[sb.seg_list[1 + sj]];   // the forward's work item: (tile, segment << 2 | quadrant)
+        uint2 info = sb.seg_info[sb.seg_list[1 + sj]];   // the forward's work item: (tile, segment << 2 | quadrant)
+        info.y &= ~S360_SEG_CLAIM;
         unit = 4u * info.x + (info.y & 3u);
         kseg = info.y >> 2;
         const size_t su = ((size_t)SEG_PER_CHUNK * sb.chunk_start[info.x] + kseg) * 4 + (info.y & 3u);   // slot * 4 + quadrant

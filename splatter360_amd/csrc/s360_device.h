@@ -74,6 +74,9 @@ __host__ __device__ inline size_t seg_slots_of(const S360Params* prm) {
 }
 #define S360_HDR_SPLIT 5     /* header word: split (tile, quadrant) units of this call */
 #define S360_HDR_SEGWORK 6   /* header word: (tile, quadrant, segment) work items k_render queued for k_render_tail (seg_info[]) */
+#define S360_HDR_TILES_DONE 24  /* header word: tile workgroups of k_render<.., SPLIT> whose four quadrant waves have all retired (cleared by k_tile_scan) */
+#define S360_HDR_NLONG 25       /* header word: tiles with more than SORT_SHORT keys (k_tile_scan) */
+#define S360_SEG_CLAIM 0x80000000u  /* bit 31 of a work item's second word: a segment wave has taken the item */
 #define S360_HDR_SEGBUFS 32  /* header words [32, 64): the segment-state pointers (SegBufs), written by k_tile_scan for k_render */
 
 // compute units of the current device (256 on MI355X), cached per device: sizes the grids of the persistent kernels
@@ -698,7 +701,8 @@ static __global__ __launch_bounds__(1024) void k_order_units(const uint32_t* __r
         __syncthreads();
         const uint32_t n = header[S360_HDR_SEGWORK];   // the forward's work items: (tile, segment << 2 | quadrant)
         for (uint32_t i = threadIdx.x; i < n; i += 1024) {
-            const uint2 w = seg_info[i];
+            uint2 w = seg_info[i];
+            w.y &= ~S360_SEG_CLAIM;
             if (seg_cnt[((size_t)SEG_PER_CHUNK * chunk_start[w.x] + (w.y >> 2)) * 4 + (w.y & 3u)]) seg_list[1u + atomicAdd(&s_n, 1u)] = i;
         }
         __syncthreads();

@@ -813,8 +813,8 @@ __global__ __launch_bounds__(TS_BLOCK) void k_tile_scan(const uint32_t* __restri
                                                          uint32_t* __restrict__ chunk_start, unsigned long long* __restrict__ header_mirror,
                                                          SegBufs sg_in) {
     __shared__ uint32_t lds[TS_BLOCK / 64];
-    __shared__ uint32_t lds_max;
-    if (threadIdx.x == 0) lds_max = 0;
+    __shared__ uint32_t lds_max, lds_nlong;
+    if (threadIdx.x == 0) { lds_max = 0; lds_nlong = 0; }
     __syncthreads();
     uint32_t carry = 0, mx = 0, ccarry = 0;
     for (int b = 0; b < nt; b += TS_BLOCK) {
@@ -826,6 +826,7 @@ __global__ __launch_bounds__(TS_BLOCK) void k_tile_scan(const uint32_t* __restri
         // the sort kernels see list lengths clamped to the binning capacity
         const uint32_t nclamp = min(carry + ex + v, cap) - min(carry + ex, cap);
         const uint32_t nch = nclamp > SORT_SHORT ? (nclamp + SORT_CHUNK - 1) / SORT_CHUNK : 0u;
+        if (nch) atomicAdd(&lds_nlong, 1u);
         uint32_t ctot;
         const uint32_t cex = block_exclusive_scan<TS_BLOCK / 64>(nch, lds, ctot);
         if (i < nt) {
@@ -862,7 +863,8 @@ __global__ __launch_bounds__(TS_BLOCK) void k_tile_scan(const uint32_t* __restri
         if (header_mirror) __hip_atomic_store(header_mirror, (unsigned long long)carry | ((unsigned long long)(carry > cap ? 1u : 0u) << 32) |
                                                              ((unsigned long long)ccarry << 33),   // + sort chunks of the long lists: sizes max_segments
                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        for (int i = 8; i < 24; ++i) header[i] = 0;  // debug counters; [16, 24): deferred-loss hand-over (S360_HDR_LOSS), set by k_render
+        header[S360_HDR_NLONG] = lds_nlong;  // tiles whose lists are sorted as chunks (> SORT_SHORT keys): the first workgroups of k_render<.., SPLIT>
+        for (int i = 8; i < 25; ++i) header[i] = 0;  // debug counters; [16, 24): deferred-loss hand-over (S360_HDR_LOSS), set by k_render; [24]: S360_HDR_TILES_DONE
     }
 }
 
@@ -1572,6 +1574,23 @@ __device__ __forceinline__ uint32_t ld_dev32(const uint32_t* p) { return __hip_a
 __device__ __forceinline__ void st_devf(float* p, float v) { st_dev32(reinterpret_cast<uint32_t*>(p), __float_as_uint(v)); }
 __device__ __forceinline__ float ld_devf(const float* p) { return __uint_as_float(ld_dev32(reinterpret_cast<const uint32_t*>(p))); }
 
+__device__ __forceinline__ void st_dev64(uint2* p, uint2 v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint2 ld_dev64(const uint2* p) {
+    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+}
+__device__ __forceinline__ float4 ld_dev_f4(const float4* p) {   // one device-coherent 16-byte load
+    f4v r;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\ns_waitcnt vmcnt(0)" : "=&v"(r) : "v"(p) : "memory");
+    return make_float4(r.x, r.y, r.z, r.w);
+}
+__device__ __forceinline__ void st_dev_f4(float4* p, float4 v) {
+    float* q = reinterpret_cast<float*>(p);
+    st_devf(q, v.x); st_devf(q + 1, v.y); st_devf(q + 2, v.z); st_devf(q + 3, v.w);
+}
+
 struct WaveLds {   // one wave's slices of the compaction arrays (see k_render)
     float *x, *y, *a, *b, *c, *o;
     float2 *rg, *bz;
@@ -1745,8 +1764,34 @@ __device__ __forceinline__ void composite_segment(const uint32_t* __restrict__ l
 // have handed over (one store into the caller's host-visible mirror), so that a caller which splits adaptively — the Python layer:
 // the flag is set for the calls that follow a report — pays nothing for the feature on clouds that never split (the hand-over code
 // costs this kernel, at its 80-VGPR cap, a scratch dword and ~10 us on the headline; the second launch another 3 us).
+template <bool WITH_DEPTH, bool COH>
+__device__ __forceinline__ void seg_item(const KParams& kp, const S360View* __restrict__ views, const uint32_t* __restrict__ tile_start,
+                                         const uint32_t* __restrict__ list, const float4* __restrict__ recA, float* __restrict__ images,
+                                         float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_max_contrib,
+                                         uint32_t* __restrict__ strip_last, const float* __restrict__ depths, float* __restrict__ depth_maps,
+                                         int depth_mode, const MseEp& ep, float4* __restrict__ surv, uint32_t* __restrict__ surv_count,
+                                         const SegBufs& sg, int nt, uint32_t* __restrict__ dbg, const WaveLds& L, int lane, uint2 item, uint32_t wi,
+                                         uint32_t nwork);
+
+#ifndef S360_SPLIT_WAVES
+#define S360_SPLIT_WAVES 4      // waves per SIMD of the SPLIT instance of k_render (128 VGPRs: its segment workers need them)
+#endif
+#ifndef S360_P1_GRID
+#define S360_P1_GRID 1024
+#endif
+#ifndef S360_P1_FIRST
+#define S360_P1_FIRST 0         // 0: the phase-1 workers behind ALL tiles (in front of the phase-2 workers); 1: right behind the long tiles
+                                // — measured on the 1 M surface-like cloud: forward composite 220 us (0) against 277 (1): the 1 024
+                                // phase-1 workgroups then sit in front of 1 100 ordinary tiles for two residency rounds
+#endif
+#ifndef S360_P2_GRID
+#define S360_P2_GRID 1024
+#endif
+#ifndef S360_SEGS_SPINS
+#define S360_SEGS_SPINS 600     // polls (~1.7 us apart) without finding anything before a segment wave gives up: ~1 ms
+#endif
 template <bool WITH_DEPTH, bool SPLIT>
-__global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_render(KParams kp, const S360View* __restrict__ views,
+__global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(SPLIT ? S360_SPLIT_WAVES : 6, SPLIT ? S360_SPLIT_WAVES : 6))) void k_render(KParams kp, const S360View* __restrict__ views,
                                                       const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ list,
                                                       const float4* __restrict__ recA, const float4* __restrict__ recB,
                                                       const float4* __restrict__ recC, float* __restrict__ images,
@@ -1757,7 +1802,8 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
                                                       const uint32_t* __restrict__ tile_order, float4* __restrict__ surv,
                                                       uint32_t* __restrict__ surv_count, uint32_t* __restrict__ hdr_loss,
                                                       const SegBufs* __restrict__ sgp, const uint32_t* __restrict__ chunk_start,
-                                                      unsigned long long* __restrict__ cand_mirror, int nt) {
+                                                      unsigned long long* __restrict__ cand_mirror, int nt, const uint32_t* __restrict__ list_all,
+                                                      const float* __restrict__ depths_all) {
 #ifdef S360_DBG_TIMING
     const long long t_begin = wall_clock64();
 #endif
@@ -1783,40 +1829,109 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
         // returned loss) is then visibly wrong instead of uninitialised memory
         for (int i = 0; i <= kp.V; ++i) ep.loss_out[i] = __uint_as_float(0x7FC00000u);
     }
-    if (SPLIT && blockIdx.x >= (uint32_t)nt) {
-        // ---- phase-1 workers of the split lists (the workgroups behind the nt tile workgroups: they start as the first tiles retire
-        // and work under the tail of this kernel, which a split cloud's 1 024-entry heads draw out to ~140 us at falling occupancy).
-        // For every list that MAY split (whether a quadrant does is decided by its head, still running) and every segment k >= SEG_K0:
-        // the segment's own transmittance per pixel, T_k = prod (1 - alpha) over its accepted entries from T = 1 — the alpha
-        // evaluations of the composite without its colour arithmetic; a pixel whose own product trips the 1e-4 test is finished
-        // inside the segment whatever came before: T_k := 0.  k_render_tail (next launch) forms every pixel's true incoming
-        // transmittance from these.  Speculative for the quadrants that end up not splitting: bounded (T-only, and only lists
-        // beyond SEG_HEAD + SEG_MIN_REST), and this variant of the kernel only runs on clouds that split (adaptive flag).
-        const SegBufs sg = *sgp;
-        const int pwave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-        const WaveLds L{s_x[pwave], s_y[pwave], s_a[pwave], s_b[pwave], s_c[pwave], s_o[pwave], s_rg[pwave], s_bz[pwave], s_pos[pwave]};
-        const uint32_t nunits = min((uint32_t)(SEG_PER_CHUNK * chunk_start[nt]), sg.n_slots);
-        for (uint32_t u = blockIdx.x - (uint32_t)nt; u < nunits; u += gridDim.x - (uint32_t)nt) {
-            const ChunkUnit cu = chunk_unit(tile_start, chunk_start, nt, kp.cap, u / SEG_PER_CHUNK);
-            const uint32_t k = cu.k * SEG_PER_CHUNK + (u % SEG_PER_CHUNK);
-            if (!cu.valid || k < SEG_K0 || k * SEG_LEN >= cu.n || cu.n < SEG_HEAD + SEG_MIN_REST) continue;   // block-uniform
-            const int t1 = (int)cu.t, v1 = t1 / kp.T, rem1 = t1 - v1 * kp.T;
-            const int ty1 = rem1 / kp.gx, tx1 = rem1 - ty1 * kp.gx;
-            const int px1 = tx1 * 16 + sub_ox(pwave) + lane % SUB_W, py1 = ty1 * 16 + sub_oy(pwave) + lane / SUB_W;
-            const bool inside1 = px1 < kp.W && py1 < kp.H;
-            float T1 = 1.0f;
-            f2 c01 = f2{0.f, 0.f}, c2d = f2{0.f, 0.f};
-            uint32_t last1 = 0, cnt1 = 0;
-            bool done1 = !inside1;
-            const uint32_t b0 = cu.s + k * SEG_LEN, b1 = min(b0 + SEG_LEN, cu.s + cu.n);
-            composite_segment<WITH_DEPTH, true>(list, recA, depths, cu.s, b0, b1, (float)px1, (float)py1, (float)(tx1 * 16 + sub_ox(pwave)),
-                                                (float)(ty1 * 16 + sub_oy(pwave)), lane, L, 0.f, 0.f, 0.f, depth_mode, T1, c01, c2d, last1, done1,
-                                                nullptr, cnt1);
-            sg.part_t[((size_t)u * 4 + pwave) * 64 + lane] = (done1 && inside1) ? 0.0f : T1;
+    // SPLIT (round 6): ONE launch does everything.  Workgroup roles by launch position — the hardware dispatches in blockIdx order:
+    //   [0, n_long)                   the tiles whose lists may split (tile_order deals the longest lists first): their heads
+    //   [n_long, n_long + P1)         phase-1 workers: the own transmittance T_k of every segment of every such list (no dependency)
+    //   [n_long + P1, nt + P1)        all other tiles
+    //   [nt + P1, nt + P1 + P2)       phase-2 workers: the (tile, quadrant, segment) items the heads publish, from the pixels' true
+    //                                 incoming transmittance, + the combine by whoever delivers last
+    // A worker only ever waits (bounded) for workgroups IN FRONT of it in that order, which are running or done by the time it is
+    // dispatched; a phase-2 wave that gives up leaves its items unclaimed and k_render_tail (the next launch) takes them.
+    // (Until round 6 phase 2 was that second launch: strictly behind the last tile workgroup.)
+    __shared__ uint32_t s_retired;
+    uint32_t tile_slot = blockIdx.x;
+    if (SPLIT) {
+        const SegBufs& sgr = *sgp;
+        const uint32_t n_long = S360_P1_FIRST ? sgr.header[S360_HDR_NLONG] : (uint32_t)nt;
+        const uint32_t b = blockIdx.x;
+        if (b >= n_long && b < n_long + (uint32_t)S360_P1_GRID) {
+            // ---- phase-1 worker
+            const SegBufs sg = sgr;
+            const int pwave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+            const WaveLds L{s_x[pwave], s_y[pwave], s_a[pwave], s_b[pwave], s_c[pwave], s_o[pwave], s_rg[pwave], s_bz[pwave], s_pos[pwave]};
+            const uint32_t nunits = min((uint32_t)(SEG_PER_CHUNK * chunk_start[nt]), sg.n_slots);
+            for (uint32_t u = b - n_long; u < nunits; u += (uint32_t)S360_P1_GRID) {
+                const ChunkUnit cu = chunk_unit(tile_start, chunk_start, nt, kp.cap, u / SEG_PER_CHUNK);
+                const uint32_t k = cu.k * SEG_PER_CHUNK + (u % SEG_PER_CHUNK);
+                if (!cu.valid || k < SEG_K0 || k * SEG_LEN >= cu.n || cu.n < SEG_HEAD + SEG_MIN_REST) continue;   // block-uniform
+                const int t1 = (int)cu.t, v1 = t1 / kp.T, rem1 = t1 - v1 * kp.T;
+                const int ty1 = rem1 / kp.gx, tx1 = rem1 - ty1 * kp.gx;
+                const int px1 = tx1 * 16 + sub_ox(pwave) + lane % SUB_W, py1 = ty1 * 16 + sub_oy(pwave) + lane / SUB_W;
+                const bool inside1 = px1 < kp.W && py1 < kp.H;
+                float T1 = 1.0f;
+                f2 c01 = f2{0.f, 0.f}, c2d = f2{0.f, 0.f};
+                uint32_t last1 = 0, cnt1 = 0;
+                bool done1 = !inside1;
+                const uint32_t b0 = cu.s + k * SEG_LEN, b1 = min(b0 + SEG_LEN, cu.s + cu.n);
+                composite_segment<WITH_DEPTH, true>(list, recA, depths, cu.s, b0, b1, (float)px1, (float)py1, (float)(tx1 * 16 + sub_ox(pwave)),
+                                                    (float)(ty1 * 16 + sub_oy(pwave)), lane, L, 0.f, 0.f, 0.f, depth_mode, T1, c01, c2d, last1, done1,
+                                                    nullptr, cnt1);
+                st_devf(sg.part_t + ((size_t)u * 4 + pwave) * 64 + lane, (done1 && inside1) ? 0.0f : T1);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_fetch_add(&sg.seg_arrive[4 * t1 + pwave], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
         }
-        return;
+        if (b >= (uint32_t)nt + (uint32_t)S360_P1_GRID) {
+            // ---- phase-2 worker: item i belongs to wave slot i mod (4 P2)
+            const SegBufs sg = sgr;
+            const int pwave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+            const WaveLds L{s_x[pwave], s_y[pwave], s_a[pwave], s_b[pwave], s_c[pwave], s_o[pwave], s_rg[pwave], s_bz[pwave], s_pos[pwave]};
+            const uint32_t n_items_cap = sg.n_slots * 4u;
+            const uint32_t stride = (S360_BLOCK / 64) * (uint32_t)S360_P2_GRID;
+            uint32_t wi = (uint32_t)pwave * (uint32_t)S360_P2_GRID + (b - (uint32_t)nt - (uint32_t)S360_P1_GRID);
+            uint32_t spins = 0;
+            while (wi < n_items_cap) {
+                uint2 item = ld_dev64(sg.seg_info + wi);         // every lane loads the same address: one request, one value
+                item.x = (uint32_t)__shfl((int)item.x, 0);
+                item.y = (uint32_t)__shfl((int)item.y, 0);
+                if (item.y == 0u) {     // not published (yet)
+                    bool finished = false;
+                    if ((spins & 3u) == 0u) {
+                        uint32_t td = ld_dev32(sg.header + S360_HDR_TILES_DONE);
+                        td = (uint32_t)__shfl((int)td, 0);
+                        if (td >= (uint32_t)nt) {      // every tile workgroup has retired: the item count is final
+                            uint32_t nw = ld_dev32(sg.header + S360_HDR_SEGWORK);
+                            nw = (uint32_t)__shfl((int)nw, 0);
+                            finished = wi >= nw;
+                        }
+                    }
+                    if (finished || ++spins > (uint32_t)S360_SEGS_SPINS) break;
+                    __builtin_amdgcn_s_sleep(64);
+                    continue;
+                }
+                if (item.y & S360_SEG_CLAIM) { wi += stride; continue; }
+                const int ti = (int)item.x, q = (int)(item.y & 3u);
+                bool ready = (uint32_t)ti < (uint32_t)nt;
+                if (ready) {   // all phase-1 products of the quadrant delivered?
+                    const uint32_t n = min(tile_start[ti + 1], kp.cap) - min(tile_start[ti], kp.cap);
+                    const uint32_t need = (n + SEG_LEN - 1) / SEG_LEN - SEG_K0;
+                    uint32_t w2 = 0;
+                    for (;;) {
+                        uint32_t got = ld_dev32(sg.seg_arrive + 4 * ti + q);
+                        got = (uint32_t)__shfl((int)got, 0);
+                        if (got >= need) break;
+                        if (++w2 > (uint32_t)S360_SEGS_SPINS) { ready = false; break; }
+                        __builtin_amdgcn_s_sleep(32);
+                    }
+                }
+                if (!ready) break;      // gives up: this and the wave's remaining items stay unclaimed (k_render_tail takes them)
+                uint32_t old = 0;
+                if (lane == 0) old = __hip_atomic_fetch_or(reinterpret_cast<uint32_t*>(sg.seg_info + wi) + 1, S360_SEG_CLAIM, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                old = (uint32_t)__shfl((int)old, 0);
+                if (!(old & S360_SEG_CLAIM))
+                    seg_item<WITH_DEPTH, true>(kp, views, tile_start, list, recA, images, final_T, n_contrib, tile_max_contrib, strip_last, depths, depth_maps,
+                                               depth_mode, ep, surv, surv_count, sg, nt, dbg, L, lane, item, wi, 0xFFFFFFFFu);
+                wi += stride;
+                spins = 0;
+            }
+            return;
+        }
+        tile_slot = b < n_long ? b : b - (uint32_t)S360_P1_GRID;
+        if (threadIdx.x == 0) s_retired = 0u;
+        __syncthreads();
     }
-    const int t = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;
+    const int t = tile_order ? (int)tile_order[tile_slot] : (int)tile_slot;
     // (s_setprio by launch-order quartile — the longest lists take the SIMD's issue slots first, all 6 144 waves being resident at
     // once — measured no change: 141.5 vs 141.8 us; the slowest waves are ordinary tiles whose pixels never saturate.)
     const int v = t / kp.T, rem = t - v * kp.T;
@@ -2035,29 +2150,30 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
         }
     }
     if (SPLIT && went) {
-        // The exact sequential state of this quadrant after SEG_HEAD entries, per pixel, in slot k = 0 of the tile; the segment
-        // waves of k_render_tail (next launch) composite [SEG_HEAD, end) in parallel and the last of them to finish combines,
-        // replays where a pixel's stop test can trip, and writes the pixels.
+        // The exact sequential state of this quadrant after SEG_HEAD entries, per pixel, in slot k = 0 of the tile; the segment waves
+        // (k_render_segs, running beside this kernel) composite [SEG_HEAD, end) in parallel and the last of them to finish combines and
+        // writes the pixels.  Everything they read is stored device-coherently and drained BEFORE the work items appear.
         const SegBufs sg = *sgp;     // (loaded here only)
         const size_t slot = (size_t)SEG_PER_CHUNK * chunk_start[t];
         const size_t li = (slot * 4 + wave) * 64 + lane;
-        sg.part_c[li] = make_float4(C01.x, C01.y, C2D.x, C2D.y);
-        sg.part_t[li] = T;
-        sg.part_l[li] = last | (done ? 0x80000000u : 0u);
+        st_dev_f4(sg.part_c + li, make_float4(C01.x, C01.y, C2D.x, C2D.y));
+        st_devf(sg.part_t + li, T);
+        st_dev32(sg.part_l + li, last | (done ? 0x80000000u : 0u));
         const uint32_t wmh = wave_max_u32(inside ? last : 0u);
-        // the quadrant's segments join the work list of k_render_tail: (tile, segment << 2 | quadrant), in ascending segment order
+        // the quadrant's segments join the work list: (tile, segment << 2 | quadrant), in ascending segment order
         const uint32_t nseg = (end - start + SEG_LEN - 1) / SEG_LEN - SEG_K0;
         uint32_t wbase = 0;
         if (lane == 0) {
-            sg.part_n[slot * 4 + wave] = scount;        // survivor records of the head
+            st_dev32(sg.part_n + slot * 4 + wave, scount);        // survivor records of the head
             // ... and how many of them lie in front of the head's last contributor (what the backward replays if no segment adds one)
-            sg.seg_cnt[slot * 4 + wave] = wmh ? sv_cnt + (uint32_t)__popcll(sv_m & ((2ull << (wmh - 1u - sv_rel)) - 1ull)) : 0u;
-            sg.seg_flag[4 * t + wave] = 1u;
+            st_dev32(sg.seg_cnt + slot * 4 + wave, wmh ? sv_cnt + (uint32_t)__popcll(sv_m & ((2ull << (wmh - 1u - sv_rel)) - 1ull)) : 0u);
+            st_dev32(sg.seg_flag + 4 * t + wave, 1u);
             atomicAdd(&sg.header[S360_HDR_SPLIT], 1u);
             wbase = atomicAdd(&sg.header[S360_HDR_SEGWORK], nseg);
         }
         wbase = (uint32_t)__shfl((int)wbase, 0);
-        for (uint32_t i = (uint32_t)lane; i < nseg; i += 64u) sg.seg_info[wbase + i] = make_uint2((uint32_t)t, ((SEG_K0 + i) << 2) | (uint32_t)wave);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the state above (and this wave's survivor records) before the items
+        for (uint32_t i = (uint32_t)lane; i < nseg; i += 64u) st_dev64(sg.seg_info + wbase + i, make_uint2((uint32_t)t, ((SEG_K0 + i) << 2) | (uint32_t)wave));
 #ifdef S360_DBG_TIMING
         if (lane == 0) {
             dbg[4 * (4 * t + wave)] = (uint32_t)t_begin;
@@ -2066,6 +2182,8 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
             dbg[4 * (4 * t + wave) + 3] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);
         }
 #endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0 && atomicAdd(&s_retired, 1u) == 3u) __hip_atomic_fetch_add(&sg.header[S360_HDR_TILES_DONE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
     float sq = 0.f, sqc = 0.f;
@@ -2119,6 +2237,10 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
         dbg[4 * (4 * t + wave) + 3] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);  // HW_REG_XCC_ID
     }
 #endif
+    if (SPLIT) {   // the segment waves stop looking for work once every tile workgroup has retired
+        if (lane == 0 && atomicAdd(&s_retired, 1u) == 3u)
+            __hip_atomic_fetch_add(&sgp->header[S360_HDR_TILES_DONE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 
@@ -2147,45 +2269,34 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
 #ifndef S360_TAIL_WAVES
 #define S360_TAIL_WAVES 4   // waves per SIMD of k_render_tail (128 VGPRs; 3 = unconstrained: 141 VGPRs)
 #endif
-template <bool WITH_DEPTH>
-__global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(S360_TAIL_WAVES, S360_TAIL_WAVES))) void k_render_tail(KParams kp, const S360View* __restrict__ views, const uint32_t* __restrict__ tile_start,
-                                                            const uint32_t* __restrict__ list, const float4* __restrict__ recA,
-                                                            float* __restrict__ images, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                                                            uint32_t* __restrict__ tile_max_contrib, uint32_t* __restrict__ strip_last,
-                                                            const float* __restrict__ depths, float* __restrict__ depth_maps, int depth_mode, MseEp ep,
-                                                            float4* __restrict__ surv, uint32_t* __restrict__ surv_count, SegBufs sg, int nt,
-                                                            uint32_t* __restrict__ dbg) {
-    __shared__ __attribute__((aligned(16))) float s_x[S360_BLOCK / 64][68], s_y[S360_BLOCK / 64][68], s_a[S360_BLOCK / 64][68],
-        s_b[S360_BLOCK / 64][68], s_c[S360_BLOCK / 64][68], s_o[S360_BLOCK / 64][68];
-    __shared__ __attribute__((aligned(16))) float2 s_rg[S360_BLOCK / 64][68], s_bz[S360_BLOCK / 64][68];
-    __shared__ __attribute__((aligned(16))) uint32_t s_pos[S360_BLOCK / 64][68];
-    if (sg.header[S360_HDR_SPLIT] == 0u) return;   // no quadrant of this call split
-    const int pwave = threadIdx.x >> 6, lane = threadIdx.x & 63;   // pwave: this wave's LDS slices; its quadrant comes with the work item
-    const WaveLds L{s_x[pwave], s_y[pwave], s_a[pwave], s_b[pwave], s_c[pwave], s_o[pwave], s_rg[pwave], s_bz[pwave], s_pos[pwave]};
-    const uint32_t nwork = sg.header[S360_HDR_SEGWORK];       // (tile, quadrant, segment) items k_render queued
-    // Work items are dealt STATICALLY, item i to wave slot i mod (4 gridDim): consecutive items — the segments of one quadrant — go to
-    // different workgroups, so a call with fewer items than wave slots (2 419 against 4 096 on the 1 M surface-like cloud) spreads
-    // them over every CU.  (A ticket counter — one agent-scope atomic per item on ONE address — let the last wave start 27 us into
-    // the kernel: ~10 ns per ticket, serialised in one L2 channel.)
-    for (uint32_t wi = (uint32_t)pwave * gridDim.x + blockIdx.x; wi < nwork; wi += (S360_BLOCK / 64) * gridDim.x) {
+// One (tile, quadrant, segment) work item: phase 2 + delivery + (for the wave that delivers last) the combine.  COH: the head's state and
+// the phase-1 products were written inside the CURRENT launch window by other CUs (k_render / k_render_segs running side by side) — read
+// them device-coherently; false: they come from completed launches (k_render_tail, the mop-up).
+template <bool WITH_DEPTH, bool COH>
+__device__ __forceinline__ void seg_item(const KParams& kp, const S360View* __restrict__ views, const uint32_t* __restrict__ tile_start,
+                                         const uint32_t* __restrict__ list, const float4* __restrict__ recA, float* __restrict__ images,
+                                         float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_max_contrib,
+                                         uint32_t* __restrict__ strip_last, const float* __restrict__ depths, float* __restrict__ depth_maps,
+                                         int depth_mode, const MseEp& ep, float4* __restrict__ surv, uint32_t* __restrict__ surv_count,
+                                         const SegBufs& sg, int nt, uint32_t* __restrict__ dbg, const WaveLds& L, int lane, uint2 item, uint32_t wi,
+                                         uint32_t nwork) {
 #ifdef S360_DBG_TIMING
         const long long t_begin = wall_clock64();
 #endif
-        const uint2 item = sg.seg_info[wi];
         const int t = (int)item.x, wave = (int)(item.y & 3u);
         const uint32_t k = item.y >> 2;
         if ((uint32_t)t >= (uint32_t)nt) {   // corrupt work item: an error word (RasterState.split_errors), never a wild access
             if (lane == 0 && atomicAdd(&sg.header[7], 0x10000u) == 0u) {
                 sg.header[8] = item.x; sg.header[9] = item.y; sg.header[12] = wi; sg.header[13] = nwork;
             }
-            continue;
+            return;
         }
         const uint32_t start = min(tile_start[t], kp.cap), end = min(tile_start[t + 1], kp.cap), n = end - start;
-        if (k < SEG_K0 || k * SEG_LEN >= n || sg.seg_flag[4 * t + wave] != 1u) {
+        if (k < SEG_K0 || k * SEG_LEN >= n || (COH ? ld_dev32(sg.seg_flag + 4 * t + wave) : sg.seg_flag[4 * t + wave]) != 1u) {
             if (lane == 0 && atomicAdd(&sg.header[7], 0x100u) == 0u) {
                 sg.header[8] = item.x; sg.header[9] = item.y; sg.header[10] = n; sg.header[12] = wi; sg.header[13] = nwork;
             }
-            continue;
+            return;
         }
         const size_t u = (size_t)SEG_PER_CHUNK * sg.chunk_start[t] + k;     // the segment's slot
         const int v = t / kp.T, rem = t - v * kp.T;
@@ -2206,23 +2317,27 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(S360
         float T;
         bool head_done;
         {   // the head's state (written by k_render: the previous launch) and the fixed left-to-right product of the segments in front
-            const uint32_t l = sg.part_l[li0];
+            const uint32_t l = COH ? ld_dev32(sg.part_l + li0) : sg.part_l[li0];
             head_done = (l >> 31) != 0u || !inside;
-            T = sg.part_t[li0];
+            T = COH ? ld_devf(sg.part_t + li0) : sg.part_t[li0];
 #pragma unroll 8
-            for (uint32_t kk = SEG_K0; kk < k; ++kk) T = T * sg.part_t[((slot0 + kk) * 4 + wave) * 64 + lane];
+            for (uint32_t kk = SEG_K0; kk < k; ++kk) {
+                const float* q = sg.part_t + ((slot0 + kk) * 4 + wave) * 64 + lane;
+                T = T * (COH ? ld_devf(q) : *q);
+            }
         }
         {
             f2 C01 = f2{0.f, 0.f}, C2D = f2{0.f, 0.f};
             uint32_t last = 0, scount = 0;
             bool done = head_done || T < 0.0001f;    // stopped in an earlier segment (its product took T below the stop threshold)
+            const bool live_in = !done;
             float4* const sv_unit = surv ? surv + 3 * ((size_t)4 * start + (size_t)wave * n) : nullptr;
             composite_segment<WITH_DEPTH, false>(list, recA, depths, start, b0, b1, pxf, pyf, x0, ys0, lane, L, inv_scale, v_near, v_far, depth_mode, T,
                                                  C01, C2D, last, done, sv_unit ? sv_unit + 3 * (size_t)(k * SEG_LEN) : nullptr, scount);
             float* pc = reinterpret_cast<float*>(sg.part_c + li);
             st_devf(pc, C01.x); st_devf(pc + 1, C01.y); st_devf(pc + 2, C2D.x); st_devf(pc + 3, C2D.y);
             st_devf(sg.part_e + li, T);         // transmittance behind the segment (unchanged where the pixel took nothing)
-            st_dev32(sg.part_l + li, last);
+            st_dev32(sg.part_l + li, last | ((live_in && done) ? 0x80000000u : 0u));   // bit 31: the stop test fired INSIDE this segment
             if (lane == 0) st_dev32(sg.part_n + (size_t)u * 4 + wave, scount);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2237,15 +2352,15 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(S360
             dbg[di + 3] = ((uint32_t)t << 12) | (k << 2) | (uint32_t)wave;
         }
 #endif
-        if (arrived + 1u != K - SEG_K0) continue;   // wave-uniform: another segment of this quadrant is still out
+        if (arrived + 1u != K - SEG_K0) return;   // wave-uniform: another segment of this quadrant is still out
         // ---- combine: this wave delivered last
         f2 C01, C2D;
         uint32_t last;
         {
-            const float4 c = sg.part_c[li0];
+            const float4 c = COH ? ld_dev_f4(sg.part_c + li0) : sg.part_c[li0];
             C01 = f2{c.x, c.y}; C2D = f2{c.z, c.w};
-            last = sg.part_l[li0] & 0x7FFFFFFFu;
-            T = sg.part_t[li0];
+            last = (COH ? ld_dev32(sg.part_l + li0) : sg.part_l[li0]) & 0x7FFFFFFFu;
+            T = COH ? ld_devf(sg.part_t + li0) : sg.part_t[li0];
         }
         const float head_T = T;
         uint32_t kstop = SEG_K0;   // the pixel was live in segments [SEG_K0, kstop) (the products only shrink: one change-over)
@@ -2260,7 +2375,7 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(S360
 #pragma unroll
                 for (uint32_t j = 0; j < 4; ++j) {
                     ix[j] = ((slot0 + min(kb + j, K - 1)) * 4 + wave) * 64 + lane;
-                    tq[j] = sg.part_t[ix[j]];      // (phase 1: the previous launch)
+                    tq[j] = COH ? ld_devf(sg.part_t + ix[j]) : sg.part_t[ix[j]];      // (phase 1)
                 }
                 f4v cq[4];
                 float teq[4];
@@ -2293,8 +2408,11 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(S360
                         if (alive) {
                             C01 = C01 + f2{cq[j].x, cq[j].y}; C2D = C2D + f2{cq[j].z, cq[j].w};
                             T = teq[j];
-                            last = plq[j] ? plq[j] : last;
+                            last = (plq[j] & 0x7FFFFFFFu) ? (plq[j] & 0x7FFFFFFFu) : last;
                             kstop = kb + j + 1;
+                            // the segment's own sequential stop decides, not the rounding of the product of products: a
+                            // pixel that stopped inside segment k is dead in every later one, for the forward's sums and the backward's units alike
+                            alive = (plq[j] >> 31) == 0u;
                         }
                         sg.seg_t[ix[j]] = T;                                   // transmittance behind the segment
                     }
@@ -2343,7 +2461,7 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(S360
             if (wm) atomicMax(&tile_max_contrib[t], wm);
             // the backward's units of this quadrant: the head (all of its survivor records once a later segment contributes, else
             // those in front of its own last contributor) and every segment that starts in front of the last contributor
-            if (surv_count) surv_count[4 * t + wave] = wm > SEG_HEAD ? sg.part_n[slot0 * 4 + wave] : sg.seg_cnt[slot0 * 4 + wave];
+            if (surv_count) surv_count[4 * t + wave] = wm > SEG_HEAD ? ld_dev32(sg.part_n + slot0 * 4 + wave) : ld_dev32(sg.seg_cnt + slot0 * 4 + wave);
         }
         for (uint32_t kk = SEG_K0 + (uint32_t)lane; kk < K; kk += 64)      // (one segment per lane: the loads overlap)
             sg.seg_cnt[(slot0 + kk) * 4 + wave] = (surv_count && kk * SEG_LEN < wm) ? ld_dev32(sg.part_n + (slot0 + kk) * 4 + wave) : 0u;
@@ -2386,6 +2504,34 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(S360
             dbg[di + 3] |= 0x80000000u;
         }
 #endif
+}
+
+// The mop-up behind k_render: every work item no phase-2 worker of k_render claimed —
+// none, normally: then this launch reads the item list once and returns.  (Until round 6 this launch did ALL the segment work,
+// strictly after the last tile workgroup: 62 us on the 1 M surface-like cloud behind a 159-us k_render, and no gain at 4 M / 512^2.)
+template <bool WITH_DEPTH>
+__global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(S360_TAIL_WAVES, S360_TAIL_WAVES))) void k_render_tail(KParams kp, const S360View* __restrict__ views, const uint32_t* __restrict__ tile_start,
+                                                            const uint32_t* __restrict__ list, const float4* __restrict__ recA,
+                                                            float* __restrict__ images, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+                                                            uint32_t* __restrict__ tile_max_contrib, uint32_t* __restrict__ strip_last,
+                                                            const float* __restrict__ depths, float* __restrict__ depth_maps, int depth_mode, MseEp ep,
+                                                            float4* __restrict__ surv, uint32_t* __restrict__ surv_count, SegBufs sg, int nt,
+                                                            uint32_t* __restrict__ dbg) {
+    __shared__ __attribute__((aligned(16))) float s_x[S360_BLOCK / 64][68], s_y[S360_BLOCK / 64][68], s_a[S360_BLOCK / 64][68],
+        s_b[S360_BLOCK / 64][68], s_c[S360_BLOCK / 64][68], s_o[S360_BLOCK / 64][68];
+    __shared__ __attribute__((aligned(16))) float2 s_rg[S360_BLOCK / 64][68], s_bz[S360_BLOCK / 64][68];
+    __shared__ __attribute__((aligned(16))) uint32_t s_pos[S360_BLOCK / 64][68];
+    if (sg.header[S360_HDR_SPLIT] == 0u) return;   // no quadrant of this call split
+    const int pwave = threadIdx.x >> 6, lane = threadIdx.x & 63;   // pwave: this wave's LDS slices; its quadrant comes with the work item
+    const WaveLds L{s_x[pwave], s_y[pwave], s_a[pwave], s_b[pwave], s_c[pwave], s_o[pwave], s_rg[pwave], s_bz[pwave], s_pos[pwave]};
+    const uint32_t nwork = sg.header[S360_HDR_SEGWORK];       // (tile, quadrant, segment) items k_render queued
+    // items are dealt STATICALLY, item i to wave slot i mod (4 gridDim) (a ticket counter — one agent-scope atomic per item on ONE
+    // address — let the last wave start 27 us into the kernel)
+    for (uint32_t wi = (uint32_t)pwave * gridDim.x + blockIdx.x; wi < nwork; wi += (S360_BLOCK / 64) * gridDim.x) {
+        uint2 item = sg.seg_info[wi];
+        if (item.y & S360_SEG_CLAIM) continue;       // a phase-2 worker of k_render took it
+        seg_item<WITH_DEPTH, false>(kp, views, tile_start, list, recA, images, final_T, n_contrib, tile_max_contrib, strip_last, depths, depth_maps,
+                                    depth_mode, ep, surv, surv_count, sg, nt, dbg, L, lane, item, wi, nwork);
     }
 }
 
@@ -2695,11 +2841,13 @@ static int forward_impl(const S360Params* prm, const S360View* views, const floa
                    (float4*)(ws + L.seg_c), (float*)(ws + L.seg_t), (uint32_t*)(ws + L.seg_cnt), (uint2*)(ws + L.seg_info), header};
         unsigned long long* cand = prm->header_mirror ? (unsigned long long*)prm->header_mirror + 1 : nullptr;   // word 1 of the mirror
         const SegBufs* sgp = split ? (const SegBufs*)(header + S360_HDR_SEGBUFS) : (const SegBufs*)nullptr;
-        const unsigned p1grid = (unsigned)min((size_t)1024, seg_slots_of(prm));   // phase-1 workers of the split lists, behind the tile workgroups
+        // S360_FLAG_SPLIT_LISTS: the segment work runs INSIDE k_render's launch (phase-1 workers behind the long tiles, phase-2 workers
+        // behind all tiles); k_render_tail behind it takes whatever no phase-2 worker claimed (normally nothing)
+        if (split && hipMemsetAsync(ws + L.seg_info, 0, seg_slots_of(prm) * 4 * 8, st) != hipSuccess) return S360_E_LAUNCH;   // a published work item is non-zero
 #define S360_LAUNCH_RENDER(WD, SP)                                                                                                         \
-    hipLaunchKernelGGL((k_render<WD, SP>), SP ? dim3(nt + p1grid) : rgrid, rblock, 0, st, kp, views, tile_start, list, recA, recB, recC, images, final_T, n_contrib,      \
+    hipLaunchKernelGGL((k_render<WD, SP>), SP ? dim3(nt + S360_P1_GRID + S360_P2_GRID) : rgrid, rblock, 0, st, kp, views, tile_start, list, recA, recB, recC, images, final_T, n_contrib,      \
                        tile_max_contrib, strip_last, dbg, depths, depth_maps, depth_mode, ep, kp.P > 0 ? tile_order : (const uint32_t*)nullptr, \
-                       surv, surv_count, hdr_loss, sgp, chunk_start, cand, nt)
+                       surv, surv_count, hdr_loss, sgp, chunk_start, cand, nt, list, depths)
         if (depth_maps) { if (split) S360_LAUNCH_RENDER(true, true); else S360_LAUNCH_RENDER(true, false); }
         else { if (split) S360_LAUNCH_RENDER(false, true); else S360_LAUNCH_RENDER(false, false); }
 #undef S360_LAUNCH_RENDER
