@@ -519,7 +519,7 @@ int s360_cube2erp_backward(const float* d_erp, const float* grid, float* d_faces
  * (survivor records in front of each 8x8 quadrant's last contributor x 64 pixels).  counts: DEVICE uint64[2], written
  * asynchronously on `stream`.  bench.py derives the work-based VALU fraction of the composites from it. */
 int s360_count_contributions(const S360Params* prm, const void* workspace, size_t workspace_bytes, uint64_t* counts, void* stream);
-/* Second measurement aid: where the backward composite's evaluated (entry, pixel) slots go — counts[26]: [0] slots executed, [1] padding
+/* Second measurement aid: where the backward composite's evaluated (entry, pixel) slots go — counts[32]: [0] slots executed, [1] padding
  * lanes, [2] entry at / behind the pixel's last contributor, [3] splat does not reach the pixel (power > 0 or alpha < 1/255),
  * [4] contributing, [5] slots of skipped four-pixel runs, [6] units, [7] groups, [8..17] executed slots by the unit's contributing
  * fraction (deciles), [18..25] executed runs by how many of the group's records contribute to the run (0, 1-4, 5-8, 9-16, 17-24, 25-32,

@@ -28,3 +28,6 @@ for name in (sys.argv[1:] or ["encoder_like", "surface_like", "uniform"]):
     print("   executed slots by the unit's contributing fraction (deciles 0-10% ... 90-100%):", " ".join(f"{x / e:.1%}" for x in r["by_unit_hit_decile"]))
     tot_runs = sum(r["runs_by_active_records"].values())
     print("   executed four-pixel runs by records (of 64 lanes) contributing to the run:", {k: f"{v / tot_runs:.1%}" for k, v in r["runs_by_active_records"].items()})
+    n = r["records"]
+    print(f"   records {n:,}: reach the quadrant's upper 8x4 half {r['reach_upper_half'] / n:.1%}, lower {r['reach_lower_half'] / n:.1%}, both {r['reach_both_halves'] / n:.1%};"
+          f" a half-wave composite (32 + 32 lanes, 8 runs per iteration) would execute {r['half_wave_iterations'] * 8:,} runs against {e // 256:,} today")

@@ -1112,6 +1112,7 @@ __global__ __launch_bounds__(64) void k_count_bwd_slots(KParams kp, const uint32
     if (n_surv == 0) return;
     const float4* const sv = surv + 3 * ((size_t)4 * start + (size_t)wave * (end - start));
     uint32_t c_pad = 0, c_stop = 0, c_miss = 0, c_hit = 0;
+    uint32_t h_top = 0, h_bot = 0, h_both = 0;    // records whose splat reaches the quadrant's upper / lower 8x4 half (the composites' own box test)
     unsigned long long runs_exec = 0, runs_skip = 0, groups = 0;
     unsigned long long rh[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int64_t top = (int64_t)n_surv - 1; top >= 0; top -= 64) {
@@ -1123,6 +1124,12 @@ __global__ __launch_bounds__(64) void k_count_bwd_slots(KParams kp, const uint32
             a = r[0]; b = r[1]; c = r[2];
         }
         const uint32_t pos = lane_ok ? __float_as_uint(c.z) : 0xFFFFFFFFu;
+        if (lane_ok) {
+            const float ka = -a.w / (2.0f * a.z), kb = -a.w / (2.0f * b.x);
+            const bool ht = box_hit_rt(a.x, a.y, a.z, a.w, b.x, b.y, ka, kb, (float)qx, (float)qy, 7.0f, 3.0f);
+            const bool hb = box_hit_rt(a.x, a.y, a.z, a.w, b.x, b.y, ka, kb, (float)qx, (float)(qy + 4), 7.0f, 3.0f);
+            h_top += ht; h_bot += hb; h_both += ht && hb;
+        }
         const uint32_t pos_min = (uint32_t)__builtin_amdgcn_readlane((int)pos, (int)n - 1);
         const uint4 l4 = *reinterpret_cast<const uint4*>(&s_last[(lane & 15) * 4]);
         const uint32_t qmask = (uint32_t)__ballot(max(max(l4.x, l4.y), max(l4.z, l4.w)) > pos_min) & 0xFFFFu;
@@ -1145,9 +1152,9 @@ __global__ __launch_bounds__(64) void k_count_bwd_slots(KParams kp, const uint32
             ++rh[na == 0 ? 0 : na <= 4 ? 1 : na <= 8 ? 2 : na <= 16 ? 3 : na <= 24 ? 4 : na <= 32 ? 5 : na <= 48 ? 6 : 7];
         }
     }
-    uint32_t tot[4] = {c_pad, c_stop, c_miss, c_hit};
+    uint32_t tot[7] = {c_pad, c_stop, c_miss, c_hit, h_top, h_bot, h_both};
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < 7; ++k)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) tot[k] += (uint32_t)__shfl_xor((int)tot[k], o);
     if (lane == 0) {
@@ -1163,6 +1170,13 @@ __global__ __launch_bounds__(64) void k_count_bwd_slots(KParams kp, const uint32
         const int bin = exec ? min(9, (int)(10ull * tot[3] / exec)) : 0;
         atomicAdd(&out[8 + bin], exec);
         for (int r = 0; r < 8; ++r) atomicAdd(&out[18 + r], rh[r]);
+        // out[26..28]: records reaching the upper half / the lower half / both; out[29]: records; out[30]: 8-run iterations of a
+        // composite that walks the two halves' records side by side, 32 + 32 lanes (max over the halves of ceil(records / 32))
+        atomicAdd(&out[26], (unsigned long long)tot[4]);
+        atomicAdd(&out[27], (unsigned long long)tot[5]);
+        atomicAdd(&out[28], (unsigned long long)tot[6]);
+        atomicAdd(&out[29], (unsigned long long)n_surv);
+        atomicAdd(&out[30], (unsigned long long)max((tot[4] + 31u) / 32u, (tot[5] + 31u) / 32u));
     }
 }
 
@@ -1326,7 +1340,7 @@ extern "C" int s360_count_backward_slots(const S360Params* prm, const void* work
     const int nt = kp.V * kp.T;
     const char* ws = (const char*)workspace;
     hipStream_t st = (hipStream_t)stream_;
-    if (hipMemsetAsync(counts, 0, 26 * sizeof(uint64_t), st) != hipSuccess) return S360_E_LAUNCH;
+    if (hipMemsetAsync(counts, 0, 32 * sizeof(uint64_t), st) != hipSuccess) return S360_E_LAUNCH;
     if (prm->P == 0) return S360_OK;
     hipLaunchKernelGGL(s360::k_count_bwd_slots, dim3(nt * 4), dim3(64), 0, st, kp, (const uint32_t*)(ws + L.tile_start), (const float4*)(ws + L.surv),
                        (const uint32_t*)(ws + L.surv_count), (const uint32_t*)(ws + L.n_contrib), (unsigned long long*)counts);

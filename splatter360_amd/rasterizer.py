@@ -362,14 +362,15 @@ class RasterState:
 
     def count_backward_slots(self) -> dict:
         """s360_count_backward_slots on this (unsplit, training) workspace: where the backward composite's lane x pixel slots go."""
-        out = torch.zeros(26, dtype=torch.int64, device=self.workspace.device)
+        out = torch.zeros(32, dtype=torch.int64, device=self.workspace.device)
         with torch.cuda.device(self.workspace.device):
             stream = C.c_void_p(torch.cuda.current_stream(self.workspace.device).cuda_stream)
             _lib.check(_lib.lib().s360_count_backward_slots(C.byref(self.prm), _ptr(self.workspace), self.layout.total_bytes, _ptr(out), stream),
                        "s360_count_backward_slots")
         c = [int(x) for x in out.cpu().tolist()]
         return dict(executed=c[0], padding=c[1], stopped=c[2], miss=c[3], contributing=c[4], skipped_runs=c[5], units=c[6], groups=c[7],
-                    by_unit_hit_decile=c[8:18], runs_by_active_records=dict(zip(("0", "1-4", "5-8", "9-16", "17-24", "25-32", "33-48", "49-64"), c[18:26])))
+                    by_unit_hit_decile=c[8:18], runs_by_active_records=dict(zip(("0", "1-4", "5-8", "9-16", "17-24", "25-32", "33-48", "49-64"), c[18:26])),
+                    records=c[29], reach_upper_half=c[26], reach_lower_half=c[27], reach_both_halves=c[28], half_wave_iterations=c[30])
 
     def split_errors(self) -> int:
         """header[7] (host read): 0 unless k_render_tail met a corrupt segment work item (it then skips the item; the images of such a
