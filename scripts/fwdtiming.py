@@ -52,6 +52,11 @@ if nseg:
               "| longest item / mean item:", round(p2.max() / p2.mean(), 2))
         b0 = d[4 * nu + 0::4]
         st0 = ((b0 - b0.min()) & 0xFFFFFFFF) / 100.0
+        rel = ((b0 - origin) & 0xFFFFFFFF) / 100.0      # round 6: phase 2 runs inside k_render's launch — starts on k_render's own clock
+        print("  item starts after k_render's first wave: min %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f | last item end %.1f | heads (split units) end: p50 %.1f p90 %.1f max %.1f"
+              % (rel.min(), np.percentile(rel, 10), np.percentile(rel, 50), np.percentile(rel, 90), rel.max(), (rel + p2).max(),
+                 np.percentile(end[flag == 1], 50), np.percentile(end[flag == 1], 90), end[flag == 1].max()))
+        print("  unsplit units end: p50 %.1f p90 %.1f p99 %.1f max %.1f" % tuple(np.percentile(end[flag != 1], q) for q in (50, 90, 99, 100)))
         p2own = d[4 * nu + 1::4] / 100.0
         print("  tail span us (first item start -> last item end)", round((st0 + p2).max(), 1), "| item starts: p50", round(np.percentile(st0, 50), 1), "p90",
               round(np.percentile(st0, 90), 1), "max", round(st0.max(), 1), "| own segment (to arrival) mean/p90/max", round(p2own.mean(), 1),
