@@ -6,7 +6,7 @@
 # Outputs land in gpurun_out/$ROUND/ ; scripts/make_profiles.py then condenses them into profiles/.
 # meta.json stamps the kernel-source hash the counters belong to (bench.py refuses to quote a mismatching profile).
 set -x
-ROUND=${ROUND:-r05}
+ROUND=${ROUND:-r06}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$ROUND
 mkdir -p $O
@@ -29,6 +29,10 @@ S360_RCCL_TEST_W=512 timeout 300 rocprofv3 --kernel-trace --stats --output-forma
 # the stand-alone adapter kernels + fused raw path, and the per-face drop-in training step of the unchanged reference
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/adapter -o adapter -- python $R/scripts/prof_adapter_dropin.py adapter > $O/prof_adapter.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/dropin -o dropin -- python $R/scripts/prof_adapter_dropin.py dropin > $O/prof_dropin.log 2>&1
+# round 6: the 4 M / 512^2 shape with the stress workloads (surface-like: list splitting inside k_render's launch), and the kernel table of
+# the 1 M surface-like step with splitting off and on
+timeout 400 python $R/bench.py --steps 10 --warmup 3 --pano-h 1024 --cpu-baseline 0 --workloads 1 > $O/bench_c5_4m_workloads.json 2> /dev/null
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/surface -o surface -- python $R/scripts/split_diag.py surface_like 10 > $O/split_diag_surface_like.txt 2>&1
 # per-unit timing of both composites (instrumented build; the box is discarded afterwards)
 S360_HIPCC_EXTRA=-DS360_DBG_TIMING python -c "import sys; sys.path.insert(0, '$R'); from splatter360_amd import _lib; _lib.build(force=True)"
 timeout 120 python $R/scripts/bwdtiming.py encoder_like > $O/bwd_unit_timing.txt 2>/dev/null

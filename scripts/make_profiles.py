@@ -2,7 +2,7 @@
 import collections, csv, glob, json, os, shutil, subprocess, sys
 from pathlib import Path
 R = Path(__file__).resolve().parent.parent
-ROUND = os.environ.get("ROUND", "r05")
+ROUND = os.environ.get("ROUND", "r06")
 O = R / "gpurun_out" / ROUND
 P = R / "profiles"
 P.mkdir(exist_ok=True)
@@ -13,7 +13,7 @@ with open(P / f"{ROUND}_bench_kernel_stats.csv", "w") as f:
     for r in rows[:45]:
         w.writerow([r["Name"].split("(")[0][:90], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
 for n in ("bench_fwdbwd.json", "bench_fwd.json", "bench_under_rocprof.json", "bench_eval.json", "bench_c5_4m_fwdbwd.json",
-          "bench_c5_4m_fwd.json", "bench_2rank_gloo_one_gpu.json", "bench_1rank_nccl.json"):
+          "bench_c5_4m_fwd.json", "bench_2rank_gloo_one_gpu.json", "bench_1rank_nccl.json", "bench_c5_4m_workloads.json"):
     if not (O / n).exists():
         continue
     txt = [l for l in (O / n).read_text().strip().splitlines() if l.startswith("{")]
@@ -51,7 +51,7 @@ for n in ("bwd_unit_timing.txt", "bwd_unit_timing_surface_like.txt", "fwd_unit_t
           "fwd_unit_timing_surface_like_unsplit.txt", "rccl_kernel_sequence.txt", "rccl_single_rank.log"):
     if (O / n).exists():
         shutil.copy(O / n, P / f"{ROUND}_{n}")
-for leg in ("rccl", "adapter", "dropin"):      # kernel-stat tables of the side traces: top 30 rows each
+for leg in ("rccl", "adapter", "dropin", "surface"):      # kernel-stat tables of the side traces: top 30 rows each
     fs = glob.glob(str(O / leg / "**" / "*kernel_stats.csv"), recursive=True)
     if fs:
         rr = list(csv.DictReader(open(fs[0])))

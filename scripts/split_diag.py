@@ -12,9 +12,9 @@ from splatter360_amd import _lib, decoder, rasterizer, synthetic
 dev = torch.device("cuda:0")
 name = sys.argv[1] if len(sys.argv) > 1 else "surface_like"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-FW = 512 if name.endswith("_4m") else 256
+FW = 1024 if name.endswith("_16m") else 512 if name.endswith("_4m") else 256
 cloud = {"encoder_like": lambda: synthetic.encoder_like_cloud(512, 1024), "surface_like": lambda: synthetic.surface_like_cloud(512, 1024),
-         "surface_like_4m": lambda: synthetic.surface_like_cloud(1024, 2048), "encoder_like_4m": lambda: synthetic.encoder_like_cloud(1024, 2048),
+         "surface_like_4m": lambda: synthetic.surface_like_cloud(1024, 2048), "surface_like_16m": lambda: synthetic.surface_like_cloud(2048, 4096), "encoder_like_4m": lambda: synthetic.encoder_like_cloud(1024, 2048),
          "uniform": lambda: synthetic.uniform_cloud(1 << 20, seed=0, extent=5.0)}[name]()
 params = [torch.tensor(cloud[k], device=dev) for k in ("means", "covariances", "harmonics", "opacities")]
 ext, K, near, far = decoder.cube_cameras(torch.eye(4, device=dev), 0.1, 10.0)
