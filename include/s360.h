@@ -523,9 +523,7 @@ int s360_count_contributions(const S360Params* prm, const void* workspace, size_
  * lanes, [2] entry at / behind the pixel's last contributor, [3] splat does not reach the pixel (power > 0 or alpha < 1/255),
  * [4] contributing, [5] slots of skipped four-pixel runs, [6] units, [7] groups, [8..17] executed slots by the unit's contributing
  * fraction (deciles), [18..25] executed runs by how many of the group's records contribute to the run (0, 1-4, 5-8, 9-16, 17-24, 25-32,
- * 33-48, 49-64), [26] / [27] / [28] survivor records whose splat reaches the quadrant's upper 8x4 half / its lower half / both (the
- * composites' own box test), [29] records, [30] 8-run iterations of a composite walking the two halves side by side on 32 + 32 lanes,
- * [31] unused.  Training workspaces of unsplit calls only. */
+ * 33-48, 49-64).  Training workspaces of unsplit calls only. */
 int s360_count_backward_slots(const S360Params* prm, const void* workspace, size_t workspace_bytes, uint64_t* counts, void* stream);
 int s360_profile_slots(void);
 const char* s360_profile_slot_name(int slot);

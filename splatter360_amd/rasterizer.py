@@ -361,7 +361,10 @@ class RasterState:
         return int(a), int(b)
 
     def count_backward_slots(self) -> dict:
-        """s360_count_backward_slots on this (unsplit, training) workspace: where the backward composite's lane x pixel slots go."""
+        """s360_count_backward_slots on this (unsplit, training) workspace: where the backward composite's lane x pixel slots go.
+        The library fills 32 words: [0..25] as include/s360.h lists them, [26] / [27] / [28] survivor records whose splat reaches the
+        quadrant's upper 8x4 half / its lower half / both (the composites' own box test), [29] records, [30] 8-run iterations of a
+        composite that would walk the two halves side by side on 32 + 32 lanes (round 6: counted before building it — see DESIGN.md)."""
         out = torch.zeros(32, dtype=torch.int64, device=self.workspace.device)
         with torch.cuda.device(self.workspace.device):
             stream = C.c_void_p(torch.cuda.current_stream(self.workspace.device).cuda_stream)
