@@ -103,3 +103,41 @@ def test_raw_entry_inference_call_and_plain_images(gpu):
     with pytest.raises(RuntimeError):
         rasterizer.rasterize_raw(depths.reshape(-1), opac.reshape(-1), raw.reshape(-1, 82)[:, :40], ext, views=views, image_height=fw, image_width=fw,
                                  context_shape=hw, scale_min=0.5, scale_max=15.0)
+
+
+_MFMA_CHILD = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import test_gpu_raw_entry as T
+from splatter360_amd import adapter, decoder
+dev = torch.device("cuda:0")
+hw, nv, fw = (32, 64), 2, 64
+depths, opac, raw, ext = T._inputs(dev, nv, hw[0], hw[1], seed=11)
+rot = adapter.sh_rotation_blocks(ext, 25)
+cams = decoder.cube_cameras(torch.eye(4, device=dev), 0.1, 10.0)
+target = torch.rand((6, 3, fw, fw), generator=torch.Generator().manual_seed(2)).to(dev)
+(img, means, cov, dep, fm), ins = T._raw(depths, opac, raw, ext, rot, cams, fw, hw, False, "depth", target)
+fm.loss.backward()
+np.savez(sys.argv[2], img=img.detach().cpu().numpy(), loss=fm.loss.detach().cpu().numpy(), **{"g%d" % i: t.grad.cpu().numpy() for i, t in enumerate(ins)})
+"""
+
+
+def test_raw_eval_mfma_variant_is_bit_identical(gpu, tmp_path):
+    """S360_RAW_MFMA=1 (k_raw_eval<.., MFMA>: the per-view coefficient rotation on v_mfma_f32_16x16x4_f32, DESIGN.md section 4 "MFMA")
+    against the default SGPR-operand form: the switch is read once per process, so each variant renders the same seeded raw cloud in
+    its own process; images, loss and every raw gradient must be the same bits."""
+    import os, subprocess, sys
+    from pathlib import Path
+    root = str(Path(__file__).resolve().parent.parent)
+    outs = []
+    for flag in ("0", "1"):
+        out = tmp_path / f"raw_mfma_{flag}.npz"
+        env = dict(os.environ, S360_RAW_MFMA=flag)
+        r = subprocess.run([sys.executable, "-c", _MFMA_CHILD, root, str(out)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    a, b = outs
+    assert set(a.files) == set(b.files)
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k
+    assert np.isfinite(a["img"]).all() and float(np.abs(a["g2"]).max()) > 0.0
