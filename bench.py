@@ -15,7 +15,7 @@ into the composite store unless --fused-loss 0), stitch, backward (+ the gradien
 it every rank holds the summed gradients of all four parameter tensors).  Inputs are resident in HBM before
 the timed region.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -51,8 +51,11 @@ VALU_BOUND = ("render", "render_bwd")   # the two alpha composites: instruction-
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    # 200 timed steps (~155 ms): starting and draining the timed region costs ~0.8 ms whatever its length (the first step's launches
+    # reach an idle device, the closing synchronise) — 20 steps carry 0.04 ms of it each (0.801 ms/step measured against 0.766 at 200,
+    # same box, same minute; VERDICT r05 weak #17: a 15.8-ms timed region)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--mode", choices=("fwdbwd", "fwd", "eval"), default="fwdbwd",
                     help="eval = BASELINE configs[3] shape: 3 target panoramas x 6 faces, colour + depth, forward only")
     ap.add_argument("--pano-h", type=int, default=512, help="context/target ERP height (width = 2h)")
@@ -534,7 +537,7 @@ def main():
         # ---- the same training step on two more clouds of the same size (every tuning decision of rounds 1-3 was taken on the
         # encoder-like cloud alone): SURVEY 8(d)'s uniform-random stress cloud, and a surface-like cloud (what a trained encoder
         # emits: spatially coherent depth, opacity >= 0.9 — the first surface hides most of what lies behind it)
-        k2 = max(3, min(a.steps, 10))
+        k2 = max(3, min(a.steps, 100))    # (round 6: 100 instead of 10 — the fixed cost of a timed region, see --steps)
         res["workloads"] = {}
         for name, make in (("uniform_U[-5,5]^3", lambda: synthetic.uniform_cloud(G, seed=0, extent=5.0)),
                            ("surface_like", lambda: synthetic.surface_like_cloud(pano_h, pano_w, n_context=2, seed=0))):
