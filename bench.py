@@ -669,10 +669,17 @@ def main():
             res["cpu_baseline_torch"] = {"error": repr(e)}
     elif rank == 0:
         res["cpu_baseline"] = None
-    if rank == 0:
-        print(json.dumps(res), flush=True)
     if world > 1 or forced:
         torch.distributed.destroy_process_group()
+    if rank == 0:
+        # the JSON line is the LAST thing on stdout: RCCL prints its version banner through C stdio, which — stdout being a pipe — is
+        # flushed at exit, i.e. behind anything Python printed earlier (seen with one RCCL rank: five banner lines after the JSON line)
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":
