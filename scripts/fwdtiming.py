@@ -69,3 +69,25 @@ if nseg:
                 print("  segments k in [%d,%d): %d items, own-segment mean us %.1f" % (lo, hi, int(m.sum()), p2own[m].mean()))
         for i in np.argsort(-p2)[:6]:
             print("  item tile", int((tag[i] >> 12) & 0x7FFFF), "k", int((tag[i] >> 2) & 0x3FF), "q", int(tag[i] & 3), "us", round(p2[i], 1), "combined", int(comb[i]))
+
+if nseg:
+    # round 6: phase-1 units and the phase-2 worker waves' own start stamps (behind the item records)
+    ns = int(st.prm.max_segments) if int(st.prm.max_segments) else 8 * (int(st.prm.max_instances) // 2048 + 1)
+    base1 = 4 * (nu + 4 * ns)
+    d1 = st._arr(st.layout.keys_alt, base1 + 16 * ns, torch.int32).cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    p1 = d1[base1:].reshape(-1, 4)
+    ok = p1[:, 2] > 0
+    ok &= (((p1[:, 1] - origin) & 0xFFFFFFFF) / 100.0) < 1000.0
+    if ok.any():
+        wg0 = ((p1[ok, 0] - origin) & 0xFFFFFFFF) / 100.0
+        u0 = ((p1[ok, 1] - origin) & 0xFFFFFFFF) / 100.0
+        du = p1[ok, 2] / 100.0
+        pr = lambda x: " ".join("%.1f" % np.percentile(x, q) for q in (0, 10, 50, 90, 100))
+        print("phase-1 (unit, quadrant) records:", int(ok.sum()), "| worker workgroup start (min p10 p50 p90 max):", pr(wg0), "| unit start:", pr(u0),
+              "| unit duration:", pr(du), "| last unit end %.1f" % (u0 + du).max())
+    base2 = 4 * (nu + 8 * ns)
+    d2 = st._arr(st.layout.keys_alt, base2 + 4096, torch.int32).cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    w = ((d2[base2:] - origin) & 0xFFFFFFFF) / 100.0
+    w = w[w < 1000.0]
+    if w.size:
+        print("phase-2 worker waves: %d started, at (min p10 p50 p90 max):" % w.size, " ".join("%.1f" % np.percentile(w, q) for q in (0, 10, 50, 90, 100)))

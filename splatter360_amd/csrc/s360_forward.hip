@@ -1851,6 +1851,9 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(SPLI
             const WaveLds L{s_x[pwave], s_y[pwave], s_a[pwave], s_b[pwave], s_c[pwave], s_o[pwave], s_rg[pwave], s_bz[pwave], s_pos[pwave]};
             const uint32_t nunits = min((uint32_t)(SEG_PER_CHUNK * chunk_start[nt]), sg.n_slots);
             for (uint32_t u = b - n_long; u < nunits; u += (uint32_t)S360_P1_GRID) {
+#ifdef S360_DBG_TIMING
+                const long long t_p1 = wall_clock64();
+#endif
                 const ChunkUnit cu = chunk_unit(tile_start, chunk_start, nt, kp.cap, u / SEG_PER_CHUNK);
                 const uint32_t k = cu.k * SEG_PER_CHUNK + (u % SEG_PER_CHUNK);
                 if (!cu.valid || k < SEG_K0 || k * SEG_LEN >= cu.n || cu.n < SEG_HEAD + SEG_MIN_REST) continue;   // block-uniform
@@ -1869,6 +1872,13 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(SPLI
                 st_devf(sg.part_t + ((size_t)u * 4 + pwave) * 64 + lane, (done1 && inside1) ? 0.0f : T1);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (lane == 0) __hip_atomic_fetch_add(&sg.seg_arrive[4 * t1 + pwave], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef S360_DBG_TIMING
+                if (lane == 0) {   // phase-1 records behind the item records: (workgroup start, unit start, unit duration, tile << 8 | k)
+                    const size_t di = 4 * ((size_t)4 * nt + (size_t)4 * sg.n_slots + (size_t)u * 4 + pwave);
+                    dbg[di] = (uint32_t)t_begin; dbg[di + 1] = (uint32_t)t_p1; dbg[di + 2] = (uint32_t)(wall_clock64() - t_p1);
+                    dbg[di + 3] = ((uint32_t)t1 << 8) | k;
+                }
+#endif
             }
             return;
         }
@@ -1880,6 +1890,9 @@ __global__ __launch_bounds__(S360_BLOCK) __attribute__((amdgpu_waves_per_eu(SPLI
             const uint32_t n_items_cap = sg.n_slots * 4u;
             const uint32_t stride = (S360_BLOCK / 64) * (uint32_t)S360_P2_GRID;
             uint32_t wi = (uint32_t)pwave * (uint32_t)S360_P2_GRID + (b - (uint32_t)nt - (uint32_t)S360_P1_GRID);
+#ifdef S360_DBG_TIMING
+            if (lane == 0) dbg[4 * ((size_t)4 * nt + (size_t)8 * sg.n_slots) + wi] = (uint32_t)t_begin;    // when this worker wave started
+#endif
             uint32_t spins = 0;
             while (wi < n_items_cap) {
                 uint2 item = ld_dev64(sg.seg_info + wi);         // every lane loads the same address: one request, one value
