@@ -817,23 +817,37 @@ __global__ __launch_bounds__(TS_BLOCK) void k_tile_scan(const uint32_t* __restri
     if (threadIdx.x == 0) { lds_max = 0; lds_nlong = 0; }
     __syncthreads();
     uint32_t carry = 0, mx = 0, ccarry = 0;
-    for (int b = 0; b < nt; b += TS_BLOCK) {
-        const int i = b + threadIdx.x;
-        const uint32_t v = i < nt ? tile_count[i] : 0u;
-        mx = max(mx, v);
+    // two adjacent tiles per thread: the headline's 1 536 tiles are ONE sweep (two block scans, one round of global loads) instead of two
+    for (int b = 0; b < nt; b += 2 * TS_BLOCK) {
+        const int i0 = b + 2 * (int)threadIdx.x, i1 = i0 + 1;
+        uint32_t v0 = 0u, v1 = 0u;
+        if (i1 < nt) {
+            const uint2 vv = *reinterpret_cast<const uint2*>(tile_count + i0);   // (i0 is even: 8-byte aligned)
+            v0 = vv.x; v1 = vv.y;
+        } else if (i0 < nt) {
+            v0 = tile_count[i0];
+        }
+        mx = max(mx, max(v0, v1));
         uint32_t tot;
-        const uint32_t ex = block_exclusive_scan<TS_BLOCK / 64>(v, lds, tot);
+        const uint32_t ex0 = block_exclusive_scan<TS_BLOCK / 64>(v0 + v1, lds, tot), ex1 = ex0 + v0;
         // the sort kernels see list lengths clamped to the binning capacity
-        const uint32_t nclamp = min(carry + ex + v, cap) - min(carry + ex, cap);
-        const uint32_t nch = nclamp > SORT_SHORT ? (nclamp + SORT_CHUNK - 1) / SORT_CHUNK : 0u;
-        if (nch) atomicAdd(&lds_nlong, 1u);
+        const uint32_t nc0 = min(carry + ex0 + v0, cap) - min(carry + ex0, cap), nc1 = min(carry + ex1 + v1, cap) - min(carry + ex1, cap);
+        const uint32_t nch0 = nc0 > SORT_SHORT ? (nc0 + SORT_CHUNK - 1) / SORT_CHUNK : 0u;
+        const uint32_t nch1 = nc1 > SORT_SHORT ? (nc1 + SORT_CHUNK - 1) / SORT_CHUNK : 0u;
+        if (nch0 || nch1) atomicAdd(&lds_nlong, (nch0 ? 1u : 0u) + (nch1 ? 1u : 0u));
         uint32_t ctot;
-        const uint32_t cex = block_exclusive_scan<TS_BLOCK / 64>(nch, lds, ctot);
-        if (i < nt) {
-            tile_start[i] = carry + ex;
-            tile_cursor[i] = 0;
-            tile_max_contrib[i] = 0;
-            chunk_start[i] = ccarry + cex;
+        const uint32_t cex0 = block_exclusive_scan<TS_BLOCK / 64>(nch0 + nch1, lds, ctot), cex1 = cex0 + nch0;
+        if (i0 < nt) {
+            tile_start[i0] = carry + ex0;
+            tile_cursor[i0] = 0;
+            tile_max_contrib[i0] = 0;
+            chunk_start[i0] = ccarry + cex0;
+        }
+        if (i1 < nt) {
+            tile_start[i1] = carry + ex1;
+            tile_cursor[i1] = 0;
+            tile_max_contrib[i1] = 0;
+            chunk_start[i1] = ccarry + cex1;
         }
         carry += tot;
         ccarry += ctot;
