@@ -12,12 +12,12 @@ O=$R/gpurun_out/$ROUND
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python -c "import sys, json; sys.path.insert(0, '$R'); from splatter360_amd import _lib; print(json.dumps(dict(source_hash=_lib.source_hash(), gaussians=1048576, face=256)))" > $O/meta.json
-timeout 400 python $R/bench.py --steps 20 --warmup 5 > $O/bench_fwdbwd.json 2> $O/bench_fwdbwd.err
-timeout 200 python $R/bench.py --steps 20 --warmup 5 --mode fwd --cpu-baseline 0 --workloads 0 > $O/bench_fwd.json 2> $O/bench_fwd.err
+timeout 400 python $R/bench.py > $O/bench_fwdbwd.json 2> $O/bench_fwdbwd.err
+timeout 200 python $R/bench.py --mode fwd --cpu-baseline 0 --workloads 0 > $O/bench_fwd.json 2> $O/bench_fwd.err
 timeout 200 python $R/bench.py --steps 10 --warmup 3 --mode eval --cpu-baseline 0 > $O/bench_eval.json 2> /dev/null
 timeout 300 python $R/bench.py --steps 10 --warmup 3 --pano-h 1024 --cpu-baseline 0 --workloads 0 > $O/bench_c5_4m_fwdbwd.json 2> /dev/null
 S360_DIST_BACKEND=gloo S360_FORCE_DEVICE=0 timeout 300 python $R/bench.py --gpus 2 --steps 4 --warmup 2 --cpu-baseline 0 --workloads 0 > $O/bench_2rank_gloo_one_gpu.json 2> /dev/null
-timeout 300 python $R/bench.py --steps 20 --warmup 5 --cpu-baseline 0 --workloads 0 --single-rank-rccl 1 > $O/bench_1rank_nccl.json 2> $O/bench_1rank_nccl.err
+timeout 300 python $R/bench.py --cpu-baseline 0 --workloads 0 --single-rank-rccl 1 > $O/bench_1rank_nccl.json 2> $O/bench_1rank_nccl.err
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python $R/bench.py --steps 20 --warmup 5 --cpu-baseline 0 --forward-figure 0 --workloads 0 > $O/bench_under_rocprof.json 2>/dev/null
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -o pmc -- python $R/bench.py --steps 3 --warmup 1 --cpu-baseline 0 --forward-figure 0 --workloads 0 > /dev/null 2>&1
